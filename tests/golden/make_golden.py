@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING the reference's PointSelector.
+
+Run in the build container only (needs /root/reference); the GPU box never has the reference,
+it only reads the committed `.npz` files.  Usage:  python tests/golden/make_golden.py
+
+What is stored is data only: the inputs handed to the reference class through its attribute
+protocol (/root/reference/select_parameters.py:146-157, 282-293) and the outputs it left in
+`kernel_params / mean_func / cov_func / acq_func_eval` plus the index returned by
+`lower_confidence_bound()` (/root/reference/point_selector.py:42-102, 197-207).
+
+Harness rules: never write bytecode into the reference tree; run with cwd =
+a scratch dir that has `plots/` (tune_kernel writes plots/ARD_*.png, point_selector.py:146,163);
+silence the reference's prints.
+"""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import scipy  # noqa: E402
+
+from bayesian_optimisation_amd.synthetic import make_problem  # noqa: E402
+
+_scratch = tempfile.mkdtemp(prefix="gpbo_golden_")
+os.makedirs(os.path.join(_scratch, "plots"), exist_ok=True)
+os.chdir(_scratch)
+
+from point_selector import PointSelector  # noqa: E402  (the reference)
+
+# the reference's own domains and length-scale search grids (select_parameters.py:62-75);
+# regenerated here as data, the driver file itself executes at import and cannot be imported.
+T1 = np.linspace(1, 14, 50)
+T2 = np.linspace(10, 90, 50)
+TR = np.linspace(0.1, 2.0, 50)
+W56 = np.linspace(0.01, 0.9, 50)
+L1 = np.linspace(0.5, 10, 50)
+L2 = np.linspace(2, 100, 50)
+LTHETA = np.linspace(0.1, 2, 20)
+
+VERS = dict(numpy_version=np.__version__, scipy_version=scipy.__version__)
+
+
+def run_reference(X, y, Xs, feature_domain, length_scales=None, preset_ls=None, explore=None,
+                  name="G", iteration=0, expect_error=None):
+    ps = PointSelector()
+    ps.name = name
+    ps.iteration = iteration
+    ps.measured_pts = X
+    ps.measured_vals = y
+    ps.feature_domain = list(feature_domain)
+    ps.predicted_pts = Xs
+    ps.length_scales = length_scales
+    if preset_ls is not None:
+        ps.kernel_params = np.asarray(preset_ls, dtype=np.float64)
+        ps.tune_kernel = lambda: None  # instance override: keeps the preset length scales
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        try:
+            ps.update_surrogate()
+            idx = ps.lower_confidence_bound() if explore is None else ps.lower_confidence_bound(explore)
+        except Exception as e:  # noqa: BLE001
+            if expect_error is None:
+                raise
+            out["error"] = np.array(type(e).__name__)
+            return out, ps
+    assert expect_error is None, "expected the reference to raise"
+    acq = ps.acq_func_eval.ravel()
+    top2 = np.sort(acq)[-2:]
+    out.update(kernel_params=np.asarray(ps.kernel_params, dtype=np.float64),
+               mean_func=ps.mean_func, cov_func=ps.cov_func, acq_func_eval=ps.acq_func_eval,
+               index=np.asarray(idx), top2_gap=np.array(top2[1] - top2[0]),
+               n_max_ties=np.array(int(np.sum(acq == acq.max()))))
+    return out, ps
+
+
+def nlml_grid_reference(X, y, length_scales):
+    """The float32 -log marginal likelihood grid exactly as tune_kernel builds it
+    (point_selector.py:111-156), evaluated through the reference's own kernel_rbf."""
+    ps = PointSelector()
+    ps.measured_pts = np.asarray(X)
+    ps.measured_vals = np.asarray(y)
+    two = len(length_scales) == 2
+    if two:
+        a1, a2 = length_scales[0], length_scales[1]
+        g = np.zeros((len(a1), len(a2)), dtype=np.float32)
+        cells = [((i, j), np.array([a1[i], a2[j]])) for i in range(len(a1)) for j in range(len(a2))]
+    else:
+        g = np.zeros(len(length_scales), dtype=np.float32)
+        cells = [((i,), np.array([length_scales[i]])) for i in range(len(length_scales))]
+    with np.errstate(all="ignore"):
+        for ij, kp in cells:
+            ps.kernel_params = kp
+            rbf = ps.kernel_rbf(ps.measured_pts, ps.measured_pts)
+            inv = np.linalg.inv(rbf)
+            det = np.linalg.det(rbf)
+            g[ij] = 0.5 * (ps.measured_vals.T @ inv @ ps.measured_vals + np.log(det)
+                           + len(ps.measured_pts) * np.log(2 * np.pi))
+    return g
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **VERS, **arrs)
+    print(f"wrote {name}.npz  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+def grid2(a, b):
+    return np.array([[u, v] for u in a for v in b], dtype=np.float64)
+
+
+def synth_y2(X, rng):
+    """Smooth 2-D bowl + noise on the T1/T2 domain, objective-like magnitudes (hundreds)."""
+    return 300.0 * ((X[:, 0] - 5.2) / 13.0) ** 2 + 200.0 * ((X[:, 1] - 35.0) / 80.0) ** 2 \
+        + 50.0 + 5.0 * rng.standard_normal(len(X))
+
+
+def main():
+    # ---- G1: the C1-shaped full path (d=2, N=32, ARD 50x50) at M=32x32 and M=50x50
+    rng = np.random.default_rng(101)
+    pick = rng.choice(2500, size=32, replace=False)
+    X = np.stack([T1[pick // 50], T2[pick % 50]], 1)
+    y = synth_y2(X, rng)
+    ls = np.array([L1, L2])
+    for tag, (a, b) in dict(m32=(np.linspace(1, 14, 32), np.linspace(10, 90, 32)), m50=(T1, T2)).items():
+        Xs = grid2(a, b)
+        out, _ = run_reference(X, y, Xs, [len(a), len(b)], length_scales=ls, name=np.array(["T1", "T2"]))
+        save(f"g1_{tag}", X=X, y=y, Xs=Xs, feature_domain=np.array([len(a), len(b)]),
+             length_scales=ls, nlogml=nlml_grid_reference(X, y, ls), **out)
+
+    # ---- G2: 1-D paths. N=1 (midpoint branch, 1e10-scale y), N=5 and N=20 with ltheta / l1 grids
+    rng = np.random.default_rng(202)
+    for tag, dom, lsg, n, yscale in [("n1_tr", TR, L1, 1, 1e10), ("n5_a", W56, LTHETA, 5, 1e3),
+                                     ("n20_tr", TR, L1, 20, 1e3), ("n12_a", W56, LTHETA, 12, 1.0)]:
+        pick = rng.choice(50, size=n, replace=False)
+        X = dom[pick].reshape(n, 1)
+        y = yscale * (1.0 + (X[:, 0] - dom[20]) ** 2 + 0.05 * rng.standard_normal(n))
+        Xs = dom.reshape(50, 1)
+        out, _ = run_reference(X, y, Xs, [50], length_scales=lsg, name="A1")
+        extra = {} if n == 1 else dict(nlogml=nlml_grid_reference(X, y, lsg))
+        save(f"g2_{tag}", X=X, y=y, Xs=Xs, feature_domain=np.array([50]), length_scales=lsg, **out, **extra)
+
+    # ---- G3: 2-D N=1 midpoint branch
+    X = np.array([[5.2, 15.7]])
+    y = np.array([1e10])
+    out, _ = run_reference(X, y, grid2(T1, T2), [50, 50], length_scales=np.array([L1, L2]),
+                           name=np.array(["T1", "T2"]))
+    save("g3_n1_2d", X=X, y=y, Xs=grid2(T1, T2), feature_domain=np.array([50, 50]),
+         length_scales=np.array([L1, L2]), **out)
+
+    # ---- G4: tie cases
+    # (a) tiny preset length scale: k* == 0 everywhere off the data -> 2,500-way tie -> index [0 0]
+    rng = np.random.default_rng(404)
+    X = np.array([[1.13, 10.7], [7.77, 55.5], [13.1, 88.8]])  # off-grid points
+    y = np.array([3.0, -2.0, 1.0])
+    out, _ = run_reference(X, y, grid2(T1, T2), [50, 50], preset_ls=[1e-3, 1e-3])
+    save("g4_tie_tiny_ls", X=X, y=y, Xs=grid2(T1, T2), feature_domain=np.array([50, 50]), **out)
+    # (b) duplicated observation rows (K singular up to the jitter)
+    pick = rng.choice(2500, size=6, replace=False)
+    X = np.stack([T1[pick // 50], T2[pick % 50]], 1)
+    X = np.concatenate([X, X[:2]], 0)
+    y = synth_y2(X, rng)
+    out, _ = run_reference(X, y, grid2(T1, T2), [50, 50], preset_ls=[3.0, 20.0])
+    save("g4_dup_rows", X=X, y=y, Xs=grid2(T1, T2), feature_domain=np.array([50, 50]), **out)
+    # (c) N=2 ARD: the float32 nlogml grid has exact ties; first row-major minimum wins
+    X = np.array([[T1[10], T2[12]], [T1[30], T2[40]]])
+    y = np.array([120.0, 80.0])
+    ls = np.array([L1, L2])
+    out, _ = run_reference(X, y, grid2(T1, T2), [50, 50], length_scales=ls, name=np.array(["T1", "T2"]))
+    save("g4_ard_n2", X=X, y=y, Xs=grid2(T1, T2), feature_domain=np.array([50, 50]), length_scales=ls,
+         nlogml=nlml_grid_reference(X, y, ls), **out)
+
+    # ---- G5: preset-ls d=8 (Sobol inputs, RFF y): the configs' arithmetic at oracle-feasible M
+    for N, M in [(64, 1024), (512, 4096), (2048, 4096)]:
+        X, y, Xs, ls = make_problem(N, M, 8)
+        out, _ = run_reference(X, y, Xs, [M], preset_ls=ls)
+        save(f"g5_d8_n{N}_m{M}", N=np.array(N), M=np.array(M), d=np.array(8), ls=ls, y=y, **out)
+
+    # ---- G6: d=16 N=256 M=2048 (the fp32 config's shape; oracle in fp64)
+    X, y, Xs, ls = make_problem(256, 2048, 16)
+    out, _ = run_reference(X, y, Xs, [2048], preset_ls=ls)
+    save("g6_d16_n256_m2048", N=np.array(256), M=np.array(2048), d=np.array(16), ls=ls, y=y, **out)
+
+    # ---- G7: shape-coincidence quirk N == M: kernel_rbf adds 1e-4 on the diagonal of K(X, X*)
+    X, y, Xs, ls = make_problem(64, 64, 3)
+    out, ps = run_reference(X, y, Xs, [64], preset_ls=ls)
+    save("g7_n_eq_m", X=X, y=y, Xs=Xs, ls=ls, feature_domain=np.array([64]),
+         cov_meas_pred_diag=np.diag(ps.cov_meas_pred).copy(), **out)
+
+    # ---- G8: NaN in the observations -> acquisition all NaN -> IndexError (point_selector.py:207)
+    X, y, Xs, ls = make_problem(16, 128, 2)
+    y = y.copy()
+    y[3] = np.nan
+    out, _ = run_reference(X, y, Xs, [128], preset_ls=ls, expect_error=True)
+    save("g8_nan", X=X, y=y, Xs=Xs, ls=ls, feature_domain=np.array([128]), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,96 @@
+"""Pin the CPU oracle (oracle/gp_oracle.py) against the golden vectors that were produced by
+running the reference's PointSelector (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from bayesian_optimisation_amd.synthetic import make_problem
+from oracle import gp_oracle as O
+
+# fp64 tolerances of SURVEY.md §8(a): |dmu| <= 1e-9*max(1,|y|inf), |dsigma| <= 1e-8, |dacq| <= 1e-8
+# (the literal route reproduces the reference's arithmetic, so it is held an order tighter)
+
+
+def _check(out, g, tight=1.0):
+    ys = max(1.0, float(np.max(np.abs(g["y"]))))
+    assert np.max(np.abs(out["mean_func"] - g["mean_func"])) <= 1e-9 * ys * tight
+    assert np.max(np.abs(out["cov_func"] - g["cov_func"])) <= 1e-8 * tight
+    assert np.max(np.abs(out["acq_func_eval"] - g["acq_func_eval"])) <= 1e-8 * ys * tight
+    assert out["mean_func"].shape == g["mean_func"].shape
+    if g["top2_gap"] > 1e-7 * ys or g["n_max_ties"] > 1:
+        assert np.array_equal(out["index"], g["index"])
+
+
+@pytest.mark.parametrize("name", ["g1_m32", "g1_m50", "g4_ard_n2"])
+def test_full_path_2d_with_ard(golden, name):
+    g = golden(name)
+    out = O.select_next(g["X"], g["y"], g["Xs"], g["feature_domain"], length_scales=g["length_scales"])
+    assert np.array_equal(out["kernel_params"], g["kernel_params"])
+    assert out["nlogml"].dtype == np.float32
+    np.testing.assert_allclose(out["nlogml"], g["nlogml"], rtol=1e-6, atol=0)
+    _check(out, g, tight=0.1)
+
+
+@pytest.mark.parametrize("name", ["g2_n1_tr", "g2_n5_a", "g2_n20_tr", "g2_n12_a", "g3_n1_2d"])
+def test_1d_and_midpoint_branches(golden, name):
+    g = golden(name)
+    out = O.select_next(g["X"], g["y"], g["Xs"], g["feature_domain"], length_scales=g["length_scales"])
+    assert np.array_equal(out["kernel_params"], g["kernel_params"])
+    if "nlogml" in g:
+        np.testing.assert_allclose(out["nlogml"], g["nlogml"], rtol=1e-6)
+    _check(out, g, tight=0.1)
+
+
+def test_tie_tiny_length_scale_returns_first_index(golden):
+    g = golden("g4_tie_tiny_ls")
+    out = O.select_next(g["X"], g["y"], g["Xs"], g["feature_domain"], kernel_params=g["kernel_params"])
+    assert g["n_max_ties"] == 2500 and np.array_equal(g["index"], [0, 0])
+    assert np.array_equal(out["index"], [0, 0])
+    assert np.array_equal(out["acq_func_eval"], g["acq_func_eval"])
+
+
+def test_duplicated_rows(golden):
+    g = golden("g4_dup_rows")
+    for route in ("literal", "chol"):
+        out = O.select_next(g["X"], g["y"], g["Xs"], g["feature_domain"],
+                            kernel_params=g["kernel_params"], route=route)
+        _check(out, g)
+
+
+@pytest.mark.parametrize("name", ["g5_d8_n64_m1024", "g5_d8_n512_m4096", "g5_d8_n2048_m4096",
+                                  "g6_d16_n256_m2048"])
+@pytest.mark.parametrize("route", ["literal", "chol"])
+def test_preset_ls_high_dim(golden, name, route):
+    g = golden(name)
+    X, y, Xs, ls = make_problem(int(g["N"]), int(g["M"]), int(g["d"]))
+    assert np.array_equal(y, g["y"]) and np.array_equal(ls, g["ls"])
+    out = O.select_next(X, y, Xs, [int(g["M"])], kernel_params=ls, route=route)
+    _check(out, g)
+    assert np.array_equal(out["index"], g["index"])
+
+
+def test_shape_coincidence_quirk(golden):
+    g = golden("g7_n_eq_m")
+    k = O.kernel_rbf(g["X"], g["Xs"], g["ls"])
+    np.testing.assert_allclose(np.diag(k), g["cov_meas_pred_diag"], rtol=0, atol=1e-15)
+    for route in ("literal", "chol"):
+        out = O.select_next(g["X"], g["y"], g["Xs"], g["feature_domain"], kernel_params=g["ls"], route=route)
+        _check(out, g)
+
+
+def test_nan_raises_index_error(golden):
+    g = golden("g8_nan")
+    assert str(g["error"]) == "IndexError"
+    with pytest.raises(IndexError):
+        O.select_next(g["X"], g["y"], g["Xs"], g["feature_domain"], kernel_params=g["ls"])
+
+
+def test_prior_var_constant():
+    assert O.PRIOR_VAR == (1.0 + 1e-4) + 1e-6
+
+
+def test_ei_closed_form_limits():
+    mu = np.array([0.0, 1.0, -1.0, 0.5])
+    sg = np.array([1.0, 0.0, 0.0, 1e-300])
+    ei = O.expected_improvement(mu, sg, f_best=0.0)
+    assert abs(ei[0] - 1.0 / np.sqrt(2 * np.pi)) < 1e-15
+    assert ei[1] == 0.0 and ei[2] == 1.0 and ei[3] == 0.0
