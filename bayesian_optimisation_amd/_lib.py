@@ -1,0 +1,85 @@
+"""ctypes binding of libgpbo.so (the C ABI declared in include/gpbo.h).
+
+The library is built in-tree by `bayesian_optimisation_amd/csrc/build.sh` (or `__graft_entry__.build()`).
+There is NO fallback: if the shared object is missing or a symbol is absent, loading raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpbo.so")
+
+GPBO_OK = 0
+ACQ_LCB = 0
+ACQ_EI = 1
+NPAD = 128
+CHUNK_GRANULE = 512
+MAX_D = 16
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_f64 = C.c_double
+
+# name -> (restype, argtypes); mirrors include/gpbo.h one to one
+SIGNATURES = {
+    "gpbo_version": (C.c_int, []),
+    "gpbo_strerror": (C.c_char_p, [C.c_int]),
+    "gpbo_padded_n": (_i64, [_i64]),
+    "gpbo_kxx_f64": (C.c_int, [_p, _i64, _i32, _p, _f64, _f64, _p, _i64, _p]),
+    "gpbo_potrf_f64": (C.c_int, [_p, _i64, _p, _p, _p]),
+    "gpbo_trtri_f64": (C.c_int, [_p, _p, _i64, _p, _p, _p]),
+    "gpbo_alpha_f64": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p]),
+    "gpbo_factorise_workspace_bytes": (_i64, [_i64]),
+    "gpbo_factorise_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _f64, _f64, _i64, _p, _p, _p, _p, _p, _i64, _p]),
+    "gpbo_kstar_mu_f64": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _f64, _i64, _p, _i64, _p, _p]),
+    "gpbo_posterior_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "gpbo_posterior_acq_f64": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _i32, _f64, _f64, _f64,
+                                         _i64, _i64, _p, _p, _p, _p, _p, _i64, _p]),
+    "gpbo_acq_workspace_bytes": (_i64, []),
+    "gpbo_acq_argmax_f64": (C.c_int, [_p, _p, _i64, _i32, _f64, _f64, _i64, _p, _p, _p, _i64, _p]),
+    "gpbo_nlml_grid_max_n": (C.c_int, []),
+    "gpbo_nlml_grid_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p, _p]),
+    "gpbo_gemm_f64": (C.c_int, [_i32, _i64, _i64, _i64, _f64, _p, _i64, _i64, _p, _i64, _i64, _f64, _p, _i64, _i64,
+                                _i32, _i32, _p]),
+}
+
+_lib = None
+
+
+class GpboError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgpbo.so and attach prototypes.  Raises if the library or any symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GpboError(
+            f"{LIB_PATH} not found: build it with bayesian_optimisation_amd/csrc/build.sh "
+            "(there is no CPU fallback for the acquisition path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != GPBO_OK:
+        msg = load().gpbo_strerror(status).decode()
+        raise GpboError(f"{what}: {msg} (status {status})")
+
+
+def host_f64(arr):
+    """ctypes pointer to a contiguous fp64 host array (kept alive by the caller)."""
+    import numpy as np
+
+    a = np.ascontiguousarray(arr, dtype=np.float64)
+    return a, a.ctypes.data_as(C.c_void_p)

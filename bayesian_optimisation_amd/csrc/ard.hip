@@ -1,0 +1,103 @@
+// ARD length-scale grid search: -log marginal likelihood of every grid cell.
+//
+// Replaces PointSelector.tune_kernel / eval_log_marginal (/root/reference/point_selector.py:104-163):
+//     rbf = kernel_rbf(X, X)            (1e-4 jitter only, :116,193)
+//     nlml = 0.5 * (y^T inv(rbf) y + log(det(rbf)) + N log(2 pi))          (:117-119), stored as float32
+// One workgroup per grid cell.  The reference's inv + det become one Cholesky of the bordered matrix
+//     [ K   y ]
+//     [ y^T 0 ]
+// carried N columns deep in LDS: the last row then holds (L^-1 y)^T, the last pivot is -y^T K^-1 y,
+// and log det K = 2 sum log L_ii.  NumPy's det is sign * exp(logdet) (LAPACK getrf), so the reference's
+// underflow of det to 0 (-> -inf cells for N >~ 100) is reproduced by evaluating log(exp(logdet)).
+#include "gpbo_internal.h"
+
+#include <cmath>
+#include <limits>
+
+namespace {
+
+constexpr int ARD_MAX_N = 128;
+
+__global__ __launch_bounds__(256) void nlml_grid_kernel(const double *__restrict__ X, const double *__restrict__ y,
+                                                        int N, int d, const double *__restrict__ ls_cells,
+                                                        double jitter, float *__restrict__ out) {
+    extern __shared__ double lds[];
+    const int ld = N + 2;              // bordered matrix is (N+1) x (N+1); +1 more to break bank strides
+    double *a = lds;                   // (N+1) x ld
+    double *xs = a + (N + 1) * ld;     // N x d
+    double *il2 = xs + N * d;          // d
+    double *diag = il2 + d;            // N   (L_ii)
+    const int tid = threadIdx.x;
+    const double *ls = ls_cells + (int64_t)blockIdx.x * d;
+
+    for (int e = tid; e < N * d; e += 256) xs[e] = X[e];
+    if (tid < d) il2[tid] = 1.0 / (ls[tid] * ls[tid]);
+    __syncthreads();
+    const int n1 = N + 1;
+    for (int e = tid; e < n1 * n1; e += 256) {
+        const int r = e / n1, q = e - r * n1;
+        double v = 0.0;
+        if (q <= r) {
+            if (r < N) {
+                double acc = 0.0;
+                for (int k = 0; k < d; ++k) {
+                    const double diff = xs[r * d + k] - xs[q * d + k];
+                    acc = fma(diff * diff, il2[k], acc);
+                }
+                v = exp(-0.5 * acc);
+                if (r == q) v += jitter;
+            } else if (q < N) {
+                v = y[q];
+            }
+        }
+        a[r * ld + q] = v;
+    }
+    for (int c = 0; c < N; ++c) {
+        __syncthreads();
+        const double piv = a[c * ld + c];
+        const double dd = sqrt(piv);   // NaN for a negative pivot: propagates to the cell's value
+        const double inv = 1.0 / dd;
+        if (tid == 0) diag[c] = dd;
+        // trailing update on rows r > c, columns c < q <= r of the bordered matrix
+        const int m = N - c;           // rows c+1 .. N
+        for (int e = tid; e < m * m; e += 256) {
+            const int r = c + 1 + e / m, q = c + 1 + (e - (e / m) * m);
+            if (q <= r) {
+                const double lr = a[r * ld + c] * inv;
+                const double lq = a[q * ld + c] * inv;
+                a[r * ld + q] = fma(-lr, lq, a[r * ld + q]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double logdet = 0.0;
+        for (int c = 0; c < N; ++c) logdet += log(diag[c]);
+        logdet *= 2.0;
+        const double quad = -a[N * ld + N];
+        const double logdet_ref = log(exp(logdet));  // the reference takes log of an underflowing det
+        const double nlml = 0.5 * (quad + logdet_ref + (double)N * 1.8378770664093453);  // log(2 pi)
+        out[blockIdx.x] = (float)nlml;
+    }
+}
+
+}  // namespace
+
+extern "C" int gpbo_nlml_grid_max_n(void) { return ARD_MAX_N; }
+
+extern "C" int gpbo_nlml_grid_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells,
+                                  int64_t G, double jitter, float *out, void *stream) {
+    if (!X || !y || !ls_cells || !out || N < 1 || N > ARD_MAX_N || d < 1 || d > GPBO_MAX_D || G < 1 ||
+        G > (1 << 30))
+        return GPBO_ERR_ARG;
+    const size_t lds_bytes = sizeof(double) * ((size_t)(N + 1) * (N + 2) + (size_t)N * d + d + N);
+    if (lds_bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nlml_grid_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(nlml_grid_kernel, dim3((unsigned)G), dim3(256), lds_bytes, gpbo_stream(stream), X, y, (int)N,
+                       (int)d, ls_cells, jitter, out);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}

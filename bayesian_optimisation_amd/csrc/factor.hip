@@ -1,0 +1,265 @@
+// Factorisation of K + sigma^2 I: blocked right-looking Cholesky, block-recursive
+// inverse of the Cholesky factor, and alpha = K^-1 y.
+//
+// The reference inverts cov_meas with np.linalg.inv (/root/reference/point_selector.py:89) and uses
+// the inverse twice (:90-91).  Here K = L L^T once per BO step; U = L^-T is formed explicitly so the
+// per-candidate variance becomes a dense triangular product on the matrix cores
+// (sigma_acq.hip) instead of a sequential triangular solve per candidate.
+#include "gpbo_internal.h"
+
+int gpbo_gemm_launch(int transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                     int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double beta, double *C,
+                     int64_t ldc, int64_t strideC, int batch, int lower_only, hipStream_t st);
+
+namespace {
+
+constexpr int NB = GPBO_NB;  // 64
+constexpr int LDS_LD = NB + 1;
+
+// ---------------------------------------------------------------------------------------------
+// Diagonal block: unblocked Cholesky of one 64x64 block in LDS + its triangular inverse.
+// One workgroup of 256 threads.  a[][] holds the running Schur complement, l[][] the factor.
+// One barrier per column: column c of a[][] is never written again after step c, the scaled column
+// goes to l[][].
+// The inverse is built by doubling: blocks of size s are inverted, then
+// W21 = -W22 * (L21 * W11) joins two of them into a block of size 2s.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ K, int64_t ld, int jb,
+                                                         double *__restrict__ dinv, int32_t *__restrict__ info) {
+    __shared__ double a[NB * LDS_LD];
+    __shared__ double l[NB * LDS_LD];
+    __shared__ double w[NB * LDS_LD];
+    __shared__ double t[NB * LDS_LD];
+    const int tid = threadIdx.x;
+    double *Kd = K + ((int64_t)jb * NB) * ld + (int64_t)jb * NB;
+
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        a[r * LDS_LD + c] = (c <= r) ? Kd[(int64_t)r * ld + c] : 0.0;
+        l[r * LDS_LD + c] = 0.0;
+        w[r * LDS_LD + c] = 0.0;
+    }
+    for (int c = 0; c < NB; ++c) {
+        __syncthreads();
+        const double piv = a[c * LDS_LD + c];
+        if (!(piv > 0.0) || !(piv < 1.0e300)) {  // non-positive, NaN or Inf pivot
+            if (tid == 0) atomicCAS(info, 0, jb * NB + c + 1);
+        }
+        const double dd = sqrt(piv);
+        const double inv = 1.0 / dd;
+        // trailing update of the lower triangle: a[r][q] -= (a[r][c]/d) * (a[q][c]/d),  c < q <= r
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int r = e >> 6, q = e & 63;
+            if (q > c && r >= q) {
+                const double lr = a[r * LDS_LD + c] * inv;
+                const double lq = a[q * LDS_LD + c] * inv;
+                a[r * LDS_LD + q] = fma(-lr, lq, a[r * LDS_LD + q]);
+            }
+        }
+        if (tid < NB) {
+            if (tid == c) l[c * LDS_LD + c] = dd;
+            else if (tid > c) l[tid * LDS_LD + c] = a[tid * LDS_LD + c] * inv;
+        }
+    }
+    __syncthreads();
+    // write L back (lower triangle incl. diagonal)
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        if (c <= r) Kd[(int64_t)r * ld + c] = l[r * LDS_LD + c];
+    }
+    // inverse: size-1 blocks
+    if (tid < NB) w[tid * LDS_LD + tid] = 1.0 / l[tid * LDS_LD + tid];
+    for (int s = 1; s < NB; s <<= 1) {
+        __syncthreads();
+        // T = L21 * W11 for every pair; pair p covers rows/cols [2ps, 2ps+2s)
+        const int npairs = NB / (2 * s);
+        for (int e = tid; e < npairs * s * s; e += 256) {
+            const int p = e / (s * s), rem = e - p * s * s;
+            const int i = rem / s, j = rem - i * s;
+            const int o = 2 * p * s;
+            double sum = 0.0;
+            for (int m = j; m < s; ++m) sum = fma(l[(o + s + i) * LDS_LD + o + m], w[(o + m) * LDS_LD + o + j], sum);
+            t[(o + s + i) * LDS_LD + o + j] = sum;
+        }
+        __syncthreads();
+        // W21 = -W22 * T
+        for (int e = tid; e < npairs * s * s; e += 256) {
+            const int p = e / (s * s), rem = e - p * s * s;
+            const int i = rem / s, j = rem - i * s;
+            const int o = 2 * p * s;
+            double sum = 0.0;
+            for (int m = 0; m <= i; ++m) sum = fma(w[(o + s + i) * LDS_LD + o + s + m], t[(o + s + m) * LDS_LD + o + j], sum);
+            w[(o + s + i) * LDS_LD + o + j] = -sum;
+        }
+    }
+    __syncthreads();
+    double *dv = dinv + (int64_t)jb * NB * NB;
+    for (int e = tid; e < NB * NB; e += 256) dv[e] = w[(e >> 6) * LDS_LD + (e & 63)];
+}
+
+// W <- block-diagonal of dinv, zero elsewhere.   grid (Np/64, Np/64), block 256.
+__global__ __launch_bounds__(256) void init_w_kernel(const double *__restrict__ dinv, double *__restrict__ W,
+                                                     int64_t Np) {
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    double *Wb = W + ((int64_t)bi * NB) * Np + (int64_t)bj * NB;
+    const double *dv = dinv + (int64_t)bi * NB * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        Wb[(int64_t)r * Np + c] = (bi == bj) ? dv[e] : 0.0;
+    }
+}
+
+// U = W^T restricted to the upper triangle (W is lower triangular): 64x64 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_upper_kernel(const double *__restrict__ W, double *__restrict__ U,
+                                                              int64_t Np) {
+    __shared__ double tile[NB * LDS_LD];
+    const int bi = blockIdx.y, bj = blockIdx.x;  // output tile (bi, bj) of U = input tile (bj, bi) of W
+    double *Ub = U + ((int64_t)bi * NB) * Np + (int64_t)bj * NB;
+    if (bj < bi) {  // strictly below the diagonal: zeros
+        for (int e = threadIdx.x; e < NB * NB; e += 256) Ub[(int64_t)(e >> 6) * Np + (e & 63)] = 0.0;
+        return;
+    }
+    const double *Wb = W + ((int64_t)bj * NB) * Np + (int64_t)bi * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) tile[(e >> 6) * LDS_LD + (e & 63)] = Wb[(int64_t)(e >> 6) * Np + (e & 63)];
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        double v = tile[c * LDS_LD + r];
+        if (bi == bj && c < r) v = 0.0;
+        Ub[(int64_t)r * Np + c] = v;
+    }
+}
+
+// tmp_i = sum_{m<=i} U[m][i] y_m   (= (L^-1 y)_i).  One thread per i, coalesced across i.
+__global__ __launch_bounds__(256) void utv_kernel(const double *__restrict__ U, const double *__restrict__ y,
+                                                  int64_t N, int64_t Np, double *__restrict__ tmp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Np) return;
+    double s = 0.0;
+    const int64_t mend = (i < N ? i : N - 1);
+    for (int64_t m = 0; m <= mend; ++m) s = fma(U[m * Np + i], y[m], s);
+    tmp[i] = s;
+}
+
+// alpha_m = sum_{i>=m} U[m][i] tmp_i.  One wave per row m, lanes stride over i, fixed-order reduce.
+__global__ __launch_bounds__(256) void uv_kernel(const double *__restrict__ U, const double *__restrict__ tmp,
+                                                 int64_t N, int64_t Np, double *__restrict__ alpha) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= Np) return;
+    double s = 0.0;
+    if (m < N) {
+        for (int64_t i = (m & ~63LL) + lane; i < Np; i += 64)
+            if (i >= m) s = fma(U[m * Np + i], tmp[i], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) alpha[m] = (m < N) ? s : 0.0;
+}
+
+__global__ void zero_i32_kernel(int32_t *p) { *p = 0; }
+
+}  // namespace
+
+extern "C" int gpbo_potrf_f64(double *Kp, int64_t Np, double *dinv, int32_t *info, void *stream) {
+    if (!Kp || !dinv || !info || Np < GPBO_NPAD || Np % GPBO_NPAD) return GPBO_ERR_ARG;
+    hipStream_t st = gpbo_stream(stream);
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(1), 0, st, info);
+    const int nb = (int)(Np / NB);
+    for (int j = 0; j < nb; ++j) {
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, Kp, Np, j, dinv, info);
+        GPBO_CHECK_LAUNCH();
+        const int64_t rest = Np - (int64_t)(j + 1) * NB;
+        if (rest <= 0) break;
+        double *panel = Kp + (int64_t)(j + 1) * NB * Np + (int64_t)j * NB;  // [rest x 64]
+        // panel <- panel * inv(L_jj)^T      (in place: each 64x64 tile is read whole before it is written)
+        int rc = gpbo_gemm_launch(1, rest, NB, NB, 1.0, panel, Np, 0, dinv + (int64_t)j * NB * NB, NB, 0, 0.0, panel,
+                                  Np, 0, 1, 0, st);
+        if (rc != GPBO_OK) return rc;
+        // trailing lower triangle -= panel * panel^T
+        double *trail = Kp + (int64_t)(j + 1) * NB * Np + (int64_t)(j + 1) * NB;
+        rc = gpbo_gemm_launch(1, rest, rest, NB, -1.0, panel, Np, 0, panel, Np, 0, 1.0, trail, Np, 0, 1, 1, st);
+        if (rc != GPBO_OK) return rc;
+    }
+    return GPBO_OK;
+}
+
+int gpbo_launch_transpose_upper(const double *W, int64_t Np, double *U, hipStream_t st) {
+    dim3 grid((unsigned)(Np / NB), (unsigned)(Np / NB));
+    hipLaunchKernelGGL(transpose_upper_kernel, grid, dim3(256), 0, st, W, U, Np);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
+extern "C" int gpbo_trtri_f64(const double *L, const double *dinv, int64_t Np, double *U, double *work,
+                              void *stream) {
+    if (!L || !dinv || !U || !work || Np < GPBO_NPAD || Np % GPBO_NPAD) return GPBO_ERR_ARG;
+    hipStream_t st = gpbo_stream(stream);
+    double *W = work;
+    double *T = U;  // scratch until the final transpose
+    dim3 g2((unsigned)(Np / NB), (unsigned)(Np / NB));
+    hipLaunchKernelGGL(init_w_kernel, g2, dim3(256), 0, st, dinv, W, Np);
+    GPBO_CHECK_LAUNCH();
+    for (int64_t s = NB; s < Np; s <<= 1) {
+        const int64_t full = Np / (2 * s);       // complete pairs (s, s)
+        const int64_t rem = Np - full * 2 * s;   // what is left after them
+        const int64_t stride = 2 * s * (Np + 1);
+        if (full > 0) {
+            // T21 = L21 * W11 ; W21 = -W22 * T21      (block (p): rows o+s.., cols o.., o = 2ps)
+            int rc = gpbo_gemm_launch(0, s, s, s, 1.0, L + s * Np, Np, stride, W, Np, stride, 0.0, T + s * Np, Np,
+                                      stride, (int)full, 0, st);
+            if (rc != GPBO_OK) return rc;
+            rc = gpbo_gemm_launch(0, s, s, s, -1.0, W + s * Np + s, Np, stride, T + s * Np, Np, stride, 0.0,
+                                  W + s * Np, Np, stride, (int)full, 0, st);
+            if (rc != GPBO_OK) return rc;
+        }
+        if (rem > s) {  // ragged last pair: W11 is s x s, W22 is m2 x m2 with m2 = rem - s < s
+            const int64_t o = full * 2 * s, m2 = rem - s;
+            const double *L21 = L + (o + s) * Np + o;
+            int rc = gpbo_gemm_launch(0, m2, s, s, 1.0, L21, Np, 0, W + o * Np + o, Np, 0, 0.0, T + (o + s) * Np + o, Np,
+                                      0, 1, 0, st);
+            if (rc != GPBO_OK) return rc;
+            rc = gpbo_gemm_launch(0, m2, s, m2, -1.0, W + (o + s) * Np + o + s, Np, 0, T + (o + s) * Np + o, Np, 0, 0.0,
+                                  W + (o + s) * Np + o, Np, 0, 1, 0, st);
+            if (rc != GPBO_OK) return rc;
+        }
+    }
+    return gpbo_launch_transpose_upper(W, Np, U, st);
+}
+
+extern "C" int gpbo_alpha_f64(const double *U, const double *y, int64_t N, int64_t Np, double *tmp, double *alpha,
+                              void *stream) {
+    if (!U || !y || !tmp || !alpha || N < 1 || Np < N || Np % GPBO_NPAD) return GPBO_ERR_ARG;
+    hipStream_t st = gpbo_stream(stream);
+    hipLaunchKernelGGL(utv_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, U, y, N, Np, tmp);
+    hipLaunchKernelGGL(uv_kernel, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, st, U, tmp, N, Np, alpha);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
+extern "C" int64_t gpbo_factorise_workspace_bytes(int64_t Np) {
+    // L [Np*Np] + trtri work [Np*Np] + dinv [Np*64] + tmp [Np]
+    return (int64_t)sizeof(double) * (2 * Np * Np + Np * NB + Np);
+}
+
+extern "C" int gpbo_factorise_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_host,
+                                  double jitter1, double jitter2, int64_t Np, double *Kp, double *U, double *alpha,
+                                  int32_t *info, void *work, int64_t work_bytes, void *stream) {
+    if (!X || !y || !Kp || !U || !alpha || !info || !work) return GPBO_ERR_ARG;
+    if (Np != gpbo_padded_n(N)) return GPBO_ERR_ARG;
+    if (work_bytes < gpbo_factorise_workspace_bytes(Np)) return GPBO_ERR_WORKSPACE;
+    hipStream_t st = gpbo_stream(stream);
+    double *L = reinterpret_cast<double *>(work);
+    double *W = L + Np * Np;
+    double *dinv = W + Np * Np;
+    double *tmp = dinv + Np * NB;
+    int rc = gpbo_kxx_f64(X, N, d, ls_host, jitter1, jitter2, Kp, Np, stream);
+    if (rc != GPBO_OK) return rc;
+    if (hipMemcpyAsync(L, Kp, sizeof(double) * Np * Np, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return GPBO_ERR_LAUNCH;
+    rc = gpbo_potrf_f64(L, Np, dinv, info, stream);
+    if (rc != GPBO_OK) return rc;
+    rc = gpbo_trtri_f64(L, dinv, Np, U, W, stream);
+    if (rc != GPBO_OK) return rc;
+    return gpbo_alpha_f64(U, y, N, Np, tmp, alpha, stream);
+}

@@ -1,0 +1,134 @@
+// Strided-batched fp64 GEMM on the gfx950 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// Serves the factorisation only: the Cholesky panel solve and trailing
+// SYRK/GEMM update, and the block-recursive triangular inverse.  None of this exists in the
+// reference, which calls np.linalg.inv (/root/reference/point_selector.py:89).
+//
+// C_b = alpha * A_b * op(B_b) + beta * C_b, all row-major.
+//   workgroup = 256 threads = 4 waves in a 2x2 arrangement, 64x64 tile of C, BK = 16;
+//   wave tile 32x32 = 2x2 MFMA tiles, accumulators 4 x d4 = 32 VGPRs.
+// LDS images are chosen so that staging is a straight, coalesced copy of the global layout:
+//   A  [M x K] row-major -> As[m][k], row stride 17 doubles (ds_read_b64 conflict-free: lanes
+//                           l and l+16 of a 32-lane group read k and k+1 of 16 different rows)
+//   B  [K x N] row-major -> Bs[k][n], row stride 80 doubles (lanes 16-31 land 32 banks away)
+//   B' [N x K] row-major -> As-style image [n][k], stride 17.
+#include "gpbo_internal.h"
+
+namespace {
+
+constexpr int TM = 64, TN = 64, BK = 16;
+constexpr int LDA_S = 17;  // As[m][k] / Bt[n][k] row stride (doubles)
+constexpr int LDB_S = 80;  // Bs[k][n] row stride (doubles)
+
+template <int TRANSB>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int64_t K, double alpha,
+                                                        const double *__restrict__ A, int64_t lda, int64_t strideA,
+                                                        const double *__restrict__ B, int64_t ldb, int64_t strideB,
+                                                        double beta, double *__restrict__ C, int64_t ldc,
+                                                        int64_t strideC, int lower_only) {
+    const int bx = blockIdx.x, by = blockIdx.y;  // bx: column tile, by: row tile
+    if (lower_only && bx > by) return;
+    __shared__ double As[TM * LDA_S];
+    __shared__ double Bs[(TRANSB ? TN * LDA_S : BK * LDB_S)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    A += (int64_t)blockIdx.z * strideA + (int64_t)by * TM * lda;
+    B += (int64_t)blockIdx.z * strideB;
+    C += (int64_t)blockIdx.z * strideC + (int64_t)by * TM * ldc + (int64_t)bx * TN;
+    if (TRANSB) B += (int64_t)bx * TN * ldb; else B += (int64_t)bx * TN;
+
+    d4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    // staging indices: A-style tile = 64 rows x 16 k: thread -> row tid/4, 4 doubles at k = (tid%4)*4
+    const int ar = tid >> 2, ak = (tid & 3) * 4;
+    // B (no-trans) tile = 16 k-rows x 64 cols: thread -> k-row tid/16, 4 doubles at col (tid%16)*4
+    const int bk = tid >> 4, bn = (tid & 15) * 4;
+
+    for (int64_t k0 = 0; k0 < K; k0 += BK) {
+        const d2_t *ap = reinterpret_cast<const d2_t *>(A + (int64_t)ar * lda + k0 + ak);
+        d2_t a0 = ap[0], a1 = ap[1];
+        d2_t b0, b1;
+        if (TRANSB) {
+            const d2_t *bp = reinterpret_cast<const d2_t *>(B + (int64_t)ar * ldb + k0 + ak);
+            b0 = bp[0]; b1 = bp[1];
+        } else {
+            const d2_t *bp = reinterpret_cast<const d2_t *>(B + (k0 + bk) * ldb + bn);
+            b0 = bp[0]; b1 = bp[1];
+        }
+        __syncthreads();  // previous tile fully consumed
+        As[ar * LDA_S + ak + 0] = a0.x; As[ar * LDA_S + ak + 1] = a0.y;
+        As[ar * LDA_S + ak + 2] = a1.x; As[ar * LDA_S + ak + 3] = a1.y;
+        if (TRANSB) {
+            Bs[ar * LDA_S + ak + 0] = b0.x; Bs[ar * LDA_S + ak + 1] = b0.y;
+            Bs[ar * LDA_S + ak + 2] = b1.x; Bs[ar * LDA_S + ak + 3] = b1.y;
+        } else {
+            *reinterpret_cast<d2_t *>(&Bs[bk * LDB_S + bn]) = b0;
+            *reinterpret_cast<d2_t *>(&Bs[bk * LDB_S + bn + 2]) = b1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[(wr * 32 + i * 16 + l15) * LDA_S + kk + l4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bf[j] = TRANSB ? Bs[(wc * 32 + j * 16 + l15) * LDA_S + kk + l4]
+                               : Bs[(kk + l4) * LDB_S + wc * 32 + j * 16 + l15];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64_16x16x4(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr * 32 + i * 16 + l4 + 4 * r;
+                const int col = wc * 32 + j * 16 + l15;
+                double *cp = C + (int64_t)row * ldc + col;
+                double v = alpha * acc[i][j][r];
+                if (beta != 0.0) v = fma(beta, *cp, v);
+                *cp = v;
+            }
+}
+
+}  // namespace
+
+int gpbo_gemm_launch(int transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                     int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double beta, double *C,
+                     int64_t ldc, int64_t strideC, int batch, int lower_only, hipStream_t st) {
+    if (M <= 0 || N <= 0 || batch <= 0) return GPBO_OK;
+    if (!A || !B || !C || M % TM || N % TN || K % BK || K <= 0 || (lda & 1) || (ldb & 1)) return GPBO_ERR_ARG;
+    if (((uintptr_t)A | (uintptr_t)B) & 15) return GPBO_ERR_ARG;
+    if (N / TN > 65535 || M / TM > 65535 || batch > 65535) return GPBO_ERR_ARG;
+    dim3 grid((unsigned)(N / TN), (unsigned)(M / TM), (unsigned)batch);
+    if (transB)
+        hipLaunchKernelGGL(gemm_f64_kernel<1>, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, strideA, B, ldb,
+                           strideB, beta, C, ldc, strideC, lower_only);
+    else
+        hipLaunchKernelGGL(gemm_f64_kernel<0>, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, strideA, B, ldb,
+                           strideB, beta, C, ldc, strideC, lower_only);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
+extern "C" int gpbo_gemm_f64(int32_t transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A,
+                             int64_t lda, int64_t strideA, const double *B, int64_t ldb, int64_t strideB,
+                             double beta, double *C, int64_t ldc, int64_t strideC, int32_t batch,
+                             int32_t lower_only, void *stream) {
+    return gpbo_gemm_launch(transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch,
+                            lower_only, gpbo_stream(stream));
+}

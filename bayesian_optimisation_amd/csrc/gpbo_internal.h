@@ -1,0 +1,27 @@
+// Internal declarations shared by the HIP translation units of libgpbo (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gpbo.h"
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+#define GPBO_NB 64 /* Cholesky / triangular-inverse block size */
+
+#define GPBO_CHECK_LAUNCH()                                  \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return GPBO_ERR_LAUNCH; \
+    } while (0)
+
+static inline hipStream_t gpbo_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// fp64 MFMA 16x16x4: lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15];
+// result register r of lane l is C[row = (l>>4) + 4r][col = l&15].
+__device__ __forceinline__ d4_t mfma_f64_16x16x4(double a, double b, d4_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// launchers implemented in the individual .hip files (host side, enqueue only)
+int gpbo_launch_transpose_upper(const double *W, int64_t Np, double *U, hipStream_t st);

@@ -1,0 +1,362 @@
+// Posterior variance + acquisition + arg-max, fused.
+//
+// Replaces, for every candidate c,
+//     Sigma = K** - K*x inv K*x^T ; cov_func = sqrt(|diag Sigma|)        point_selector.py:91,98
+//     acq   = explore * cov_func - mean_func ; argwhere(acq == amax)[0]   point_selector.py:204,207
+// The reference forms the full M x M matrix; only its diagonal is ever used, and
+//     diag_c = prior_var - |v_c|^2,   v_c = L^-1 k_c = U^T k_c,   U = L^-T (upper triangular).
+// V = KsT^T * U is a dense triangular product: it runs on v_mfma_f64_16x16x4_f64 and V itself is
+// never stored - each 256 x 128 block of V is squared and row-summed out of the accumulators.
+//
+// Workgroup = 512 threads = 8 waves, owns 256 candidates end to end:
+//   for each 128-column block jb of V:   k runs over [0, 128*(jb+1))  (U is upper triangular)
+//       16-deep k tiles: KsT tile [16 x 256] and U tile [16 x 128] staged global -> VGPR -> LDS,
+//       double-buffered in LDS (one barrier per k tile), MFMA 4x4 tiles of 16x16 per wave;
+//       inside the diagonal block, 16x16 tiles of U that lie wholly below the diagonal are skipped
+//   epilogue: row-sum of squares -> sigma -> mean from the per-slice partials -> LCB / EI -> optional
+//   dense stores -> block arg-max carrying (value, lowest index).
+// Waves w and w+4 share a SIMD; they are given the two column halves of the block so that when the
+// left half runs out of non-zero U tiles on the diagonal the right half has the matrix pipe alone.
+#include "gpbo_internal.h"
+
+#include <limits>
+
+namespace {
+
+constexpr int BM = 256, BN = 128, BK = 16;
+constexpr int LDA = BM + 16;  // padded so lanes l and l+16 (k, k+1) of a ds_read_b64 group hit disjoint banks
+constexpr int LDB = BN + 16;
+constexpr int A_TILE = BK * LDA;  // 4352 doubles
+constexpr int B_TILE = BK * LDB;  // 2304 doubles
+constexpr int STAGE = A_TILE + B_TILE;
+
+__device__ __forceinline__ bool better(double v2, int64_t i2, double v, int64_t i) {
+    return (v2 > v) || (v2 == v && i2 < i);
+}
+
+__device__ __forceinline__ double acquisition(int kind, double mu, double sigma, double p0, double p1) {
+    if (kind == GPBO_ACQ_LCB) return p0 * sigma - mu;
+    // Expected improvement for minimisation: imp = f_best - mu - xi
+    const double imp = p0 - mu - p1;
+    if (!(sigma > 0.0)) return (sigma == 0.0) ? fmax(imp, 0.0) : sigma;  // sigma NaN propagates
+    const double z = imp / sigma;
+    const double cdf = 0.5 * erfc(-z * 0.70710678118654752440);
+    const double pdf = exp(-0.5 * z * z) * 0.39894228040143267794;
+    return imp * cdf + sigma * pdf;
+}
+
+__global__ __launch_bounds__(512) void sigma_acq_kernel(
+    const double *__restrict__ KsT, int64_t ldk, const double *__restrict__ U, int Np,
+    const double *__restrict__ mu_part, int nsl, int64_t Mc, double prior_var, int acq_kind, double p0, double p1,
+    int64_t idx_base, double *__restrict__ mu_out, double *__restrict__ sigma_out, double *__restrict__ acq_out,
+    double *__restrict__ part_val, int64_t *__restrict__ part_idx, unsigned long long *__restrict__ nan_count) {
+    __shared__ double smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid & 3, wc = wid >> 2;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t cand0 = (int64_t)blockIdx.x * BM;
+
+    // staging coordinates (16-byte chunks)
+    const int a_row = tid >> 7, a_c = (tid & 127) * 2;  // rows a_row + 4r, r = 0..3
+    const int b_row = tid >> 6, b_c = (tid & 63) * 2;   // rows b_row + 8r, r = 0..1
+    const double *a_src = KsT + (int64_t)a_row * ldk + cand0 + a_c;
+    const double *b_src = U + (int64_t)b_row * Np + b_c;
+
+    d4_t acc[4][4];
+    double ss[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+            ss[i][j] = 0.0;
+        }
+
+    const int nJ = Np / BN;
+    d2_t ra[4], rb[2];
+
+    auto gload = [&](int jb, int kt) {
+        const double *ap = a_src + (int64_t)kt * BK * ldk;
+        const double *bp = b_src + (int64_t)kt * BK * Np + jb * BN;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ra[r] = *reinterpret_cast<const d2_t *>(ap + (int64_t)(4 * r) * ldk);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) rb[r] = *reinterpret_cast<const d2_t *>(bp + (int64_t)(8 * r) * Np);
+    };
+    auto sstore = [&](int buf) {
+        double *As = smem + buf * STAGE;
+        double *Bs = As + A_TILE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<d2_t *>(&As[(a_row + 4 * r) * LDA + a_c]) = ra[r];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) *reinterpret_cast<d2_t *>(&Bs[(b_row + 8 * r) * LDB + b_c]) = rb[r];
+    };
+
+    int jb = 0, kt = 0, cur = 0;
+    gload(0, 0);
+    sstore(0);
+    __syncthreads();
+    while (true) {
+        const int kt_end = (jb + 1) * (BN / BK);  // k tiles of this column block
+        int njb = jb, nkt = kt + 1;
+        if (nkt == kt_end) { njb = jb + 1; nkt = 0; }
+        const bool has_next = njb < nJ;
+        if (has_next) gload(njb, nkt);
+
+        const double *As = smem + cur * STAGE;
+        const double *Bs = As + A_TILE;
+        // first 16-column tile of this wave that still has non-zero rows of U in this k tile
+        int ni_min = kt - jb * (BN / BK) - wc * 4;
+        ni_min = ni_min < 0 ? 0 : ni_min;
+        if (ni_min < 4) {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 4) {
+                double af[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) af[mi] = As[(kk + l4) * LDA + wr * 64 + mi * 16 + l15];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    if (ni >= ni_min) {
+                        const double bf = Bs[(kk + l4) * LDB + wc * 64 + ni * 16 + l15];
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf, acc[mi][ni]);
+                    }
+                }
+            }
+        }
+        if (kt + 1 == kt_end) {  // column block finished: fold |V|^2 into the row sums
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ss[mi][r] = fma(acc[mi][ni][r], acc[mi][ni][r], ss[mi][r]);
+                    acc[mi][ni] = d4_t{0.0, 0.0, 0.0, 0.0};
+                }
+        }
+        if (!has_next) break;
+        sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        jb = njb;
+        kt = nkt;
+    }
+
+    // ---- row sums: across the 16 lanes that share a candidate row, then across the two column halves
+    __syncthreads();
+    double *red = smem;  // [2][256]
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = ss[mi][r];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            if (l15 == 0) red[wc * BM + wr * 64 + mi * 16 + l4 + 4 * r] = v;
+        }
+    __syncthreads();
+
+    __shared__ double s_val[4];
+    __shared__ int64_t s_idx[4];
+    if (tid < BM) {
+        const int64_t c = cand0 + tid;  // chunk-local candidate
+        const bool valid = c < Mc;
+        const double ssq = red[tid] + red[BM + tid];
+        double mu = 0.0;
+        for (int s = 0; s < nsl; ++s) mu += mu_part[(int64_t)s * ldk + c];
+        const double var = prior_var - ssq;
+        const double sigma = sqrt(fabs(var));  // abs, then sqrt: point_selector.py:98
+        const double acq = acquisition(acq_kind, mu, sigma, p0, p1);
+        if (valid) {
+            if (mu_out) mu_out[c] = mu;
+            if (sigma_out) sigma_out[c] = sigma;
+            if (acq_out) acq_out[c] = acq;
+        }
+        const bool is_nan = valid && (acq != acq);
+        const unsigned long long nan_mask = __ballot(is_nan);
+        if (lane == 0 && nan_mask) atomicAdd(nan_count, (unsigned long long)__popcll(nan_mask));
+        double bv = (valid && !is_nan) ? acq : -std::numeric_limits<double>::infinity();
+        int64_t bi = (valid && !is_nan) ? idx_base + c : std::numeric_limits<int64_t>::max();
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int64_t oi = __shfl_xor(bi, off);
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = s_val[0];
+        int64_t bi = s_idx[0];
+        for (int w = 1; w < 4; ++w)
+            if (better(s_val[w], s_idx[w], bv, bi)) { bv = s_val[w]; bi = s_idx[w]; }
+        part_val[blockIdx.x] = bv;
+        part_idx[blockIdx.x] = bi;
+    }
+}
+
+// Final reduction over the per-workgroup partials of all chunks: one workgroup.
+__global__ __launch_bounds__(256) void argmax_finish_kernel(const double *__restrict__ part_val,
+                                                            const int64_t *__restrict__ part_idx, int64_t nparts,
+                                                            const unsigned long long *__restrict__ nan_count,
+                                                            gpbo_result *__restrict__ result) {
+    __shared__ double s_val[4];
+    __shared__ int64_t s_idx[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    double bv = -std::numeric_limits<double>::infinity();
+    int64_t bi = std::numeric_limits<int64_t>::max();
+    for (int64_t p = tid; p < nparts; p += 256)
+        if (better(part_val[p], part_idx[p], bv, bi)) { bv = part_val[p]; bi = part_idx[p]; }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int64_t oi = __shfl_xor(bi, off);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better(s_val[w], s_idx[w], bv, bi)) { bv = s_val[w]; bi = s_idx[w]; }
+        result->best_val = bv;
+        result->best_idx = bi;
+        result->nan_count = (int64_t)*nan_count;
+        result->reserved = 0;
+    }
+}
+
+// Acquisition + arg-max over dense mu / sigma that are already on the device (used when the caller asks
+// for a second acquisition on the same posterior, e.g. lower_confidence_bound(explore != 4)).
+__global__ __launch_bounds__(256) void acq_argmax_kernel(const double *__restrict__ mu, const double *__restrict__ sigma,
+                                                         int64_t M, int acq_kind, double p0, double p1, int64_t idx_base,
+                                                         double *__restrict__ acq_out, double *__restrict__ part_val,
+                                                         int64_t *__restrict__ part_idx,
+                                                         unsigned long long *__restrict__ nan_count) {
+    __shared__ double s_val[4];
+    __shared__ int64_t s_idx[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    double bv = -std::numeric_limits<double>::infinity();
+    int64_t bi = std::numeric_limits<int64_t>::max();
+    unsigned long long nans = 0;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + tid; c < M; c += (int64_t)gridDim.x * 256) {
+        const double a = acquisition(acq_kind, mu[c], sigma[c], p0, p1);
+        if (acq_out) acq_out[c] = a;
+        if (a != a) ++nans;
+        else if (better(a, idx_base + c, bv, bi)) { bv = a; bi = idx_base + c; }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int64_t oi = __shfl_xor(bi, off);
+        nans += __shfl_xor(nans, off);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi;
+        if (nans) atomicAdd(nan_count, nans);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better(s_val[w], s_idx[w], bv, bi)) { bv = s_val[w]; bi = s_idx[w]; }
+        part_val[blockIdx.x] = bv;
+        part_idx[blockIdx.x] = bi;
+    }
+}
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct PosteriorLayout {
+    int64_t kst_off, mup_off, pval_off, pidx_off, nan_off, total, nparts_cap;
+};
+
+PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M) {
+    PosteriorLayout L;
+    const int64_t nchunks = (M + chunk - 1) / chunk;
+    L.nparts_cap = nchunks * (chunk / BM);
+    int64_t off = 0;
+    L.kst_off = off; off += align_up((int64_t)sizeof(double) * Np * chunk, 256);
+    L.mup_off = off; off += align_up((int64_t)sizeof(double) * (Np / 128) * chunk, 256);
+    L.pval_off = off; off += align_up((int64_t)sizeof(double) * L.nparts_cap, 256);
+    L.pidx_off = off; off += align_up((int64_t)sizeof(int64_t) * L.nparts_cap, 256);
+    L.nan_off = off; off += 256;
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+
+extern "C" int64_t gpbo_posterior_workspace_bytes(int64_t Np, int64_t chunk, int64_t M) {
+    if (Np < GPBO_NPAD || Np % GPBO_NPAD || chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || M < 1)
+        return GPBO_ERR_ARG;
+    return posterior_layout(Np, chunk, M).total;
+}
+
+extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                                      const double *ls_host, const double *U, const double *alpha, double prior_var,
+                                      int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset,
+                                      int64_t chunk, double *mu_out, double *sigma_out, double *acq_out,
+                                      gpbo_result *result, void *work, int64_t work_bytes, void *stream) {
+    if (!Xs || !X || !U || !alpha || !result || !work) return GPBO_ERR_ARG;
+    if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || Np > (1 << 20)) return GPBO_ERR_ARG;
+    if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE) return GPBO_ERR_ARG;
+    if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
+    if (((uintptr_t)work & 255) || ((uintptr_t)U & 15)) return GPBO_ERR_ARG;
+    const PosteriorLayout L = posterior_layout(Np, chunk, M);
+    if (work_bytes < L.total) return GPBO_ERR_WORKSPACE;
+    hipStream_t st = gpbo_stream(stream);
+    char *w = reinterpret_cast<char *>(work);
+    double *KsT = reinterpret_cast<double *>(w + L.kst_off);
+    double *mu_part = reinterpret_cast<double *>(w + L.mup_off);
+    double *part_val = reinterpret_cast<double *>(w + L.pval_off);
+    int64_t *part_idx = reinterpret_cast<int64_t *>(w + L.pidx_off);
+    unsigned long long *nan_count = reinterpret_cast<unsigned long long *>(w + L.nan_off);
+    if (hipMemsetAsync(nan_count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
+
+    int64_t nparts = 0;
+    for (int64_t s = 0; s < M; s += chunk) {
+        const int64_t Mc = (M - s < chunk) ? (M - s) : chunk;
+        int rc = gpbo_kstar_mu_f64(Xs + s * d, Mc, X, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT, chunk,
+                                   mu_part, stream);
+        if (rc != GPBO_OK) return rc;
+        const int64_t nblk = (Mc + BM - 1) / BM;
+        hipLaunchKernelGGL(sigma_acq_kernel, dim3((unsigned)nblk), dim3(512), 0, st, KsT, chunk, U, (int)Np, mu_part,
+                           (int)(Np / 128), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
+                           mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
+                           acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count);
+        GPBO_CHECK_LAUNCH();
+        nparts += nblk;
+    }
+    hipLaunchKernelGGL(argmax_finish_kernel, dim3(1), dim3(256), 0, st, part_val, part_idx, nparts, nan_count, result);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
+extern "C" int64_t gpbo_acq_workspace_bytes(void) { return 1024 * 16 + 256; }
+
+extern "C" int gpbo_acq_argmax_f64(const double *mu, const double *sigma, int64_t M, int32_t acq_kind, double p0,
+                                   double p1, int64_t idx_offset, double *acq_out, gpbo_result *result, void *work,
+                                   int64_t work_bytes, void *stream) {
+    if (!mu || !sigma || !result || !work || M < 1) return GPBO_ERR_ARG;
+    if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
+    if (work_bytes < gpbo_acq_workspace_bytes()) return GPBO_ERR_WORKSPACE;
+    hipStream_t st = gpbo_stream(stream);
+    char *w = reinterpret_cast<char *>(work);
+    double *part_val = reinterpret_cast<double *>(w);
+    int64_t *part_idx = reinterpret_cast<int64_t *>(w + 1024 * 8);
+    unsigned long long *nan_count = reinterpret_cast<unsigned long long *>(w + 1024 * 16);
+    if (hipMemsetAsync(nan_count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
+    int64_t nblk = (M + 255) / 256;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(acq_argmax_kernel, dim3((unsigned)nblk), dim3(256), 0, st, mu, sigma, M, (int)acq_kind, p0, p1,
+                       idx_offset, acq_out, part_val, part_idx, nan_count);
+    hipLaunchKernelGGL(argmax_finish_kernel, dim3(1), dim3(256), 0, st, part_val, part_idx, nblk, nan_count, result);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}

@@ -1,0 +1,59 @@
+"""Candidate sharding across the GPUs of one node and the one exchange step of the path.
+
+Not in the reference (it has no parallelism in the GP step).  Candidates are independent given
+(X, y, ls, L, alpha), so rank r owns the contiguous block [lo, hi) of the candidate rows and
+recomputes the N x N factorisation locally (deterministic kernels -> identical factors, no broadcast).
+The only collective is an all-gather of one 24-byte record per rank - (best value, lowest global
+index, NaN count) - reduced identically on every rank: max value, ties to the LOWEST global index
+(the reference's np.argwhere(...)[0] rule, /root/reference/point_selector.py:207).
+RCCL has no MAXLOC; an all-gather + local lexicographic reduce is deterministic and 24 B/rank.
+"""
+from __future__ import annotations
+
+import struct
+from typing import Tuple
+
+
+def shard_bounds(M: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block partition: the first M % world ranks get one extra candidate."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    base, extra = divmod(M, world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def reduce_records(records):
+    """records: iterable of (best_val, best_idx, nan_count).  Pure-Python lexicographic reduce."""
+    best_val, best_idx, nan_total = float("-inf"), 2 ** 63 - 1, 0
+    for v, i, n in records:
+        nan_total += int(n)
+        if v != v:  # a NaN best value never wins; it is accounted for through nan_count
+            continue
+        if v > best_val or (v == best_val and i < best_idx):
+            best_val, best_idx = v, int(i)
+    return best_val, best_idx, nan_total
+
+
+def allreduce_argmax(best_val: float, best_idx: int, nan_count: int, group=None, device=None):
+    """All ranks obtain the global (max value, lowest index, total NaN count).
+
+    One all_gather of 3 x int64 per rank (the fp64 value travels as its bit pattern, so no rounding
+    and no NaN canonicalisation can happen in transit).  Works on nccl (= RCCL, device tensors)
+    and gloo (CPU tensors)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return reduce_records([(best_val, best_idx, nan_count)])
+    world = dist.get_world_size(group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    bits = struct.unpack("<q", struct.pack("<d", float(best_val)))[0]
+    mine = torch.tensor([bits, int(best_idx), int(nan_count)], dtype=torch.int64, device=device)
+    out = torch.empty(world * 3, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    rows = out.cpu().view(world, 3).tolist()
+    recs = [(struct.unpack("<d", struct.pack("<q", b))[0], i, n) for b, i, n in rows]
+    return reduce_records(recs)

@@ -1,0 +1,239 @@
+"""Device-resident GP surrogate: host orchestration of the libgpbo kernels.
+
+PyTorch-ROCm is used here for device memory, streams and (in distributed.py) the process group -
+plumbing only; every number is produced by the HIP kernels behind the C ABI (include/gpbo.h).
+
+Mirrors the arithmetic of PointSelector.update_surrogate / lower_confidence_bound
+(/root/reference/point_selector.py:76-98, 197-207) with the factorisation done once per BO step and
+the candidates streamed in chunks.  There is no CPU path: without libgpbo.so or a GPU this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+JITTER_KERNEL = 1e-4    # point_selector.py:193
+JITTER_ASSEMBLY = 1e-6  # point_selector.py:78-79
+PRIOR_VAR = (1.0 + JITTER_KERNEL) + JITTER_ASSEMBLY  # diagonal of cov_pred as the reference rounds it
+
+DEFAULT_CHUNK = 1 << 17
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise _lib.GpboError("no GPU visible: the acquisition path runs only on the HIP kernels (no CPU fallback)")
+    return torch
+
+
+@dataclass
+class ScoreResult:
+    best_val: float
+    best_idx: int
+    nan_count: int
+    mu: Optional[object] = None      # torch fp64 device tensors [M] when dense=True
+    sigma: Optional[object] = None
+    acq: Optional[object] = None
+
+
+class DeviceGP:
+    """One BO step's surrogate on one GPU: factorise once, then score any number of candidates."""
+
+    def __init__(self, device=None, chunk: int = DEFAULT_CHUNK):
+        torch = _torch()
+        self.lib = _lib.load()
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if chunk % _lib.CHUNK_GRANULE:
+            raise ValueError(f"chunk must be a multiple of {_lib.CHUNK_GRANULE}")
+        self.chunk = int(chunk)
+        self.N = self.Np = self.d = 0
+        self._work_post = None
+        self._result = torch.zeros(4, dtype=torch.int64, device=self.device)
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, arr):
+        torch = self.torch
+        if isinstance(arr, torch.Tensor):
+            t = arr.to(device=self.device, dtype=torch.float64)
+            return t if t.is_contiguous() else t.contiguous()
+        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    # -- factorisation (once per BO step) ---------------------------------------------------------
+    def factorise(self, X, y, ls, jitter1: float = JITTER_KERNEL, jitter2: float = JITTER_ASSEMBLY,
+                  check: bool = True):
+        """K = k(X,X) + jitter; K = L L^T; U = L^-T; alpha = K^-1 y   (point_selector.py:79, 89-90)."""
+        torch = self.torch
+        Xd = self._dev(X)
+        if Xd.dim() != 2:
+            raise ValueError("X must be (N, d)")
+        N, d = int(Xd.shape[0]), int(Xd.shape[1])
+        if d > _lib.MAX_D:
+            raise ValueError(f"d = {d} > {_lib.MAX_D} is not supported by the compiled kernels")
+        yd = self._dev(y).reshape(-1)
+        if yd.numel() != N:
+            raise ValueError("y must have one value per row of X")
+        ls_h = np.ascontiguousarray(np.asarray(ls, dtype=np.float64).reshape(-1))
+        if ls_h.size != d:
+            raise ValueError(f"length scales: expected {d} values, got {ls_h.size}")
+        Np = int(self.lib.gpbo_padded_n(N))
+        with torch.cuda.device(self.device):
+            self.X, self.y, self.ls_h = Xd, yd, ls_h
+            self.N, self.Np, self.d = N, Np, d
+            self.K = torch.empty((Np, Np), dtype=torch.float64, device=self.device)
+            self.U = torch.empty((Np, Np), dtype=torch.float64, device=self.device)
+            self.alpha = torch.empty(Np, dtype=torch.float64, device=self.device)
+            self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
+            wbytes = int(self.lib.gpbo_factorise_workspace_bytes(Np))
+            work = torch.empty(wbytes // 8, dtype=torch.float64, device=self.device)
+            st = self.lib.gpbo_factorise_f64(self._ptr(Xd), self._ptr(yd), N, d, ls_h.ctypes.data_as(C.c_void_p),
+                                             jitter1, jitter2, Np, self._ptr(self.K), self._ptr(self.U),
+                                             self._ptr(self.alpha), self._ptr(self.info), self._ptr(work), wbytes,
+                                             self._stream())
+            _lib.check(st, "gpbo_factorise_f64")
+            if check:
+                info = int(self.info.item())  # synchronises
+                if info != 0:
+                    raise np.linalg.LinAlgError(
+                        f"covariance matrix is not positive definite (pivot {info} of {N}); "
+                        "the reference's np.linalg.inv would raise or return garbage here")
+            del work
+        return self
+
+    # -- scoring ------------------------------------------------------------------------------------
+    def _ensure_post_workspace(self, M):
+        torch = self.torch
+        chunk = min(self.chunk, (M + _lib.CHUNK_GRANULE - 1) // _lib.CHUNK_GRANULE * _lib.CHUNK_GRANULE)
+        need = int(self.lib.gpbo_posterior_workspace_bytes(self.Np, chunk, M))
+        if need < 0:
+            raise _lib.GpboError("gpbo_posterior_workspace_bytes: invalid sizes")
+        if self._work_post is None or self._work_post.numel() * 8 < need:
+            self._work_post = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
+        return chunk, need
+
+    def score_async(self, Xs, acquisition: str = "lcb", explore: float = 4.0, f_best: Optional[float] = None,
+                    xi: float = 0.0, dense: bool = False, idx_offset: int = 0, diag_add: float = 0.0,
+                    prior_var: float = PRIOR_VAR):
+        """Enqueue K(X*,X) + mu + sigma + acquisition + arg-max for all rows of Xs; no host sync.
+        Returns (result_tensor[int64 x4 on device], mu, sigma, acq)."""
+        torch = self.torch
+        Xsd = self._dev(Xs)
+        if Xsd.dim() != 2 or int(Xsd.shape[1]) != self.d:
+            raise ValueError("Xs must be (M, d) with the same d as X")
+        M = int(Xsd.shape[0])
+        if acquisition == "lcb":
+            kind, p0, p1 = _lib.ACQ_LCB, float(explore), 0.0
+        elif acquisition == "ei":
+            if f_best is None:
+                raise ValueError("EI needs f_best (the incumbent minimum)")
+            kind, p0, p1 = _lib.ACQ_EI, float(f_best), float(xi)
+        else:
+            raise ValueError(f"unknown acquisition {acquisition!r}")
+        with torch.cuda.device(self.device):
+            chunk, wbytes = self._ensure_post_workspace(M)
+            mu = sigma = acq = None
+            if dense:
+                mu = torch.empty(M, dtype=torch.float64, device=self.device)
+                sigma = torch.empty(M, dtype=torch.float64, device=self.device)
+                acq = torch.empty(M, dtype=torch.float64, device=self.device)
+            st = self.lib.gpbo_posterior_acq_f64(
+                self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d,
+                self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.U), self._ptr(self.alpha), prior_var,
+                kind, p0, p1, float(diag_add), int(idx_offset), chunk, self._ptr(mu), self._ptr(sigma),
+                self._ptr(acq), self._ptr(self._result), self._ptr(self._work_post), wbytes, self._stream())
+            _lib.check(st, "gpbo_posterior_acq_f64")
+        self._keep = Xsd  # keep the candidate tensor alive until the stream has consumed it
+        return self._result, mu, sigma, acq
+
+    def read_result(self, result_tensor) -> tuple:
+        r = result_tensor.cpu()  # synchronises
+        best_val = float(r[:1].view(self.torch.float64)[0])
+        return best_val, int(r[1]), int(r[2])
+
+    def score(self, Xs, **kw) -> ScoreResult:
+        res, mu, sigma, acq = self.score_async(Xs, **kw)
+        v, i, n = self.read_result(res)
+        return ScoreResult(v, i, n, mu, sigma, acq)
+
+    def acquisition_on_posterior(self, mu, sigma, acquisition: str = "lcb", explore: float = 4.0,
+                                 f_best: Optional[float] = None, xi: float = 0.0, idx_offset: int = 0) -> ScoreResult:
+        """Second acquisition on dense device mu/sigma (lower_confidence_bound(explore) after the fact)."""
+        torch = self.torch
+        M = int(mu.numel())
+        kind, p0, p1 = (_lib.ACQ_LCB, float(explore), 0.0) if acquisition == "lcb" else (_lib.ACQ_EI, float(f_best), float(xi))
+        with torch.cuda.device(self.device):
+            acq = torch.empty(M, dtype=torch.float64, device=self.device)
+            wbytes = int(self.lib.gpbo_acq_workspace_bytes())
+            work = torch.empty(wbytes // 8 + 32, dtype=torch.float64, device=self.device)
+            st = self.lib.gpbo_acq_argmax_f64(self._ptr(mu), self._ptr(sigma), M, kind, p0, p1, int(idx_offset),
+                                              self._ptr(acq), self._ptr(self._result), self._ptr(work), wbytes,
+                                              self._stream())
+            _lib.check(st, "gpbo_acq_argmax_f64")
+            v, i, n = self.read_result(self._result)
+        return ScoreResult(v, i, n, mu, sigma, acq)
+
+    # -- ARD grid ------------------------------------------------------------------------------------
+    def nlml_grid(self, X, y, ls_cells, jitter: float = JITTER_KERNEL) -> np.ndarray:
+        """float32 -log marginal likelihood of every row of ls_cells [G x d]  (point_selector.py:111-156)."""
+        torch = self.torch
+        Xd, yd = self._dev(X), self._dev(y).reshape(-1)
+        N, d = int(Xd.shape[0]), int(Xd.shape[1])
+        cells = self._dev(np.asarray(ls_cells, dtype=np.float64).reshape(-1, d))
+        G = int(cells.shape[0])
+        if N > int(self.lib.gpbo_nlml_grid_max_n()):
+            raise NotImplementedError(
+                f"ARD grid search on the GPU supports N <= {self.lib.gpbo_nlml_grid_max_n()} observations "
+                "(the reference's det-based likelihood underflows beyond N ~ 100 anyway); "
+                "pass kernel_params explicitly for larger N")
+        with torch.cuda.device(self.device):
+            out = torch.empty(G, dtype=torch.float32, device=self.device)
+            st = self.lib.gpbo_nlml_grid_f64(self._ptr(Xd), self._ptr(yd), N, d, self._ptr(cells), G, float(jitter),
+                                             self._ptr(out), self._stream())
+            _lib.check(st, "gpbo_nlml_grid_f64")
+            return out.cpu().numpy()
+
+    # -- dense covariance blocks for inspection (small problems only) --------------------------------------
+    def cov_meas_host(self) -> np.ndarray:
+        return self.K[: self.N, : self.N].cpu().numpy()
+
+    def kxx_host(self, P, ls, jitter1, jitter2) -> np.ndarray:
+        """k(P,P) with the reference's jitter, as a host array (used for `cov_pred` on small grids)."""
+        torch = self.torch
+        Pd = self._dev(P)
+        n, d = int(Pd.shape[0]), int(Pd.shape[1])
+        npad = int(self.lib.gpbo_padded_n(n))
+        ls_h = np.ascontiguousarray(np.asarray(ls, dtype=np.float64).reshape(-1))
+        with torch.cuda.device(self.device):
+            Kp = torch.empty((npad, npad), dtype=torch.float64, device=self.device)
+            st = self.lib.gpbo_kxx_f64(self._ptr(Pd), n, d, ls_h.ctypes.data_as(C.c_void_p), jitter1, jitter2,
+                                       self._ptr(Kp), npad, self._stream())
+            _lib.check(st, "gpbo_kxx_f64")
+            return Kp[:n, :n].cpu().numpy()
+
+    def cov_meas_pred_host(self, Xs, diag_add: float = 0.0) -> np.ndarray:
+        """K(X*, X) as an (M, N) host array  (point_selector.py:81); small problems only."""
+        torch = self.torch
+        Xsd = self._dev(Xs)
+        M = int(Xsd.shape[0])
+        ldk = (M + _lib.CHUNK_GRANULE - 1) // _lib.CHUNK_GRANULE * _lib.CHUNK_GRANULE
+        with torch.cuda.device(self.device):
+            kst = torch.empty((self.Np, ldk), dtype=torch.float64, device=self.device)
+            mup = torch.empty((self.Np // 128, ldk), dtype=torch.float64, device=self.device)
+            st = self.lib.gpbo_kstar_mu_f64(self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d,
+                                            self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.alpha),
+                                            float(diag_add), 0, self._ptr(kst), ldk, self._ptr(mup), self._stream())
+            _lib.check(st, "gpbo_kstar_mu_f64")
+            return kst[: self.N, :M].t().contiguous().cpu().numpy()

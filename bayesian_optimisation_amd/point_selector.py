@@ -1,0 +1,214 @@
+"""Drop-in replacement for the reference's `PointSelector` running on the MI355X kernels.
+
+Same attribute protocol and call sequence as /root/reference/point_selector.py:13-207 as driven by
+/root/reference/select_parameters.py:146-157 and :282-293:
+
+    ps = PointSelector(); ps.name = ...; ps.iteration = ...
+    ps.measured_pts, ps.measured_vals, ps.feature_domain, ps.predicted_pts, ps.length_scales = ...
+    ps.update_surrogate()
+    idx = ps.lower_confidence_bound()          # np.ndarray[int64], one entry per feature axis
+    ps.mean_func, ps.cov_func, ps.acq_func_eval, ps.kernel_params
+
+Differences from the reference, all deliberate:
+  * `cov_pred` (the M x M predictive covariance, :78) is never needed - only its diagonal is - and
+    is materialised only when M <= COV_PRED_MAX_M; `cov_meas_pred` (:81) only when M*N is small.
+  * Failures raise instead of returning garbage: numpy.linalg.LinAlgError when K is not positive
+    definite, IndexError when the acquisition contains NaN (the reference's own failure at :207).
+  * Extra, not in the reference: `expected_improvement(xi)`, `kernel_params` may be preset (then no
+    ARD search runs), optional multi-GPU candidate sharding when torch.distributed is initialised.
+There is no CPU implementation behind this class.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import distributed as D
+from .gp_device import JITTER_ASSEMBLY, JITTER_KERNEL, PRIOR_VAR, DeviceGP
+
+COV_PRED_MAX_M = 4096          # cov_pred is M x M: 128 MiB at this size
+COV_MEAS_PRED_MAX = 1 << 24    # entries of the (M, N) cross covariance kept for inspection
+
+
+def _plot_hooks():
+    """The reference star-imports plot_utils (point_selector.py:4) and calls plot_ARD_LL{,_1d} from
+    tune_kernel (:146,163).  If that module is importable (the DAG's working directory) use it."""
+    try:
+        import plot_utils  # type: ignore
+
+        return getattr(plot_utils, "plot_ARD_LL", None), getattr(plot_utils, "plot_ARD_LL_1d", None)
+    except Exception:  # noqa: BLE001 - plotting is a side output, never a reason to fail the step
+        return None, None
+
+
+class PointSelector:
+    def __init__(self, device=None, verbose: bool = False, shard_candidates: bool = True):
+        # attribute protocol of point_selector.py:15-40
+        self.feature_domain = None
+        self.predicted_pts = None
+        self.measured_vals = []
+        self.measured_pts = []
+        self.mean_func = None
+        self.cov_func = None
+        self.acq_func_eval = None
+        self.hyperparam_obj = []
+        self.length_scales = None
+        self.kernel_params = None
+        self.gradient_steps = 0.001
+        self.iteration = None
+        self.name = None
+        self.cov_pred = None
+        self.cov_meas = None
+        self.cov_meas_pred = None
+        # build-specific
+        self.nlogml = None
+        self._device = device
+        self._verbose = verbose
+        self._shard = shard_candidates
+        self._gp = None
+        self._mu_dev = self._sigma_dev = None
+        self._cached = None  # (kind, p0, p1) -> (acq ndarray, flat index)
+        self._preset_kernel_params = False
+
+    # ------------------------------------------------------------------------------------------
+    def _log(self, *a):
+        if self._verbose:
+            print(*a)
+
+    def _world(self):
+        import torch.distributed as dist
+
+        if self._shard and dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(), dist.get_rank()
+        return 1, 0
+
+    def set_kernel_params(self, kernel_params):
+        """Preset length scales: update_surrogate() then skips the ARD grid search (needed for d > 2,
+        where the reference's tune_kernel cannot run at all)."""
+        self.kernel_params = np.asarray(kernel_params, dtype=np.float64)
+        self._preset_kernel_params = True
+
+    # ------------------------------------------------------------------------------------------
+    def update_surrogate(self):
+        """point_selector.py:42-102."""
+        self.measured_pts = np.array(self.measured_pts)
+        self.measured_vals = np.array(self.measured_vals)
+        X = np.asarray(self.measured_pts, dtype=np.float64)
+        y = np.asarray(self.measured_vals, dtype=np.float64)
+        Xs = np.asarray(self.predicted_pts, dtype=np.float64)
+        if self._gp is None:
+            self._gp = DeviceGP(self._device)
+        gp = self._gp
+
+        if self._preset_kernel_params:
+            pass
+        elif len(X[:, 0]) > 1:                                           # :60
+            self.tune_kernel()
+        else:                                                            # :63-73
+            if len(self.length_scales) == 2:
+                a1, a2 = self.length_scales[0], self.length_scales[1]
+                self.kernel_params = np.array([a1[len(a1) // 2], a2[len(a2) // 2]])
+            else:
+                self.kernel_params = np.array([self.length_scales[len(self.length_scales) // 2]])
+        ls = np.asarray(self.kernel_params, dtype=np.float64).reshape(-1)
+
+        gp.factorise(X, y, ls, JITTER_KERNEL, JITTER_ASSEMBLY, check=True)   # :79, :89 (raises LinAlgError)
+        self.cov_meas = gp.cov_meas_host()
+
+        M, N = len(Xs), len(X)
+        diag_add = JITTER_KERNEL if Xs.shape == X.shape else 0.0          # :173 shape-coincidence quirk
+        world, rank = self._world()
+        lo, hi = D.shard_bounds(M, world, rank)
+        res = gp.score(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
+        self._mu_dev, self._sigma_dev = res.mu, res.sigma
+        mu, sigma, acq = res.mu.cpu().numpy(), res.sigma.cpu().numpy(), res.acq.cpu().numpy()
+        best = D.allreduce_argmax(res.best_val, res.best_idx, res.nan_count)
+        if world > 1:
+            mu, sigma, acq = (self._gather(v, M, world) for v in (mu, sigma, acq))
+        fd = [int(v) for v in self.feature_domain]
+        self.mean_func = mu.reshape(fd)                                   # :97
+        self.cov_func = sigma.reshape(fd)                                 # :98 (a standard deviation)
+        self._cached = {("lcb", 4.0, 0.0): (acq.reshape(fd), best)}
+        self._lo_hi = (lo, hi)
+
+        self.cov_meas_pred = gp.cov_meas_pred_host(Xs, diag_add) if M * N <= COV_MEAS_PRED_MAX else None
+        self.cov_pred = gp.kxx_host(Xs, ls, JITTER_KERNEL, JITTER_ASSEMBLY) if M <= COV_PRED_MAX_M else None
+
+        self.measured_pts = self.measured_pts.tolist()                    # :101-102
+        self.measured_vals = self.measured_vals.tolist()
+
+    @staticmethod
+    def _gather(local: np.ndarray, M: int, world: int) -> np.ndarray:
+        import torch
+        import torch.distributed as dist
+
+        parts = [None] * world
+        dist.all_gather_object(parts, local)
+        out = np.concatenate(parts)
+        assert out.shape[0] == M
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def tune_kernel(self):
+        """ARD grid search, point_selector.py:104-163: float32 nlml grid on the GPU, first row-major
+        minimum on the host (np.argwhere(g == amin)[0]; NaN -> IndexError, as in the reference)."""
+        X = np.asarray(self.measured_pts, dtype=np.float64)
+        y = np.asarray(self.measured_vals, dtype=np.float64)
+        plot2, plot1 = _plot_hooks()
+        if len(self.length_scales) == 2:                                  # :122
+            axis1 = np.asarray(self.length_scales[0], dtype=np.float64)
+            axis2 = np.asarray(self.length_scales[1], dtype=np.float64)
+            cells = np.stack(np.meshgrid(axis1, axis2, indexing="ij"), -1).reshape(-1, 2)
+            nlogml = self._gp.nlml_grid(X, y, cells).reshape(len(axis1), len(axis2))
+            min_idx = np.argwhere(nlogml == np.amin(nlogml))[0]           # :141
+            self.kernel_params = np.array([axis1[min_idx[0]], axis2[min_idx[1]]])
+            self.nlogml = nlogml
+            if plot2 is not None:
+                try:
+                    plot2(nlogml, self.kernel_params, self.length_scales, self.name, self.iteration)
+                except Exception:  # noqa: BLE001
+                    pass
+        else:
+            axis = np.asarray(self.length_scales, dtype=np.float64)
+            nlogml = self._gp.nlml_grid(X, y, axis.reshape(-1, 1))
+            min_idx = np.argwhere(nlogml == np.amin(nlogml))[0]           # :159
+            self.kernel_params = np.array([axis[min_idx]])                # shape (1, 1), as at :161
+            self.nlogml = nlogml
+            if plot1 is not None:
+                try:
+                    plot1(nlogml, self.kernel_params, self.length_scales, self.name, self.iteration)
+                except Exception:  # noqa: BLE001
+                    pass
+
+    # ------------------------------------------------------------------------------------------
+    def _finish(self, key, kind, **kw):
+        fd = [int(v) for v in self.feature_domain]
+        if key not in self._cached:
+            lo, hi = self._lo_hi
+            res = self._gp.acquisition_on_posterior(self._mu_dev, self._sigma_dev, acquisition=kind,
+                                                    idx_offset=lo, **kw)
+            acq = res.acq.cpu().numpy()
+            best = D.allreduce_argmax(res.best_val, res.best_idx, res.nan_count)
+            world, _ = self._world()
+            if world > 1:
+                acq = self._gather(acq, int(np.prod(fd)), world)
+            self._cached[key] = (acq.reshape(fd), best)
+        acq, (best_val, best_idx, nan_count) = self._cached[key]
+        self.acq_func_eval = acq
+        if nan_count > 0 or best_idx >= int(np.prod(fd)):
+            # the reference: amax is NaN, the comparison is empty, [0] raises (point_selector.py:207)
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0 (acquisition contains NaN)")
+        return np.array(np.unravel_index(best_idx, fd), dtype=np.int64)
+
+    def lower_confidence_bound(self, explore=4):
+        """point_selector.py:197-207: acq = explore*sigma - mu; first row-major arg-max as a multi-index."""
+        if self._cached is None:
+            raise RuntimeError("call update_surrogate() first")
+        return self._finish(("lcb", float(explore), 0.0), "lcb", explore=float(explore))
+
+    def expected_improvement(self, xi=0.0):
+        """Not in the reference (docs/README.md:363-365 'future work'): EI for minimisation,
+        f_best = min(measured_vals)."""
+        if self._cached is None:
+            raise RuntimeError("call update_surrogate() first")
+        f_best = float(np.min(np.asarray(self.measured_vals, dtype=np.float64)))
+        return self._finish(("ei", f_best, float(xi)), "ei", f_best=f_best, xi=float(xi))

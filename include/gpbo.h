@@ -1,0 +1,138 @@
+/*
+ * gpbo.h - C ABI of libgpbo: the MI355X (gfx950) GP-surrogate acquisition path.
+ *
+ * The reference has no FFI: its boundary is the Python attribute protocol between
+ * select_parameters.py:146-157 / 282-293 and class PointSelector (point_selector.py:13-207).
+ * bayesian_optimisation_amd.PointSelector keeps that protocol and binds the entry points below
+ * through ctypes.  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; all buffers are
+ *     caller-allocated and caller-owned, nothing is retained across calls;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls only enqueue
+ *     work on it and never synchronise, so they may be captured into a hipGraph;
+ *   - matrices are row-major fp64; observation-sized dimensions are padded to
+ *     Np = gpbo_padded_n(N) (a multiple of 128): the padding carries the identity in K/L/U and
+ *     zeros in y/alpha, so results on the leading N entries are those of the unpadded problem;
+ *   - return value: GPBO_OK or a negative GPBO_ERR_* (no exceptions cross the ABI).  Numerical
+ *     failures that are only known on the device (non-positive Cholesky pivot, NaN acquisition)
+ *     are reported through the device-side `info` / `result` words the caller reads back.
+ */
+#ifndef GPBO_H
+#define GPBO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPBO_VERSION 100 /* 0.1.0 */
+
+#define GPBO_OK 0
+#define GPBO_ERR_ARG (-1)      /* null pointer, bad size/alignment, unsupported d */
+#define GPBO_ERR_LAUNCH (-2)   /* HIP reported a launch/runtime error */
+#define GPBO_ERR_WORKSPACE (-3) /* workspace too small */
+
+#define GPBO_MAX_D 16          /* compile-time-unrolled feature counts 1..16 */
+#define GPBO_NPAD 128          /* observation padding granule */
+#define GPBO_CHUNK_GRANULE 512 /* candidate-chunk granule */
+
+#define GPBO_ACQ_LCB 0 /* acq = p0*sigma - mu            (point_selector.py:204, p0 = explore) */
+#define GPBO_ACQ_EI 1  /* acq = EI for minimisation, p0 = f_best, p1 = xi (not in the reference) */
+
+/* Result record written by gpbo_posterior_acq_f64 (device memory, 32 bytes). */
+typedef struct gpbo_result {
+    double best_val;   /* max acquisition over the candidates given to this call          */
+    int64_t best_idx;  /* LOWEST global index attaining it (point_selector.py:207 tie rule) */
+    int64_t nan_count; /* number of candidates whose acquisition is NaN (reference: IndexError) */
+    int64_t reserved;
+} gpbo_result;
+
+int gpbo_version(void);
+const char *gpbo_strerror(int status);
+int64_t gpbo_padded_n(int64_t N);
+
+/* K1 - replaces kernel_rbf(X, X) + jitter assembly (point_selector.py:166-195 with :79, :116).
+ * Kp[Np x Np]: leading N x N = exp(-1/2 sum_k (x_ik-x_jk)^2 / ls_k^2), diagonal = (1 + jitter1) + jitter2
+ * (the reference adds 1e-4 inside kernel_rbf and 1e-6 at assembly, in that order); padding = identity.
+ * X: [N x d] row-major, ls: [d] length scales (kernel_params). */
+int gpbo_kxx_f64(const double *X, int64_t N, int32_t d, const double *ls_host, double jitter1, double jitter2,
+                 double *Kp, int64_t Np, void *stream);
+
+/* K4 - replaces np.linalg.inv(cov_meas) (point_selector.py:89) by a blocked right-looking Cholesky.
+ * In place: lower triangle of Kp becomes L (upper triangle is left untouched). dinv [Np/64][64][64]
+ * receives the inverses of the diagonal blocks of L. info (device int32): 0, or 1-based column of the
+ * first non-positive / non-finite pivot. */
+int gpbo_potrf_f64(double *Kp, int64_t Np, double *dinv, int32_t *info, void *stream);
+
+/* U = (L^-1)^T, upper triangular, [Np x Np] row-major (strict lower triangle zero-filled).
+ * work: Np*Np doubles. Together with gpbo_potrf_f64 this is the factorisation the posterior uses. */
+int gpbo_trtri_f64(const double *L, const double *dinv, int64_t Np, double *U, double *work, void *stream);
+
+/* alpha = K^-1 y = U (U^T y)   (point_selector.py:90 `inv @ measured_vals`).
+ * y: [N]; alpha: [Np] (zero on the padding); tmp: [Np]. */
+int gpbo_alpha_f64(const double *U, const double *y, int64_t N, int64_t Np, double *tmp, double *alpha,
+                   void *stream);
+
+/* One call = kxx + potrf + trtri + alpha.  work: gpbo_factorise_workspace_bytes(Np) bytes.
+ * Outputs: Kp keeps K (the reference's `cov_meas`, point_selector.py:79; L lives in the workspace),
+ * U [Np x Np], alpha [Np], info (device int32, as gpbo_potrf_f64). */
+int64_t gpbo_factorise_workspace_bytes(int64_t Np);
+int gpbo_factorise_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_host,
+                       double jitter1, double jitter2, int64_t Np, double *Kp, double *U, double *alpha,
+                       int32_t *info, void *work, int64_t work_bytes, void *stream);
+
+/* K2+K5 - replaces kernel_rbf(X, X*).T and the mean product (point_selector.py:81, :90).
+ * Builds the transposed cross-covariance chunk KsT[Np x ldk] (row n = observation n, column c =
+ * candidate c of the chunk; rows n >= N are zero) and per-128-observation partial sums of
+ * mu_c = sum_n k(x*_c, x_n) alpha_n into mu_part[(Np/128) x ldk].
+ * Xs: [Mc x d] candidates of this chunk; Mc <= ldk, ldk a multiple of 512.
+ * diag_add / cand_base: when the caller's full candidate set has the SAME SHAPE as X the reference
+ * adds 1e-4 where observation index == global candidate index (point_selector.py:173,191-193);
+ * pass diag_add = 0 otherwise. */
+int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *X, int64_t N, int64_t Np, int32_t d,
+                      const double *ls_host, const double *alpha, double diag_add, int64_t cand_base,
+                      double *KsT, int64_t ldk, double *mu_part, void *stream);
+
+/* K5..K8, whole candidate set of this rank: chunks of `chunk` candidates through gpbo_kstar_mu_f64 and
+ * the fused sigma/acquisition/argmax kernel (point_selector.py:90-98, :204-207).
+ *   sigma_c = sqrt(|prior_var - |U^T k_c|^2|)     (abs and sqrt as at :98; "cov_func" is a std-dev)
+ *   acq_c   = LCB or EI;  result = first-index argmax over c in [0, M), reported as idx_offset + c.
+ * mu_out / sigma_out / acq_out: optional dense [M] outputs (NULL to skip).
+ * work: gpbo_posterior_workspace_bytes(Np, chunk, M) bytes. */
+int64_t gpbo_posterior_workspace_bytes(int64_t Np, int64_t chunk, int64_t M);
+int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                           const double *ls_host, const double *U, const double *alpha, double prior_var,
+                           int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset,
+                           int64_t chunk, double *mu_out, double *sigma_out, double *acq_out,
+                           gpbo_result *result, void *work, int64_t work_bytes, void *stream);
+
+/* K7+K8 on a posterior already on the device: acq = LCB/EI of (mu, sigma), first-index arg-max
+ * (point_selector.py:204-207).  Used for a second acquisition on the same surrogate.
+ * work: gpbo_acq_workspace_bytes() bytes, 256-byte aligned. */
+int64_t gpbo_acq_workspace_bytes(void);
+int gpbo_acq_argmax_f64(const double *mu, const double *sigma, int64_t M, int32_t acq_kind, double p0, double p1,
+                        int64_t idx_offset, double *acq_out, gpbo_result *result, void *work, int64_t work_bytes,
+                        void *stream);
+
+/* K9 - replaces tune_kernel / eval_log_marginal (point_selector.py:104-163): float32 grid of
+ * nlml = 0.5 (y^T K^-1 y + log det K + N log 2pi), K = k(X,X) + jitter I, one value per grid cell.
+ * ls_cells: [G x d] length scales of each cell (device); out: [G] float32 (device).
+ * N <= gpbo_nlml_grid_max_n() (the bordered matrix is factorised in LDS). */
+int gpbo_nlml_grid_max_n(void);
+int gpbo_nlml_grid_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells, int64_t G,
+                       double jitter, float *out, void *stream);
+
+/* Strided-batched fp64 MFMA GEMM used by the factorisation (exported for tests):
+ * C_b = alpha * A_b * op(B_b) + beta * C_b, row-major, M and N multiples of 64, K a multiple of 16;
+ * transB = 0: B is [K x N]; transB = 1: B is [N x K].  lower_only = 1 skips 64x64 tiles strictly above
+ * the block diagonal (SYRK-style update of a lower triangle). */
+int gpbo_gemm_f64(int32_t transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                  int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double beta, double *C,
+                  int64_t ldc, int64_t strideC, int32_t batch, int32_t lower_only, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPBO_H */

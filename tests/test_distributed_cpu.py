@@ -1,0 +1,76 @@
+"""The N>1 path on CPU: contiguous candidate sharding + the (value, lowest-index, NaN-count)
+exchange, exercised with a real 2-process gloo group (the GPU path uses the same code over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from bayesian_optimisation_amd import distributed as D
+
+
+def test_shard_bounds_cover_exactly_once():
+    for M in [1, 7, 8, 1000, (1 << 24) + 3]:
+        for world in [1, 2, 3, 8]:
+            spans = [D.shard_bounds(M, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == M
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_reduce_records_tie_and_nan_rules():
+    inf = float("inf")
+    assert D.reduce_records([(1.0, 5, 0), (2.0, 9, 0), (2.0, 3, 0)]) == (2.0, 3, 0)
+    assert D.reduce_records([(2.0, 9, 1), (-inf, 2 ** 63 - 1, 4)]) == (2.0, 9, 5)
+    assert D.reduce_records([(float("nan"), 1, 2), (0.5, 7, 0)]) == (0.5, 7, 2)
+    assert D.reduce_records([(-0.0, 4, 0), (0.0, 2, 0)]) == (0.0, 2, 0)  # -0.0 == 0.0: lowest index wins
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # a synthetic acquisition surface with an exact tie across the two shards
+        M = 1001
+        acq = np.cos(np.arange(M) * 0.37)
+        acq[[100, 900]] = 5.0  # same max on rank 0 and rank 1 -> index 100 must win everywhere
+        lo, hi = D.shard_bounds(M, world, rank)
+        loc = acq[lo:hi]
+        j = int(np.flatnonzero(loc == loc.max())[0])
+        out = D.allreduce_argmax(float(loc[j]), lo + j, 1 if rank == 1 else 0)
+        # the bit pattern of the value must survive the exchange
+        out2 = D.allreduce_argmax(float(np.nextafter(1.0, 2.0)) if rank == 0 else 1.0, rank, 0)
+        q.put((rank, out, out2))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_gloo_exchange():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, out, out2 in res:
+        assert out == (5.0, 100, 1)
+        assert out2 == (float(np.nextafter(1.0, 2.0)), 0, 0)

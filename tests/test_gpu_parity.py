@@ -1,0 +1,225 @@
+"""End-to-end parity of the HIP path on the MI355X: against the golden vectors produced by the
+reference, against the CPU oracle on seeded inputs, and - at BASELINE.json's full sizes - through
+size-independent properties (chunk / shard invariance, reported arg-max == first maximum of the dense
+acquisition, sub-sampled oracle check)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from bayesian_optimisation_amd import DeviceGP, PointSelector  # noqa: E402
+from bayesian_optimisation_amd import distributed as D  # noqa: E402
+from bayesian_optimisation_amd.synthetic import make_problem  # noqa: E402
+from oracle import gp_oracle as O  # noqa: E402
+
+# fp64 tolerances: vs the reference |dmu| <= 1e-9 max(1,|y|inf), |dsigma| <= 1e-8,
+# |dacq| <= 1e-8 max(1,|y|inf); vs the Cholesky-route oracle an order tighter.
+TOL_MU, TOL_SIG, TOL_ACQ = 1e-9, 1e-8, 1e-8
+
+
+def _check_against(mu, sig, acq, idx, g, tight=1.0):
+    ys = max(1.0, float(np.max(np.abs(g["y"]))))
+    assert np.max(np.abs(mu - g["mean_func"].ravel())) <= TOL_MU * ys * tight
+    assert np.max(np.abs(sig - g["cov_func"].ravel())) <= TOL_SIG * tight
+    assert np.max(np.abs(acq - g["acq_func_eval"].ravel())) <= TOL_ACQ * ys * tight
+    if g["top2_gap"] > 1e-7 * ys or g["n_max_ties"] > 1:
+        assert idx == int(np.ravel_multi_index(tuple(g["index"]), g["mean_func"].shape))
+
+
+def _first_argmax(a):
+    return int(np.flatnonzero(a == a.max())[0])
+
+
+@pytest.mark.parametrize("name", ["g5_d8_n64_m1024", "g5_d8_n512_m4096", "g5_d8_n2048_m4096", "g6_d16_n256_m2048"])
+def test_fused_path_vs_reference_golden(golden, name):
+    g = golden(name)
+    X, y, Xs, ls = make_problem(int(g["N"]), int(g["M"]), int(g["d"]))
+    gp = DeviceGP().factorise(X, y, ls)
+    r = gp.score(Xs, acquisition="lcb", explore=4.0, dense=True)
+    mu, sig, acq = r.mu.cpu().numpy(), r.sigma.cpu().numpy(), r.acq.cpu().numpy()
+    assert r.nan_count == 0
+    _check_against(mu, sig, acq, r.best_idx, g)
+    assert r.best_idx == _first_argmax(acq) and r.best_val == acq.max()
+    # and an order tighter against the Cholesky-route oracle
+    mu_o, sig_o = O.posterior_chol(X, y, Xs, ls)
+    assert np.max(np.abs(mu - mu_o)) <= 1e-10 * max(1.0, np.abs(y).max())
+    assert np.max(np.abs(sig - sig_o)) <= 1e-9
+    assert np.array_equal(acq, 4.0 * sig - mu)  # the LCB line itself is bit-exact given mu, sigma
+
+
+@pytest.mark.parametrize("N,M,d,chunk", [(1, 50, 1, 512), (7, 2500, 2, 1024), (129, 1300, 5, 512), (300, 5000, 8, 2048)])
+def test_fused_path_vs_oracle_ragged_sizes(N, M, d, chunk):
+    rng = np.random.default_rng(N * 7 + M)
+    X = rng.uniform(0, 1, (N, d))
+    Xs = rng.uniform(0, 1, (M, d))
+    y = 10.0 * rng.standard_normal(N)
+    ls = np.geomspace(0.15, 0.9, d)
+    gp = DeviceGP(chunk=chunk).factorise(X, y, ls)
+    r = gp.score(Xs, dense=True, idx_offset=1000)
+    mu, sig, acq = r.mu.cpu().numpy(), r.sigma.cpu().numpy(), r.acq.cpu().numpy()
+    mu_o, sig_o = O.posterior_chol(X, y, Xs, ls)
+    assert np.max(np.abs(mu - mu_o)) <= 1e-10 * max(1.0, np.abs(y).max())
+    assert np.max(np.abs(sig - sig_o)) <= 1e-9
+    assert r.best_idx == 1000 + _first_argmax(acq) and r.best_val == acq.max()
+    acq_o = O.lcb(mu_o, sig_o, 4)
+    top2 = np.sort(acq_o)[-2:]
+    if top2[1] - top2[0] > 1e-7:
+        assert r.best_idx - 1000 == _first_argmax(acq_o)
+
+
+def test_expected_improvement_vs_oracle():
+    X, y, Xs, ls = make_problem(256, 4096, 8)
+    gp = DeviceGP().factorise(X, y, ls)
+    r = gp.score(Xs, acquisition="ei", f_best=float(y.min()), xi=0.01, dense=True)
+    mu, sig, acq = r.mu.cpu().numpy(), r.sigma.cpu().numpy(), r.acq.cpu().numpy()
+    ei_same_post = O.expected_improvement(mu, sig, float(y.min()), 0.01)
+    np.testing.assert_allclose(acq, ei_same_post, rtol=1e-12, atol=1e-15)
+    mu_o, sig_o = O.posterior_chol(X, y, Xs, ls)
+    ei_o = O.expected_improvement(mu_o, sig_o, float(y.min()), 0.01)
+    assert np.max(np.abs(acq - ei_o)) <= 1e-8
+    assert r.best_idx == _first_argmax(acq)
+    top2 = np.sort(ei_o)[-2:]
+    if top2[1] - top2[0] > 1e-7:
+        assert r.best_idx == _first_argmax(ei_o)
+
+
+def test_ties_resolve_to_lowest_global_index(golden):
+    g = golden("g4_tie_tiny_ls")
+    gp = DeviceGP(chunk=512).factorise(g["X"], g["y"], g["kernel_params"])
+    r = gp.score(g["Xs"], dense=True)
+    acq = r.acq.cpu().numpy()
+    assert np.array_equal(acq, g["acq_func_eval"].ravel())  # k* underflows to exactly 0: 2,500 identical values
+    assert r.best_idx == 0
+    # the same tie split over two "ranks": the lower shard must win
+    lo0, hi0 = D.shard_bounds(2500, 2, 0)
+    lo1, hi1 = D.shard_bounds(2500, 2, 1)
+    r0 = gp.score(g["Xs"][lo0:hi0], idx_offset=lo0)
+    r1 = gp.score(g["Xs"][lo1:hi1], idx_offset=lo1)
+    assert D.reduce_records([(r1.best_val, r1.best_idx, 0), (r0.best_val, r0.best_idx, 0)])[1] == 0
+
+
+def test_nan_is_counted_not_hidden():
+    X, y, Xs, ls = make_problem(16, 128, 2)
+    y = y.copy()
+    y[3] = np.nan
+    gp = DeviceGP().factorise(X, y, ls)
+    r = gp.score(Xs)
+    assert r.nan_count == 128
+
+
+def test_not_positive_definite_raises():
+    X = np.zeros((4, 2))
+    X[:, 0] = [0.0, 0.0, 1.0, 1.0]  # duplicated rows, and a negative jitter to break definiteness
+    with pytest.raises(np.linalg.LinAlgError):
+        DeviceGP().factorise(X, np.ones(4), np.array([1.0, 1.0]), jitter1=-1e-3, jitter2=0.0)
+
+
+# ----------------------------------------------------------------------------------------------
+# the drop-in class against the reference's golden outputs
+# ----------------------------------------------------------------------------------------------
+def _run_dropin(g, preset=False):
+    ps = PointSelector()
+    ps.name = "T"
+    ps.iteration = 0
+    ps.measured_pts = g["X"]
+    ps.measured_vals = g["y"]
+    ps.feature_domain = [int(v) for v in g["feature_domain"]]
+    ps.predicted_pts = g["Xs"]
+    if preset:
+        ps.set_kernel_params(g["kernel_params"] if "kernel_params" in g else g["ls"])
+    else:
+        ps.length_scales = g["length_scales"]
+    ps.update_surrogate()
+    idx = ps.lower_confidence_bound()
+    return ps, idx
+
+
+@pytest.mark.parametrize("name", ["g1_m32", "g1_m50", "g4_ard_n2", "g2_n1_tr", "g2_n5_a", "g2_n20_tr", "g2_n12_a",
+                                  "g3_n1_2d"])
+def test_dropin_full_path_with_ard(golden, name):
+    g = golden(name)
+    ps, idx = _run_dropin(g)
+    assert np.array_equal(np.asarray(ps.kernel_params), g["kernel_params"])
+    assert ps.kernel_params.shape == g["kernel_params"].shape
+    assert idx.dtype == np.int64 and idx.shape == g["index"].shape
+    assert ps.mean_func.shape == g["mean_func"].shape
+    _check_against(ps.mean_func.ravel(), ps.cov_func.ravel(), ps.acq_func_eval.ravel(),
+                   int(np.ravel_multi_index(tuple(idx), g["mean_func"].shape)), g)
+    assert isinstance(ps.measured_pts, list) and isinstance(ps.measured_vals, list)  # point_selector.py:101-102
+    assert ps.cov_meas.shape == (len(g["X"]), len(g["X"]))
+    assert ps.cov_pred is not None and ps.cov_pred.shape == (len(g["Xs"]), len(g["Xs"]))
+    assert ps.cov_meas_pred.shape == (len(g["Xs"]), len(g["X"]))
+    if "nlogml" in g:
+        np.testing.assert_allclose(ps.nlogml, g["nlogml"], rtol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["g4_tie_tiny_ls", "g4_dup_rows", "g7_n_eq_m"])
+def test_dropin_preset_length_scales(golden, name):
+    g = golden(name)
+    ps, idx = _run_dropin(g, preset=True)
+    _check_against(ps.mean_func.ravel(), ps.cov_func.ravel(), ps.acq_func_eval.ravel(),
+                   int(np.ravel_multi_index(tuple(idx), g["mean_func"].shape)), g)
+    if name == "g7_n_eq_m":  # shape-coincidence quirk: +1e-4 on the diagonal of K(X*, X)
+        np.testing.assert_allclose(np.diag(ps.cov_meas_pred), g["cov_meas_pred_diag"], rtol=0, atol=1e-15)
+
+
+def test_dropin_nan_raises_index_error(golden):
+    g = golden("g8_nan")
+    with pytest.raises(IndexError):
+        _run_dropin(g, preset=True)
+
+
+def test_dropin_second_acquisition_matches_numpy_line():
+    g_X, g_y, g_Xs, ls = make_problem(40, 900, 2)
+    ps = PointSelector()
+    ps.measured_pts, ps.measured_vals = g_X, g_y
+    ps.feature_domain, ps.predicted_pts = [30, 30], g_Xs
+    ps.set_kernel_params(ls)
+    ps.update_surrogate()
+    i4 = ps.lower_confidence_bound()
+    a4 = ps.acq_func_eval.copy()
+    i1 = ps.lower_confidence_bound(explore=1)
+    assert np.array_equal(a4, 4 * ps.cov_func - ps.mean_func)
+    assert np.array_equal(ps.acq_func_eval, 1 * ps.cov_func - ps.mean_func)
+    assert np.array_equal(i4, np.argwhere(a4 == a4.max())[0])
+    assert np.array_equal(i1, np.argwhere(ps.acq_func_eval == ps.acq_func_eval.max())[0])
+    ie = ps.expected_improvement()
+    ei = O.expected_improvement(ps.mean_func, ps.cov_func, float(np.min(g_y)))
+    np.testing.assert_allclose(ps.acq_func_eval, ei, rtol=1e-12, atol=1e-15)
+    assert np.array_equal(ie, np.argwhere(ps.acq_func_eval == ps.acq_func_eval.max())[0])
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json config 2 at full size: d=8, N=512, M=2^20 - size-independent properties
+# ----------------------------------------------------------------------------------------------
+def test_config2_full_size_properties():
+    N, M, d = 512, 1 << 20, 8
+    X, y, Xs, ls = make_problem(N, M, d)
+    gp = DeviceGP(chunk=1 << 17).factorise(X, y, ls)
+    r = gp.score(Xs, dense=True)
+    mu, sig, acq = r.mu.cpu().numpy(), r.sigma.cpu().numpy(), r.acq.cpu().numpy()
+    assert r.nan_count == 0 and np.isfinite(acq).all()
+    # (1) reported arg-max is the first maximum of the dense acquisition
+    assert r.best_idx == _first_argmax(acq) and r.best_val == acq.max()
+    # (2) chunk-size invariance, bit for bit
+    gp2 = DeviceGP(chunk=1 << 15).factorise(X, y, ls)
+    r2 = gp2.score(Xs, dense=True)
+    assert np.array_equal(r2.acq.cpu().numpy(), acq) and r2.best_idx == r.best_idx
+    # (3) shard invariance: 8 contiguous shards + the lexicographic reduce == single call
+    recs = []
+    for rank in range(8):
+        lo, hi = D.shard_bounds(M, 8, rank)
+        rr = gp.score(Xs[lo:hi], idx_offset=lo)
+        recs.append((rr.best_val, rr.best_idx, rr.nan_count))
+    assert D.reduce_records(recs)[:2] == (r.best_val, r.best_idx)
+    # (4) oracle on a seeded sub-sample that includes the winner and its runner-ups
+    rng = np.random.default_rng(0)
+    top = np.argsort(acq)[-64:]
+    sub = np.unique(np.concatenate([rng.choice(M, 8192, replace=False), top]))
+    mu_o, sig_o = O.posterior_chol(X, y, Xs[sub], ls)
+    assert np.max(np.abs(mu[sub] - mu_o)) <= 1e-10 * max(1.0, np.abs(y).max())
+    assert np.max(np.abs(sig[sub] - sig_o)) <= 1e-9
+    acq_o = O.lcb(mu_o, sig_o, 4)
+    top2 = np.sort(acq_o)[-2:]
+    if top2[1] - top2[0] > 1e-7:
+        assert sub[_first_argmax(acq_o)] == r.best_idx
