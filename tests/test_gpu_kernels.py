@@ -72,7 +72,8 @@ def test_kxx(env, N, d):
     ls = np.geomspace(0.2, 2.0, d)
     Np = int(lib.gpbo_padded_n(N))
     K = t.full((Np, Np), 7.0, dtype=t.float64, device=env.dev)
-    assert lib.gpbo_kxx_f64(env.p(env.to(X)), N, d, env.hp(ls), 1e-4, 1e-6, env.p(K), Np, env.stream()) == 0
+    dX = env.to(X)
+    assert lib.gpbo_kxx_f64(env.p(dX), N, d, env.hp(ls), 1e-4, 1e-6, env.p(K), Np, env.stream()) == 0
     got = K.cpu().numpy()
     ref = O.kernel_rbf(X, X, ls) + 1e-6 * np.eye(N)
     np.testing.assert_allclose(got[:N, :N], ref, rtol=0, atol=5e-15)
@@ -115,7 +116,8 @@ def test_potrf_trtri_alpha(env, n):
     assert np.array_equal(np.tril(Ug, -1), np.zeros((n, n)))
     tmp = t.empty(n, dtype=t.float64, device=env.dev)
     alpha = t.full((n,), 3.0, dtype=t.float64, device=env.dev)
-    assert lib.gpbo_alpha_f64(env.p(U), env.p(env.to(y)), N, n, env.p(tmp), env.p(alpha), env.stream()) == 0
+    dy = env.to(y)
+    assert lib.gpbo_alpha_f64(env.p(U), env.p(dy), N, n, env.p(tmp), env.p(alpha), env.stream()) == 0
     aref = sla.cho_solve((Lref[:N, :N], True), y)
     got = alpha.cpu().numpy()
     np.testing.assert_allclose(got[:N], aref, rtol=0, atol=1e-10 * np.abs(aref).max())
@@ -148,7 +150,8 @@ def test_kstar_mu(env, N, M, d):
     ldk = (M + 511) // 512 * 512
     kst = t.full((Np, ldk), np.nan, dtype=t.float64, device=env.dev)
     mup = t.full((Np // 128, ldk), np.nan, dtype=t.float64, device=env.dev)
-    st = lib.gpbo_kstar_mu_f64(env.p(env.to(Xs)), M, env.p(env.to(X)), N, Np, d, env.hp(ls), env.p(env.to(alpha)),
+    dXs, dX, dal = env.to(Xs), env.to(X), env.to(alpha)  # keep the device buffers alive across the call
+    st = lib.gpbo_kstar_mu_f64(env.p(dXs), M, env.p(dX), N, Np, d, env.hp(ls), env.p(dal),
                                0.0, 0, env.p(kst), ldk, env.p(mup), env.stream())
     assert st == 0
     got = kst.cpu().numpy()
