@@ -37,7 +37,11 @@ SIGNATURES = {
     "gpbo_kstar_mu_f64": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _f64, _i64, _p, _i64, _p, _p]),
     "gpbo_posterior_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gpbo_posterior_acq_f64": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _i32, _f64, _f64, _f64,
-                                         _i64, _i64, _p, _p, _p, _p, _p, _i64, _p]),
+                                         _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _p]),
+    "gpbo_profile_create": (C.c_int, [_i32, C.POINTER(_p)]),
+    "gpbo_profile_reset": (None, [_p]),
+    "gpbo_profile_read": (C.c_int, [_p, C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "gpbo_profile_destroy": (None, [_p]),
     "gpbo_acq_workspace_bytes": (_i64, []),
     "gpbo_acq_argmax_f64": (C.c_int, [_p, _p, _i64, _i32, _f64, _f64, _i64, _p, _p, _p, _i64, _p]),
     "gpbo_nlml_grid_max_n": (C.c_int, []),

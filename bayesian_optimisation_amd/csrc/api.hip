@@ -17,3 +17,57 @@ extern "C" int64_t gpbo_padded_n(int64_t N) {
     if (N < 1) N = 1;
     return (N + GPBO_NPAD - 1) / GPBO_NPAD * GPBO_NPAD;
 }
+
+// ---- optional per-launch timing of the dominant kernel (hipEvents on the caller's stream) ----------
+extern "C" int gpbo_profile_create(int32_t capacity, gpbo_profile **out) {
+    if (capacity < 1 || !out) return GPBO_ERR_ARG;
+    gpbo_profile *p = new gpbo_profile;
+    p->capacity = capacity;
+    p->count = 0;
+    p->begin = new void *[capacity];
+    p->end = new void *[capacity];
+    p->cands = new int64_t[capacity];
+    for (int i = 0; i < capacity; ++i) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return GPBO_ERR_LAUNCH;
+        p->begin[i] = a;
+        p->end[i] = b;
+        p->cands[i] = 0;
+    }
+    *out = p;
+    return GPBO_OK;
+}
+
+extern "C" void gpbo_profile_reset(gpbo_profile *p) {
+    if (p) p->count = 0;
+}
+
+extern "C" int gpbo_profile_read(gpbo_profile *p, double *total_ms, int64_t *launches, int64_t *cands) {
+    if (!p || !total_ms || !launches || !cands) return GPBO_ERR_ARG;
+    double sum = 0.0;
+    int64_t nc = 0;
+    for (int i = 0; i < p->count; ++i) {
+        hipEvent_t a = reinterpret_cast<hipEvent_t>(p->begin[i]), b = reinterpret_cast<hipEvent_t>(p->end[i]);
+        if (hipEventSynchronize(b) != hipSuccess) return GPBO_ERR_LAUNCH;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return GPBO_ERR_LAUNCH;
+        sum += ms;
+        nc += p->cands[i];
+    }
+    *total_ms = sum;
+    *launches = p->count;
+    *cands = nc;
+    return GPBO_OK;
+}
+
+extern "C" void gpbo_profile_destroy(gpbo_profile *p) {
+    if (!p) return;
+    for (int i = 0; i < p->capacity; ++i) {
+        (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(p->begin[i]));
+        (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(p->end[i]));
+    }
+    delete[] p->begin;
+    delete[] p->end;
+    delete[] p->cands;
+    delete p;
+}

@@ -302,7 +302,8 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
                                       const double *ls_host, const double *U, const double *alpha, double prior_var,
                                       int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset,
                                       int64_t chunk, double *mu_out, double *sigma_out, double *acq_out,
-                                      gpbo_result *result, void *work, int64_t work_bytes, void *stream) {
+                                      gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof,
+                                      void *stream) {
     if (!Xs || !X || !U || !alpha || !result || !work) return GPBO_ERR_ARG;
     if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || Np > (1 << 20)) return GPBO_ERR_ARG;
     if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE) return GPBO_ERR_ARG;
@@ -326,10 +327,19 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
                                    mu_part, stream);
         if (rc != GPBO_OK) return rc;
         const int64_t nblk = (Mc + BM - 1) / BM;
+        const bool rec = prof && prof->count < prof->capacity;
+        if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
         hipLaunchKernelGGL(sigma_acq_kernel, dim3((unsigned)nblk), dim3(512), 0, st, KsT, chunk, U, (int)Np, mu_part,
                            (int)(Np / 128), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                            mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
                            acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count);
+        if (rec) {
+            if (hipEventRecord(reinterpret_cast<hipEvent_t>(prof->end[prof->count]), st) != hipSuccess)
+                return GPBO_ERR_LAUNCH;
+            prof->cands[prof->count] = Mc;
+            ++prof->count;
+        }
         GPBO_CHECK_LAUNCH();
         nparts += nblk;
     }

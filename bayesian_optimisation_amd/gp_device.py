@@ -56,6 +56,22 @@ class DeviceGP:
         self.N = self.Np = self.d = 0
         self._work_post = None
         self._result = torch.zeros(4, dtype=torch.int64, device=self.device)
+        self._profile = C.c_void_p(0)
+
+    # -- per-launch timing of the dominant kernel (bench.py) -----------------------------------------
+    def enable_profile(self, capacity: int = 4096):
+        p = C.c_void_p(0)
+        _lib.check(self.lib.gpbo_profile_create(int(capacity), C.byref(p)), "gpbo_profile_create")
+        self._profile = p
+
+    def reset_profile(self):
+        self.lib.gpbo_profile_reset(self._profile)
+
+    def read_profile(self):
+        """(total ms, launches, candidates) summed over the recorded sigma/acquisition launches."""
+        ms, n, c = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(self.lib.gpbo_profile_read(self._profile, C.byref(ms), C.byref(n), C.byref(c)), "gpbo_profile_read")
+        return ms.value, n.value, c.value
 
     # -- helpers -------------------------------------------------------------------------------
     def _stream(self):
@@ -153,7 +169,8 @@ class DeviceGP:
                 self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d,
                 self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.U), self._ptr(self.alpha), prior_var,
                 kind, p0, p1, float(diag_add), int(idx_offset), chunk, self._ptr(mu), self._ptr(sigma),
-                self._ptr(acq), self._ptr(self._result), self._ptr(self._work_post), wbytes, self._stream())
+                self._ptr(acq), self._ptr(self._result), self._ptr(self._work_post), wbytes, self._profile,
+                self._stream())
             _lib.check(st, "gpbo_posterior_acq_f64")
         self._keep = Xsd  # keep the candidate tensor alive until the stream has consumed it
         return self._result, mu, sigma, acq

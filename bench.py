@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py - candidate acquisitions/sec of the GP acquisition path on MI355X.
+
+One "step" = one BO inner-loop pass over one batch of synthetic input, everything resident in HBM
+when the timed region starts:
+    factorise K(X,X)+jitter (kxx, Cholesky, U = L^-T, alpha)            [once per step]
+    K(X*,X) + mu + sigma + acquisition (LCB, explore=4) + arg-max        [every candidate of the rank]
+    one all-gather of (best value, lowest index, NaN count) across ranks [N > 1 only]
+Workload at N=1: BASELINE.json configs[1]  (d=8, N=512, M=2^20 Sobol candidates, fp64).
+For N>1 the candidate set grows with N (2^20 per GPU, contiguous shards): weak scaling; the reported
+value is the whole-job rate M_total / max-over-ranks step time.
+
+Usage: python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak = fp64 vector peak (half the 157.3 TF fp32 rate
+#                               listed in MI355X_MICROARCH.md; AMD data sheet value)
+
+
+def cpu_baseline(X, y, Xs_sample, ls):
+    """The oracle's Cholesky route (NumPy/LAPACK, BLAS threads = host cores) on a bounded sample of the
+    same workload; factorisation excluded (it is amortised over the 2^20 candidates of a real step)."""
+    import numpy as np
+
+    from oracle import gp_oracle as O
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:  # noqa: BLE001
+        threads = os.cpu_count() or 1
+    _, L, alpha = O.factorise(X, y, ls)
+    t0 = time.perf_counter()
+    mu, sig = O.posterior_chol(X, y, Xs_sample, ls, L=L, alpha=alpha)
+    acq = O.lcb(mu, sig, 4)
+    idx = int(np.flatnonzero(acq == acq.max())[0])
+    dt = time.perf_counter() - t0
+    return dict(value=len(Xs_sample) / dt, unit="candidate acquisitions/s", cores=int(threads), kind="port",
+                sample=f"first {len(Xs_sample)} of the 2^20 candidates, N=512, d=8, posterior+LCB+argmax, "
+                       f"{dt:.1f} s wall, factorisation excluded"), idx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-obs", type=int, default=512)
+    ap.add_argument("--m-per-gpu", type=int, default=1 << 20)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from bayesian_optimisation_amd import DeviceGP
+    from bayesian_optimisation_amd import distributed as D
+    from bayesian_optimisation_amd.synthetic import ard_length_scales, rff_objective, sobol_points
+
+    N, d = args.n_obs, args.d
+    M_total = args.m_per_gpu * world
+    lo, hi = D.shard_bounds(M_total, world, rank)
+    ls = ard_length_scales(d)
+    X = sobol_points(0, N, d)
+    y = rff_objective(X, ls)
+    Xs_local = sobol_points(N + lo, hi - lo, d)  # this rank's contiguous shard of the Sobol candidate stream
+    kw = dict(chunk=args.chunk) if args.chunk else {}
+    gp = DeviceGP(dev, **kw)
+    Xd, yd, Xsd = gp._dev(X), gp._dev(y), gp._dev(Xs_local)  # inputs resident in HBM before timing
+    gp.enable_profile(8192)
+
+    def step():
+        gp.factorise(Xd, yd, ls, check=False)
+        res, _, _, _ = gp.score_async(Xsd, acquisition="lcb", explore=4.0, idx_offset=lo)
+        v, i, n = gp.read_result(res)               # 32-byte read-back (synchronises this rank)
+        if int(gp.info.item()) != 0:
+            raise RuntimeError("Cholesky failed")
+        return D.allreduce_argmax(v, i, n)           # the one exchange step (no-op at N=1)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        best = step()
+    gp.reset_profile()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        best = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_step = dt / args.steps * 1e3
+    value = M_total / (dt / args.steps)
+
+    # dominant kernel (sigma/acquisition/arg-max): hipEvent pairs recorded on its stream inside the timed region
+    k_ms, k_launches, k_cands = gp.read_profile()
+    k_avg_ms = k_ms / max(k_launches, 1)
+    cand_per_launch = k_cands / max(k_launches, 1)
+    flop_per_cand = float(N) * N + 2.0 * N           # triangular product N^2 + |v|^2 2N  
+    achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "pmc_sigma_acq.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                    kernel="sigma_acq_kernel", launches=int(k_launches), avg_launch_ms=round(k_avg_ms, 4),
+                    flop_per_candidate=flop_per_cand, candidates_per_launch=cand_per_launch)
+
+    # time of the scoring part alone (factorisation excluded), for the record
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(max(3, args.steps // 4)):
+        res, _, _, _ = gp.score_async(Xsd, acquisition="lcb", explore=4.0, idx_offset=lo)
+        gp.read_result(res)
+    torch.cuda.synchronize(dev)
+    ms_score = (time.perf_counter() - t1) / max(3, args.steps // 4) * 1e3
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "candidate acquisitions/sec", "value": value, "unit": "candidates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: d={d}, N={N} Sobol observations, M=2^{int(np.log2(args.m_per_gpu))} "
+                                   f"Sobol candidates per GPU, ARD-SE GP, LCB(explore=4) arg-max, fp64; "
+                                   f"step = factorise + score all candidates + reduce",
+                       "candidates_total": M_total, "parallelism": f"candidate-sharded x{world}"},
+            "ms_per_step_scoring_only": ms_score,
+            "value_excl_factorisation": (hi - lo) * world / (ms_score * 1e-3),
+            "argmax_index": best[1], "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ns = min(args.cpu_sample, hi - lo)
+            cb, idx_cpu = cpu_baseline(X, y, Xs_local[:ns], ls)
+            r = gp.score(Xsd[:ns], acquisition="lcb", explore=4.0)
+            cb["argmax_match_on_sample"] = bool(r.best_idx == idx_cpu)
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

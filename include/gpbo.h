@@ -49,6 +49,19 @@ typedef struct gpbo_result {
     int64_t reserved;
 } gpbo_result;
 
+/* Optional timing of the dominant kernel (sigma/acquisition): one hipEvent pair per launch, recorded
+ * on the caller's stream by gpbo_posterior_acq_f64 when a profile is passed.  Host-side object. */
+typedef struct gpbo_profile {
+    int32_t capacity, count;
+    void **begin, **end; /* hipEvent_t */
+    int64_t *cands;      /* candidates processed by each recorded launch */
+} gpbo_profile;
+int gpbo_profile_create(int32_t capacity, gpbo_profile **out);
+void gpbo_profile_reset(gpbo_profile *p);
+/* Waits for the recorded events; sums elapsed ms, launches and candidates over all recorded launches. */
+int gpbo_profile_read(gpbo_profile *p, double *total_ms_host, int64_t *launches_host, int64_t *cands_host);
+void gpbo_profile_destroy(gpbo_profile *p);
+
 int gpbo_version(void);
 const char *gpbo_strerror(int status);
 int64_t gpbo_padded_n(int64_t N);
@@ -106,7 +119,8 @@ int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double *X, int64_t
                            const double *ls_host, const double *U, const double *alpha, double prior_var,
                            int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset,
                            int64_t chunk, double *mu_out, double *sigma_out, double *acq_out,
-                           gpbo_result *result, void *work, int64_t work_bytes, void *stream);
+                           gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof /* or NULL */,
+                           void *stream);
 
 /* K7+K8 on a posterior already on the device: acq = LCB/EI of (mu, sigma), first-index arg-max
  * (point_selector.py:204-207).  Used for a second acquisition on the same surrogate.
