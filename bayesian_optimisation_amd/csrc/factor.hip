@@ -26,39 +26,62 @@ constexpr int LDS_LD = NB + 1;
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ K, int64_t ld, int jb,
                                                          double *__restrict__ dinv, int32_t *__restrict__ info) {
-    __shared__ double a[NB * LDS_LD];
     __shared__ double l[NB * LDS_LD];
     __shared__ double w[NB * LDS_LD];
     __shared__ double t[NB * LDS_LD];
+    __shared__ double colbuf[2][NB];
     const int tid = threadIdx.x;
     double *Kd = K + ((int64_t)jb * NB) * ld + (int64_t)jb * NB;
 
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        a[r * LDS_LD + c] = (c <= r) ? Kd[(int64_t)r * ld + c] : 0.0;
-        l[r * LDS_LD + c] = 0.0;
-        w[r * LDS_LD + c] = 0.0;
-    }
-    for (int c = 0; c < NB; ++c) {
-        __syncthreads();
-        const double piv = a[c * LDS_LD + c];
-        if (!(piv > 0.0) || !(piv < 1.0e300)) {  // non-positive, NaN or Inf pivot
-            if (tid == 0) atomicCAS(info, 0, jb * NB + c + 1);
+    // Factorisation with the Schur complement held in registers: thread (ti, tj) owns the 4x4 tile
+    // rows 4ti.., cols 4tj.. (only tj <= ti carries data).  Per column c: the 16 threads that own it
+    // publish the (unscaled) column through LDS, everybody scales on the fly and updates its tile.
+    // One barrier per column (colbuf is double-buffered); no LDS read-modify-write chains.
+    const int ti = tid >> 4, tj = tid & 15;
+    double a[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * ti + i, q = 4 * tj + j;
+            a[i][j] = (q <= r) ? Kd[(int64_t)r * ld + q] : 0.0;
         }
-        const double dd = sqrt(piv);
-        const double inv = 1.0 / dd;
-        // trailing update of the lower triangle: a[r][q] -= (a[r][c]/d) * (a[q][c]/d),  c < q <= r
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int r = e >> 6, q = e & 63;
-            if (q > c && r >= q) {
-                const double lr = a[r * LDS_LD + c] * inv;
-                const double lq = a[q * LDS_LD + c] * inv;
-                a[r * LDS_LD + q] = fma(-lr, lq, a[r * LDS_LD + q]);
+    for (int e = tid; e < NB * LDS_LD; e += 256) { l[e] = 0.0; w[e] = 0.0; }
+    bool bad = false;
+    for (int cj = 0; cj < NB / 4; ++cj) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = 4 * cj + cc;
+            double *cb = colbuf[c & 1];
+            if (tj == cj) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cb[4 * ti + i] = a[i][cc];
             }
-        }
-        if (tid < NB) {
-            if (tid == c) l[c * LDS_LD + c] = dd;
-            else if (tid > c) l[tid * LDS_LD + c] = a[tid * LDS_LD + c] * inv;
+            __syncthreads();
+            const double piv = cb[c];
+            if (!(piv > 0.0) || !(piv < 1.0e300)) bad = true;  // non-positive, NaN or Inf pivot
+            if (bad && tid == 0) atomicCAS(info, 0, jb * NB + c + 1);
+            const double dd = sqrt(piv);
+            const double inv = 1.0 / dd;
+            double lr[4], lq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { lr[i] = cb[4 * ti + i] * inv; lq[i] = cb[4 * tj + i] * inv; }
+            if (tj == cj) {  // column c of L
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * ti + i;
+                    if (r == c) l[r * LDS_LD + c] = dd;
+                    else if (r > c) l[r * LDS_LD + c] = lr[i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool upd = (tj > cj) || (tj == cj && j > cc);  // columns to the right of c
+                if (upd) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i][j] = fma(-lr[i], lq[j], a[i][j]);
+                }
+            }
         }
     }
     __syncthreads();
@@ -130,15 +153,24 @@ __global__ __launch_bounds__(256) void transpose_upper_kernel(const double *__re
     }
 }
 
-// tmp_i = sum_{m<=i} U[m][i] y_m   (= (L^-1 y)_i).  One thread per i, coalesced across i.
-__global__ __launch_bounds__(256) void utv_kernel(const double *__restrict__ U, const double *__restrict__ y,
-                                                  int64_t N, int64_t Np, double *__restrict__ tmp) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= Np) return;
+// tmp_i = sum_{m<=i} U[m][i] y_m   (= (L^-1 y)_i).  Block = 64 columns x 16 row groups; lanes run
+// over i (coalesced rows of U), row group g takes m = g, g+16, ...; fixed-order LDS reduction.
+__global__ __launch_bounds__(1024) void utv_kernel(const double *__restrict__ U, const double *__restrict__ y,
+                                                   int64_t N, int64_t Np, double *__restrict__ tmp) {
+    __shared__ double part[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     double s = 0.0;
     const int64_t mend = (i < N ? i : N - 1);
-    for (int64_t m = 0; m <= mend; ++m) s = fma(U[m * Np + i], y[m], s);
-    tmp[i] = s;
+    for (int64_t m = g; m <= mend; m += 16) s = fma(U[m * Np + i], y[m], s);
+    part[g][lane] = s;
+    __syncthreads();
+    if (g == 0) {
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += part[k][lane];
+        tmp[i] = r;
+    }
 }
 
 // alpha_m = sum_{i>=m} U[m][i] tmp_i.  One wave per row m, lanes stride over i, fixed-order reduce.
@@ -231,7 +263,7 @@ extern "C" int gpbo_alpha_f64(const double *U, const double *y, int64_t N, int64
                               void *stream) {
     if (!U || !y || !tmp || !alpha || N < 1 || Np < N || Np % GPBO_NPAD) return GPBO_ERR_ARG;
     hipStream_t st = gpbo_stream(stream);
-    hipLaunchKernelGGL(utv_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, U, y, N, Np, tmp);
+    hipLaunchKernelGGL(utv_kernel, dim3((unsigned)(Np / 64)), dim3(1024), 0, st, U, y, N, Np, tmp);
     hipLaunchKernelGGL(uv_kernel, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, st, U, tmp, N, Np, alpha);
     GPBO_CHECK_LAUNCH();
     return GPBO_OK;

@@ -19,6 +19,7 @@
 // left half runs out of non-zero U tiles on the diagonal the right half has the matrix pipe alone.
 #include "gpbo_internal.h"
 
+#include <cstdlib>
 #include <limits>
 
 namespace {
@@ -29,6 +30,15 @@ constexpr int LDB = BN + 16;
 constexpr int A_TILE = BK * LDA;  // 4352 doubles
 constexpr int B_TILE = BK * LDB;  // 2304 doubles
 constexpr int STAGE = A_TILE + B_TILE;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// 16 bytes per lane, global -> LDS without a VGPR round trip.  The LDS destination is the wave-uniform
+// address `l` plus lane*16; the global source is per lane.
+__device__ __forceinline__ void glds16(const double *g, double *l) {
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)l, 16, 0, 0);
+}
 
 __device__ __forceinline__ bool better(double v2, int64_t i2, double v, int64_t i) {
     return (v2 > v) || (v2 == v && i2 < i);
@@ -45,12 +55,13 @@ __device__ __forceinline__ double acquisition(int kind, double mu, double sigma,
     return imp * cdf + sigma * pdf;
 }
 
+template <int VARIANT>  // 0 = product; 1, 2 = timing-only diagnostics (GPBO_SIGMA_VARIANT), wrong results
 __global__ __launch_bounds__(512) void sigma_acq_kernel(
     const double *__restrict__ KsT, int64_t ldk, const double *__restrict__ U, int Np,
     const double *__restrict__ mu_part, int nsl, int64_t Mc, double prior_var, int acq_kind, double p0, double p1,
     int64_t idx_base, double *__restrict__ mu_out, double *__restrict__ sigma_out, double *__restrict__ acq_out,
     double *__restrict__ part_val, int64_t *__restrict__ part_idx, unsigned long long *__restrict__ nan_count) {
-    __shared__ double smem[2 * STAGE];
+    __shared__ double smem[3 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -59,12 +70,13 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t cand0 = (int64_t)blockIdx.x * BM;
 
-    // staging coordinates (16-byte chunks)
-    const int a_row = tid >> 7, a_c = (tid & 127) * 2;  // rows a_row + 4r, r = 0..3
-    const int b_row = tid >> 6, b_c = (tid & 63) * 2;   // rows b_row + 8r, r = 0..1
-    const double *a_src = KsT + (int64_t)a_row * ldk + cand0 + a_c;
-    const double *b_src = U + (int64_t)b_row * Np + b_c;
-
+    // staging: global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPRs).
+    // LDS image rows are padded, and every wave instruction's 1 KiB lies inside one row:
+    //   A tile: 16 rows x 2 halves = 32 units, wave w takes units w + 8r (r = 0..3)
+    //   B tile: 16 rows x 1        = 16 units, wave w takes rows  w + 8r (r = 0..1)
+    const double *a_src = KsT + cand0;  // wave-uniform bases; the lane offset rides in the VGPR operand
+    const double *b_src = U;
+    const int lane2 = lane * 2;
     d4_t acc[4][4];
     double ss[4][4];
 #pragma unroll
@@ -76,56 +88,106 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         }
 
     const int nJ = Np / BN;
-    d2_t ra[4], rb[2];
-
-    auto gload = [&](int jb, int kt) {
-        const double *ap = a_src + (int64_t)kt * BK * ldk;
-        const double *bp = b_src + (int64_t)kt * BK * Np + jb * BN;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ra[r] = *reinterpret_cast<const d2_t *>(ap + (int64_t)(4 * r) * ldk);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) rb[r] = *reinterpret_cast<const d2_t *>(bp + (int64_t)(8 * r) * Np);
-    };
-    auto sstore = [&](int buf) {
+    auto stage = [&](int jb, int kt, int buf) {
         double *As = smem + buf * STAGE;
         double *Bs = As + A_TILE;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<d2_t *>(&As[(a_row + 4 * r) * LDA + a_c]) = ra[r];
+        for (int r = 0; r < 4; ++r) {
+            const int u = wid + 8 * r, row = u >> 1, half = u & 1;
+            glds16(a_src + (int64_t)(kt * BK + row) * ldk + half * 128 + lane2, As + row * LDA + half * 128);
+        }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) *reinterpret_cast<d2_t *>(&Bs[(b_row + 8 * r) * LDB + b_c]) = rb[r];
+        for (int r = 0; r < 2; ++r) {
+            const int row = wid + 8 * r;
+            glds16(b_src + (int64_t)(kt * BK + row) * Np + jb * BN + lane2, Bs + row * LDB);
+        }
     };
 
+    // Flattened tile sequence (jb, kt): kt = 0 .. 8(jb+1)-1 for jb = 0 .. nJ-1.  Three LDS stages: while tile t
+    // is multiplied, tile t+1 has landed or is landing and tile t+2 is being issued - the wait before the
+    // barrier is a counted vmcnt that leaves the newest tile's 6 LDS-DMA instructions in flight (a plain
+    // __syncthreads() would drain them: hipcc puts vmcnt(0) in front of it).
+    auto advance = [&](int &j, int &k) {
+        if (++k == (j + 1) * (BN / BK)) { ++j; k = 0; }
+    };
     int jb = 0, kt = 0, cur = 0;
-    gload(0, 0);
-    sstore(0);
-    __syncthreads();
+    int pj = 0, pk = 0, pbuf = 0;  // next tile to stage
+    stage(pj, pk, pbuf);
+    advance(pj, pk);
+    pbuf = 1;
+    if (pj < nJ) {
+        stage(pj, pk, pbuf);
+        advance(pj, pk);
+        pbuf = 2;
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
     while (true) {
         const int kt_end = (jb + 1) * (BN / BK);  // k tiles of this column block
-        int njb = jb, nkt = kt + 1;
-        if (nkt == kt_end) { njb = jb + 1; nkt = 0; }
-        const bool has_next = njb < nJ;
-        if (has_next) gload(njb, nkt);
+        const bool staged = (pj < nJ) && VARIANT != 1 && VARIANT != 4;
+        // The 6 LDS-DMA issues cost each wave several hundred cycles in which it feeds no MFMAs.  The two
+        // waves of a SIMD (w and w+4, i.e. wc = 0 / 1) leave the barrier together, so they are staggered:
+        // wc = 0 issues its share here, wc = 1 half a tile later, under the partner's MFMAs.
+        if (staged && wc == 0) stage(pj, pk, pbuf);  // two tiles ahead; its stage was last read one iteration ago
 
         const double *As = smem + cur * STAGE;
         const double *Bs = As + A_TILE;
         // first 16-column tile of this wave that still has non-zero rows of U in this k tile
         int ni_min = kt - jb * (BN / BK) - wc * 4;
         ni_min = ni_min < 0 ? 0 : ni_min;
+        if (VARIANT == 2) ni_min = 0;
         if (ni_min < 4) {
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 4) {
-                double af[4];
+            // One code path for full and diagonal tiles (two paths make hipcc keep two copies of the 128
+            // accumulator registers).  LDS reads are unconditional and software-pipelined by hand: the
+            // reads of step kk+1 are issued under the MFMAs of step kk; only the MFMA groups of 16-column
+            // tiles that lie wholly below U's diagonal are branched over (wave-uniform scalar branch).
+            // sched_barrier keeps the compiler from hoisting all four steps' reads (register spills).
+            double a0[4], b0[4], a1[4], b1[4];
+            auto lds_frag = [&](double (&af)[4], double (&bf)[4], int kk) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) af[mi] = As[(kk + l4) * LDA + wr * 64 + mi * 16 + l15];
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    if (ni >= ni_min) {
-                        const double bf = Bs[(kk + l4) * LDB + wc * 64 + ni * 16 + l15];
+                for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[(kk + l4) * LDB + wc * 64 + ni * 16 + l15];
+            };
+            auto mfma8 = [&](const double (&af)[4], const double (&bf)[4], int nlo) {
 #pragma unroll
-                        for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf, acc[mi][ni]);
+                for (int ni = nlo; ni < nlo + 2; ++ni) {
+                    if (ni >= ni_min) {
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf[ni], acc[mi][ni]);
                     }
                 }
-            }
+            };
+            // step kk: 8 MFMAs, then the LDS reads of step kk+1, then the other 8 MFMAs - every read has at
+            // least 8 MFMAs (>= 512 cycles) to land before the s_waitcnt that precedes its first use
+            lds_frag(a0, b0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(a0, b0, 0);
+            lds_frag(a1, b1, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(a0, b0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(a1, b1, 0);
+            lds_frag(a0, b0, 8);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(a1, b1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (staged && wc == 1) stage(pj, pk, pbuf);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(a0, b0, 0);
+            lds_frag(a1, b1, 12);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(a0, b0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(a1, b1, 0);
+            mfma8(a1, b1, 2);
+        }
+        else if (staged && wc == 1) stage(pj, pk, pbuf);  // (idle diagonal tile of the right half)
+        if (staged) {
+            advance(pj, pk);
+            pbuf = (pbuf == 2) ? 0 : pbuf + 1;
         }
         if (kt + 1 == kt_end) {  // column block finished: fold |V|^2 into the row sums
 #pragma unroll
@@ -137,12 +199,15 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
                     acc[mi][ni] = d4_t{0.0, 0.0, 0.0, 0.0};
                 }
         }
-        if (!has_next) break;
-        sstore(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-        jb = njb;
-        kt = nkt;
+        advance(jb, kt);
+        if (jb >= nJ) break;
+        if (VARIANT != 1 && VARIANT != 3) {
+            // the next tile (issued one iteration ago) must have landed; the one just issued may stay in flight
+            if (staged) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        cur = (cur == 2) ? 0 : cur + 1;
     }
 
     // ---- row sums: across the 16 lanes that share a candidate row, then across the two column halves
@@ -161,8 +226,10 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         }
     __syncthreads();
 
-    __shared__ double s_val[4];
-    __shared__ int64_t s_idx[4];
+    // (all LDS lives in the one smem[] array: a second __shared__ object makes hipcc wait vmcnt(0) for the
+    //  LDS-DMA in front of every k tile's first ds_read)
+    double *s_val = smem + 2 * BM;
+    int64_t *s_idx = reinterpret_cast<int64_t *>(smem + 2 * BM + 4);
     if (tid < BM) {
         const int64_t c = cand0 + tid;  // chunk-local candidate
         const bool valid = c < Mc;
@@ -320,6 +387,7 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
     unsigned long long *nan_count = reinterpret_cast<unsigned long long *>(w + L.nan_off);
     if (hipMemsetAsync(nan_count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
 
+    static const int variant = getenv("GPBO_SIGMA_VARIANT") ? atoi(getenv("GPBO_SIGMA_VARIANT")) : 0;
     int64_t nparts = 0;
     for (int64_t s = 0; s < M; s += chunk) {
         const int64_t Mc = (M - s < chunk) ? (M - s) : chunk;
@@ -330,10 +398,17 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
         const bool rec = prof && prof->count < prof->capacity;
         if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
-        hipLaunchKernelGGL(sigma_acq_kernel, dim3((unsigned)nblk), dim3(512), 0, st, KsT, chunk, U, (int)Np, mu_part,
-                           (int)(Np / 128), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
-                           mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
-                           acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count);
+#define GPBO_SIGMA_LAUNCH(V)                                                                                     \
+    hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(512), 0, st, KsT, chunk, U, (int)Np, mu_part, \
+                       (int)(Np / 128), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,                          \
+                       mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                             \
+                       acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count)
+        if (variant == 1) GPBO_SIGMA_LAUNCH(1);
+        else if (variant == 3) GPBO_SIGMA_LAUNCH(3);
+        else if (variant == 4) GPBO_SIGMA_LAUNCH(4);
+        else if (variant == 2) GPBO_SIGMA_LAUNCH(2);
+        else GPBO_SIGMA_LAUNCH(0);
+#undef GPBO_SIGMA_LAUNCH
         if (rec) {
             if (hipEventRecord(reinterpret_cast<hipEvent_t>(prof->end[prof->count]), st) != hipSuccess)
                 return GPBO_ERR_LAUNCH;
