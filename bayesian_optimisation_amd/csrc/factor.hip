@@ -194,7 +194,7 @@ __global__ void zero_i32_kernel(int32_t *p) { *p = 0; }
 }  // namespace
 
 extern "C" int gpbo_potrf_f64(double *Kp, int64_t Np, double *dinv, int32_t *info, void *stream) {
-    if (!Kp || !dinv || !info || Np < GPBO_NPAD || Np % GPBO_NPAD) return GPBO_ERR_ARG;
+    if (!Kp || !dinv || !info || Np < NB || Np % NB) return GPBO_ERR_ARG;
     hipStream_t st = gpbo_stream(stream);
     hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(1), 0, st, info);
     const int nb = (int)(Np / NB);
@@ -225,7 +225,7 @@ int gpbo_launch_transpose_upper(const double *W, int64_t Np, double *U, hipStrea
 
 extern "C" int gpbo_trtri_f64(const double *L, const double *dinv, int64_t Np, double *U, double *work,
                               void *stream) {
-    if (!L || !dinv || !U || !work || Np < GPBO_NPAD || Np % GPBO_NPAD) return GPBO_ERR_ARG;
+    if (!L || !dinv || !U || !work || Np < NB || Np % NB) return GPBO_ERR_ARG;
     hipStream_t st = gpbo_stream(stream);
     double *W = work;
     double *T = U;  // scratch until the final transpose
@@ -261,7 +261,7 @@ extern "C" int gpbo_trtri_f64(const double *L, const double *dinv, int64_t Np, d
 
 extern "C" int gpbo_alpha_f64(const double *U, const double *y, int64_t N, int64_t Np, double *tmp, double *alpha,
                               void *stream) {
-    if (!U || !y || !tmp || !alpha || N < 1 || Np < N || Np % GPBO_NPAD) return GPBO_ERR_ARG;
+    if (!U || !y || !tmp || !alpha || N < 1 || Np < N || Np % NB) return GPBO_ERR_ARG;
     hipStream_t st = gpbo_stream(stream);
     hipLaunchKernelGGL(utv_kernel, dim3((unsigned)(Np / 64)), dim3(1024), 0, st, U, y, N, Np, tmp);
     hipLaunchKernelGGL(uv_kernel, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, st, U, tmp, N, Np, alpha);

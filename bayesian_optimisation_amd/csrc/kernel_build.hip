@@ -131,7 +131,7 @@ static int make_ls(const double *ls_host, int d, LsArgs *out) {
 
 extern "C" int gpbo_kxx_f64(const double *X, int64_t N, int32_t d, const double *ls_host, double jitter1,
                             double jitter2, double *Kp, int64_t Np, void *stream) {
-    if (!X || !Kp || N < 1 || Np < N || Np % GPBO_NPAD != 0 || Np > (1 << 20)) return GPBO_ERR_ARG;
+    if (!X || !Kp || N < 1 || Np < N || Np % 64 != 0 || Np > (1 << 20)) return GPBO_ERR_ARG;
     LsArgs ls;
     int rc = make_ls(ls_host, d, &ls);
     if (rc != GPBO_OK) return rc;
@@ -148,7 +148,7 @@ extern "C" int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *X, 
                                  const double *ls_host, const double *alpha, double diag_add, int64_t cand_base,
                                  double *KsT, int64_t ldk, double *mu_part, void *stream) {
     if (!Xs || !X || !alpha || !KsT || !mu_part) return GPBO_ERR_ARG;
-    if (Mc < 1 || N < 1 || Np < N || Np % GPBO_NPAD != 0 || ldk % GPBO_CHUNK_GRANULE != 0 || Mc > ldk)
+    if (Mc < 1 || N < 1 || Np < N || Np % 128 != 0 || ldk % GPBO_CHUNK_GRANULE != 0 || Mc > ldk)
         return GPBO_ERR_ARG;
     LsArgs ls;
     int rc = make_ls(ls_host, d, &ls);

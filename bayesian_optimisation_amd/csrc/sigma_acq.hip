@@ -15,8 +15,9 @@
 //       inside the diagonal block, 16x16 tiles of U that lie wholly below the diagonal are skipped
 //   epilogue: row-sum of squares -> sigma -> mean from the per-slice partials -> LCB / EI -> optional
 //   dense stores -> block arg-max carrying (value, lowest index).
-// Waves w and w+4 share a SIMD; they are given the two column halves of the block so that when the
-// left half runs out of non-zero U tiles on the diagonal the right half has the matrix pipe alone.
+// Waves w and w+4 share a SIMD; they take the even and the odd 16-column tiles of the block, so that on the
+// diagonal (where tiles below U's diagonal are skipped) both always have nearly the same amount of work and
+// keep hiding each other's LDS / branch / DMA-issue latencies.
 #include "gpbo_internal.h"
 
 #include <cstdlib>
@@ -24,11 +25,16 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 128, BK = 16;
+constexpr int BM = 256, BN = 128, BK = 16;  // candidates x columns of V per workgroup, k depth of a tile
+constexpr int WR = BM / 64;                // row groups of waves (64 candidates each)
+constexpr int WQ = 8 / WR;                 // column groups of waves; WR * WQ = 8 waves
+static_assert(BN / 16 / WQ == 4, "each wave owns four 16-column tiles");
+// (measured on MI355X, N = 512: 256 x 128 runs 0.596 ms per 2^17 candidates, 128 x 256 runs 0.635 ms - the
+//  wider column block has more k tiles on the diagonal whose MFMA time is shorter than their 48 KB of loads)
 constexpr int LDA = BM + 16;  // padded so lanes l and l+16 (k, k+1) of a ds_read_b64 group hit disjoint banks
 constexpr int LDB = BN + 16;
-constexpr int A_TILE = BK * LDA;  // 4352 doubles
-constexpr int B_TILE = BK * LDB;  // 2304 doubles
+constexpr int A_TILE = BK * LDA;
+constexpr int B_TILE = BK * LDB;
 constexpr int STAGE = A_TILE + B_TILE;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -66,14 +72,13 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid & 3, wc = wid >> 2;
+    const int wr = wid % WR, wq = wid / WR;  // SIMD partners w, w+4 get different column groups
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t cand0 = (int64_t)blockIdx.x * BM;
 
     // staging: global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPRs).
     // LDS image rows are padded, and every wave instruction's 1 KiB lies inside one row:
-    //   A tile: 16 rows x 2 halves = 32 units, wave w takes units w + 8r (r = 0..3)
-    //   B tile: 16 rows x 1        = 16 units, wave w takes rows  w + 8r (r = 0..1)
+    //   A tile (K*^T): 16 rows x BM/128 pieces, B tile (U): 16 rows x BN/128 pieces; wave w takes pieces w + 8r
     const double *a_src = KsT + cand0;  // wave-uniform bases; the lane offset rides in the VGPR operand
     const double *b_src = U;
     const int lane2 = lane * 2;
@@ -91,22 +96,27 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     auto stage = [&](int jb, int kt, int buf) {
         double *As = smem + buf * STAGE;
         double *Bs = As + A_TILE;
+        constexpr int AP = BM / 128, BP = BN / 128;  // 1 KiB pieces per row
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int u = wid + 8 * r, row = u >> 1, half = u & 1;
-            glds16(a_src + (int64_t)(kt * BK + row) * ldk + half * 128 + lane2, As + row * LDA + half * 128);
+        for (int r = 0; r < 2 * AP; ++r) {
+            const int u = wid + 8 * r, row = u / AP, piece = u % AP;
+            glds16(a_src + (int64_t)(kt * BK + row) * ldk + piece * 128 + lane2, As + row * LDA + piece * 128);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int row = wid + 8 * r;
-            glds16(b_src + (int64_t)(kt * BK + row) * Np + jb * BN + lane2, Bs + row * LDB);
+        for (int r = 0; r < 2 * BP; ++r) {
+            const int u = wid + 8 * r, row = u / BP, piece = u % BP;
+            glds16(b_src + (int64_t)(kt * BK + row) * Np + jb * BN + piece * 128 + lane2, Bs + row * LDB + piece * 128);
         }
     };
 
-    // Flattened tile sequence (jb, kt): kt = 0 .. 8(jb+1)-1 for jb = 0 .. nJ-1.  Three LDS stages: while tile t
-    // is multiplied, tile t+1 has landed or is landing and tile t+2 is being issued - the wait before the
-    // barrier is a counted vmcnt that leaves the newest tile's 6 LDS-DMA instructions in flight (a plain
-    // __syncthreads() would drain them: hipcc puts vmcnt(0) in front of it).
+    // Flattened tile sequence (jb, kt): kt = 0 .. 8(jb+1)-1 for jb = 0 .. nJ-1, three LDS stages.
+    // The MFMA stream never stops at a tile boundary: the fragments of the next tile's first step are read
+    // during the current tile's last step.  The one barrier per tile sits in the MIDDLE of the tile, where
+    // every wave still holds fragments for the following MFMAs in registers, so nobody leaves the barrier
+    // into an LDS-latency bubble.  At that barrier (iteration t):
+    //   - each wave has first waited for its own LDS-DMA of tile t+1 (issued one tile earlier), so after the
+    //     barrier tile t+1 is complete for everyone, half a tile before anyone reads it;
+    //   - every wave has left tile t-1, so its stage may be overwritten: the DMA of tile t+2 is issued now.
     auto advance = [&](int &j, int &k) {
         if (++k == (j + 1) * (BN / BK)) { ++j; k = 0; }
     };
@@ -119,76 +129,71 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         stage(pj, pk, pbuf);
         advance(pj, pk);
         pbuf = 2;
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+
+    double a0[4], b0[4], a1[4], b1[4];
+    auto lds_frag = [&](double (&af)[4], double (&bf)[4], int buf, int kk) {
+        const double *As = smem + buf * STAGE;
+        const double *Bs = As + A_TILE;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = As[(kk + l4) * LDA + wr * 64 + mi * 16 + l15];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[(kk + l4) * LDB + (WQ * ni + wq) * 16 + l15];
+    };
+    lds_frag(a0, b0, 0, 0);
     while (true) {
         const int kt_end = (jb + 1) * (BN / BK);  // k tiles of this column block
-        const bool staged = (pj < nJ) && VARIANT != 1 && VARIANT != 4;
-        // The 6 LDS-DMA issues cost each wave several hundred cycles in which it feeds no MFMAs.  The two
-        // waves of a SIMD (w and w+4, i.e. wc = 0 / 1) leave the barrier together, so they are staggered:
-        // wc = 0 issues its share here, wc = 1 half a tile later, under the partner's MFMAs.
-        if (staged && wc == 0) stage(pj, pk, pbuf);  // two tiles ahead; its stage was last read one iteration ago
-
-        const double *As = smem + cur * STAGE;
-        const double *Bs = As + A_TILE;
-        // first 16-column tile of this wave that still has non-zero rows of U in this k tile
-        int ni_min = kt - jb * (BN / BK) - wc * 4;
+        const int nxt = (cur == 2) ? 0 : cur + 1;
+        // first 16-column tile of this wave that still has non-zero rows of U in this k tile (>= 4: none)
+        // (wave column group wq owns the 16-column tiles WQ ni + wq of the block, so on the diagonal all waves
+        //  keep almost the same amount of work: column tile WQ ni + wq is needed iff it is >= kt')
+        int ni_min = (kt - jb * (BN / BK) - wq + WQ - 1) / WQ;
         ni_min = ni_min < 0 ? 0 : ni_min;
         if (VARIANT == 2) ni_min = 0;
-        if (ni_min < 4) {
-            // One code path for full and diagonal tiles (two paths make hipcc keep two copies of the 128
-            // accumulator registers).  LDS reads are unconditional and software-pipelined by hand: the
-            // reads of step kk+1 are issued under the MFMAs of step kk; only the MFMA groups of 16-column
-            // tiles that lie wholly below U's diagonal are branched over (wave-uniform scalar branch).
-            // sched_barrier keeps the compiler from hoisting all four steps' reads (register spills).
-            double a0[4], b0[4], a1[4], b1[4];
-            auto lds_frag = [&](double (&af)[4], double (&bf)[4], int kk) {
+        // MFMA groups of 16-column tiles that lie wholly below U's diagonal are branched over (wave-uniform);
+        // LDS reads, barrier and DMA are unconditional, so there is one code path and one accumulator set.
+        auto mfma8 = [&](const double (&af)[4], const double (&bf)[4], int nlo) {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) af[mi] = As[(kk + l4) * LDA + wr * 64 + mi * 16 + l15];
+            for (int ni = nlo; ni < nlo + 2; ++ni) {
+                if (ni >= ni_min) {
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[(kk + l4) * LDB + wc * 64 + ni * 16 + l15];
-            };
-            auto mfma8 = [&](const double (&af)[4], const double (&bf)[4], int nlo) {
-#pragma unroll
-                for (int ni = nlo; ni < nlo + 2; ++ni) {
-                    if (ni >= ni_min) {
-#pragma unroll
-                        for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf[ni], acc[mi][ni]);
-                    }
+                    for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf[ni], acc[mi][ni]);
                 }
-            };
-            // step kk: 8 MFMAs, then the LDS reads of step kk+1, then the other 8 MFMAs - every read has at
-            // least 8 MFMAs (>= 512 cycles) to land before the s_waitcnt that precedes its first use
-            lds_frag(a0, b0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma8(a0, b0, 0);
-            lds_frag(a1, b1, 4);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma8(a0, b0, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma8(a1, b1, 0);
-            lds_frag(a0, b0, 8);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma8(a1, b1, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (staged && wc == 1) stage(pj, pk, pbuf);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma8(a0, b0, 0);
-            lds_frag(a1, b1, 12);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma8(a0, b0, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma8(a1, b1, 0);
-            mfma8(a1, b1, 2);
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a0, b0, 0);
+        lds_frag(a1, b1, cur, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a0, b0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a1, b1, 0);
+        lds_frag(a0, b0, cur, 8);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a1, b1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (VARIANT != 1 && VARIANT != 3) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own share of tile t+1 has landed
+            __builtin_amdgcn_s_barrier();
         }
-        else if (staged && wc == 1) stage(pj, pk, pbuf);  // (idle diagonal tile of the right half)
-        if (staged) {
+        if (pj < nJ && VARIANT != 1 && VARIANT != 4) {
+            stage(pj, pk, pbuf);  // tile t+2 into the stage tile t-1 occupied
             advance(pj, pk);
             pbuf = (pbuf == 2) ? 0 : pbuf + 1;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a0, b0, 0);
+        lds_frag(a1, b1, cur, 12);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a0, b0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a1, b1, 0);
+        lds_frag(a0, b0, nxt, 0);  // first step of the next tile (stale but in-bounds after the last tile)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a1, b1, 2);
+        __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 == kt_end) {  // column block finished: fold |V|^2 into the row sums
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -201,18 +206,12 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         }
         advance(jb, kt);
         if (jb >= nJ) break;
-        if (VARIANT != 1 && VARIANT != 3) {
-            // the next tile (issued one iteration ago) must have landed; the one just issued may stay in flight
-            if (staged) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        cur = (cur == 2) ? 0 : cur + 1;
+        cur = nxt;
     }
 
     // ---- row sums: across the 16 lanes that share a candidate row, then across the two column halves
     __syncthreads();
-    double *red = smem;  // [2][256]
+    double *red = smem;  // [WQ][BM]
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -222,18 +221,20 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 8);
-            if (l15 == 0) red[wc * BM + wr * 64 + mi * 16 + l4 + 4 * r] = v;
+            if (l15 == 0) red[wq * BM + wr * 64 + mi * 16 + l4 + 4 * r] = v;
         }
     __syncthreads();
 
     // (all LDS lives in the one smem[] array: a second __shared__ object makes hipcc wait vmcnt(0) for the
     //  LDS-DMA in front of every k tile's first ds_read)
-    double *s_val = smem + 2 * BM;
-    int64_t *s_idx = reinterpret_cast<int64_t *>(smem + 2 * BM + 4);
+    double *s_val = smem + WQ * BM;
+    int64_t *s_idx = reinterpret_cast<int64_t *>(smem + WQ * BM + 4);
     if (tid < BM) {
         const int64_t c = cand0 + tid;  // chunk-local candidate
         const bool valid = c < Mc;
-        const double ssq = red[tid] + red[BM + tid];
+        double ssq = red[tid];
+#pragma unroll
+        for (int q = 1; q < WQ; ++q) ssq += red[q * BM + tid];
         double mu = 0.0;
         for (int s = 0; s < nsl; ++s) mu += mu_part[(int64_t)s * ldk + c];
         const double var = prior_var - ssq;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     if (tid == 0) {
         double bv = s_val[0];
         int64_t bi = s_idx[0];
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < BM / 64; ++w)
             if (better(s_val[w], s_idx[w], bv, bi)) { bv = s_val[w]; bi = s_idx[w]; }
         part_val[blockIdx.x] = bv;
         part_idx[blockIdx.x] = bi;
@@ -337,10 +338,35 @@ __global__ __launch_bounds__(256) void acq_argmax_kernel(const double *__restric
     }
 }
 
+// Helper stream + events for the K(X*,X) / variance overlap, one set per device, created on first use and
+// kept for the life of the process (nothing is retained about the caller's buffers).
+struct Helper {
+    hipStream_t stream;
+    hipEvent_t fork, kdone[2], sdone[2];
+};
+
+Helper *helper_for_current_device() {
+    static Helper *tab[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!tab[dev]) {
+        Helper *h = new Helper;
+        bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i) {
+            ok = ok && hipEventCreateWithFlags(&h->kdone[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&h->sdone[i], hipEventDisableTiming) == hipSuccess;
+        }
+        if (!ok) { delete h; return nullptr; }
+        tab[dev] = h;
+    }
+    return tab[dev];
+}
+
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct PosteriorLayout {
-    int64_t kst_off, mup_off, pval_off, pidx_off, nan_off, total, nparts_cap;
+    int64_t kst_off[2], mup_off[2], pval_off, pidx_off, nan_off, total, nparts_cap;
 };
 
 PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M) {
@@ -348,8 +374,14 @@ PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M) {
     const int64_t nchunks = (M + chunk - 1) / chunk;
     L.nparts_cap = nchunks * (chunk / BM);
     int64_t off = 0;
-    L.kst_off = off; off += align_up((int64_t)sizeof(double) * Np * chunk, 256);
-    L.mup_off = off; off += align_up((int64_t)sizeof(double) * (Np / 128) * chunk, 256);
+    // two chunk buffers when there is more than one chunk: K(X*,X) of chunk c+1 is built on a helper
+    // stream while the variance kernel of chunk c runs
+    const int nbuf = nchunks > 1 ? 2 : 1;
+    for (int b = 0; b < 2; ++b) {
+        L.kst_off[b] = off; if (b < nbuf) off += align_up((int64_t)sizeof(double) * Np * chunk, 256);
+        L.mup_off[b] = off; if (b < nbuf) off += align_up((int64_t)sizeof(double) * (Np / 128) * chunk, 256);
+    }
+    if (nbuf == 1) { L.kst_off[1] = L.kst_off[0]; L.mup_off[1] = L.mup_off[0]; }
     L.pval_off = off; off += align_up((int64_t)sizeof(double) * L.nparts_cap, 256);
     L.pidx_off = off; off += align_up((int64_t)sizeof(int64_t) * L.nparts_cap, 256);
     L.nan_off = off; off += 256;
@@ -380,33 +412,64 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
     if (work_bytes < L.total) return GPBO_ERR_WORKSPACE;
     hipStream_t st = gpbo_stream(stream);
     char *w = reinterpret_cast<char *>(work);
-    double *KsT = reinterpret_cast<double *>(w + L.kst_off);
-    double *mu_part = reinterpret_cast<double *>(w + L.mup_off);
+    double *KsT[2] = {reinterpret_cast<double *>(w + L.kst_off[0]), reinterpret_cast<double *>(w + L.kst_off[1])};
+    double *mu_part[2] = {reinterpret_cast<double *>(w + L.mup_off[0]), reinterpret_cast<double *>(w + L.mup_off[1])};
     double *part_val = reinterpret_cast<double *>(w + L.pval_off);
     int64_t *part_idx = reinterpret_cast<int64_t *>(w + L.pidx_off);
     unsigned long long *nan_count = reinterpret_cast<unsigned long long *>(w + L.nan_off);
     if (hipMemsetAsync(nan_count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
 
     static const int variant = getenv("GPBO_SIGMA_VARIANT") ? atoi(getenv("GPBO_SIGMA_VARIANT")) : 0;
-    int64_t nparts = 0;
-    for (int64_t s = 0; s < M; s += chunk) {
+    // Measured on MI355X (N=512, M=2^20): running K(X*,X) of chunk c+1 beside the variance kernel of chunk c gains
+    // nothing - the variance launches slow down by what the overlap hides (0.59 -> 0.70 ms), i.e. fp64 VALU work
+    // and fp64 MFMA work do not co-execute on gfx950.  Kept as an opt-in (GPBO_OVERLAP=1) for other shapes.
+    static const bool overlap_env = getenv("GPBO_OVERLAP") && atoi(getenv("GPBO_OVERLAP"));
+    const int64_t nchunks = (M + chunk - 1) / chunk;
+    Helper *hp = (nchunks > 1 && overlap_env) ? helper_for_current_device() : nullptr;
+    // Fork: the helper stream builds K(X*,X)+mu of chunk c+1 (fp64 VALU + HBM writes) while the caller's
+    // stream runs the variance kernel of chunk c (matrix cores); two chunk buffers, events both ways.
+    hipStream_t ks = hp ? hp->stream : st;
+    if (hp) {
+        if (hipEventRecord(hp->fork, st) != hipSuccess || hipStreamWaitEvent(ks, hp->fork, 0) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
+    }
+    auto launch_kstar = [&](int64_t c) -> int {
+        const int64_t s = c * chunk;
         const int64_t Mc = (M - s < chunk) ? (M - s) : chunk;
-        int rc = gpbo_kstar_mu_f64(Xs + s * d, Mc, X, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT, chunk,
-                                   mu_part, stream);
+        const int b = (int)(c & 1);
+        int rc = gpbo_kstar_mu_f64(Xs + s * d, Mc, X, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT[b], chunk,
+                                   mu_part[b], ks);
         if (rc != GPBO_OK) return rc;
+        if (hp && hipEventRecord(hp->kdone[b], ks) != hipSuccess) return GPBO_ERR_LAUNCH;
+        return GPBO_OK;
+    };
+    int rc = launch_kstar(0);
+    if (rc != GPBO_OK) return rc;
+    int64_t nparts = 0;
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int64_t s = c * chunk;
+        const int64_t Mc = (M - s < chunk) ? (M - s) : chunk;
+        const int b = (int)(c & 1);
+        if (hp && c + 1 < nchunks) {
+            // buffer (c+1)&1 was last read by the variance kernel of chunk c-1
+            if (c >= 1 && hipStreamWaitEvent(ks, hp->sdone[(c + 1) & 1], 0) != hipSuccess) return GPBO_ERR_LAUNCH;
+            rc = launch_kstar(c + 1);
+            if (rc != GPBO_OK) return rc;
+        }
+        if (hp && hipStreamWaitEvent(st, hp->kdone[b], 0) != hipSuccess) return GPBO_ERR_LAUNCH;
         const int64_t nblk = (Mc + BM - 1) / BM;
         const bool rec = prof && prof->count < prof->capacity;
         if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
-#define GPBO_SIGMA_LAUNCH(V)                                                                                     \
-    hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(512), 0, st, KsT, chunk, U, (int)Np, mu_part, \
-                       (int)(Np / 128), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,                          \
-                       mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                             \
+#define GPBO_SIGMA_LAUNCH(V)                                                                                        \
+    hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(512), 0, st, KsT[b], chunk, U, (int)Np,          \
+                       mu_part[b], (int)(Np / 128), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,               \
+                       mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                              \
                        acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count)
         if (variant == 1) GPBO_SIGMA_LAUNCH(1);
+        else if (variant == 2) GPBO_SIGMA_LAUNCH(2);
         else if (variant == 3) GPBO_SIGMA_LAUNCH(3);
         else if (variant == 4) GPBO_SIGMA_LAUNCH(4);
-        else if (variant == 2) GPBO_SIGMA_LAUNCH(2);
         else GPBO_SIGMA_LAUNCH(0);
 #undef GPBO_SIGMA_LAUNCH
         if (rec) {
@@ -416,6 +479,11 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
             ++prof->count;
         }
         GPBO_CHECK_LAUNCH();
+        if (hp && hipEventRecord(hp->sdone[b], st) != hipSuccess) return GPBO_ERR_LAUNCH;
+        if (!hp && c + 1 < nchunks) {
+            rc = launch_kstar(c + 1);
+            if (rc != GPBO_OK) return rc;
+        }
         nparts += nblk;
     }
     hipLaunchKernelGGL(argmax_finish_kernel, dim3(1), dim3(256), 0, st, part_val, part_idx, nparts, nan_count, result);

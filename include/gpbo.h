@@ -35,7 +35,7 @@ extern "C" {
 #define GPBO_ERR_WORKSPACE (-3) /* workspace too small */
 
 #define GPBO_MAX_D 16          /* compile-time-unrolled feature counts 1..16 */
-#define GPBO_NPAD 128          /* observation padding granule */
+#define GPBO_NPAD 128          /* observation padding granule (column-block width of the variance kernel) */
 #define GPBO_CHUNK_GRANULE 512 /* candidate-chunk granule */
 
 #define GPBO_ACQ_LCB 0 /* acq = p0*sigma - mu            (point_selector.py:204, p0 = explore) */
@@ -76,7 +76,7 @@ int gpbo_kxx_f64(const double *X, int64_t N, int32_t d, const double *ls_host, d
 /* K4 - replaces np.linalg.inv(cov_meas) (point_selector.py:89) by a blocked right-looking Cholesky.
  * In place: lower triangle of Kp becomes L (upper triangle is left untouched). dinv [Np/64][64][64]
  * receives the inverses of the diagonal blocks of L. info (device int32): 0, or 1-based column of the
- * first non-positive / non-finite pivot. */
+ * first non-positive / non-finite pivot.  Np: any multiple of 64. */
 int gpbo_potrf_f64(double *Kp, int64_t Np, double *dinv, int32_t *info, void *stream);
 
 /* U = (L^-1)^T, upper triangular, [Np x Np] row-major (strict lower triangle zero-filled).
