@@ -9,6 +9,9 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
 #define GPBO_NB 64 /* Cholesky / triangular-inverse block size */
+#ifndef GPBO_KS_SLICE
+#define GPBO_KS_SLICE 64 /* observations per workgroup of the K(X*,X) kernel = rows per mu_part slice */
+#endif
 
 #define GPBO_CHECK_LAUNCH()                                  \
     do {                                                     \

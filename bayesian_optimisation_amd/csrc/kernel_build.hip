@@ -4,13 +4,18 @@
 // broadcasts an (n1, n2, d) temporary; here one thread owns a column (a candidate, or an observed
 // point for K(X,X)), keeps its d coordinates in VGPRs, and walks the other set of points, whose
 // coordinates are wave-uniform and therefore travel through the scalar cache into SGPRs.
-// Per entry the arithmetic follows the reference's order: subtract, square, scale by 1/ls_k^2
-// (the reference divides by ls_k^2; multiplying by the host-rounded reciprocal differs by <= 1 ulp
-// per term), sum over features in index order, times -0.5, exp.
+// K(X,X) follows the reference's order per entry: subtract, square, scale by 1/ls_k^2 (the reference
+// divides by ls_k^2; multiplying by the host-rounded reciprocal differs by <= 1 ulp per term), sum over
+// features in index order, times -0.5, exp.  K(X*,X) - M x N entries, the fp64-issue-bound kernel - uses
+// coordinates pre-scaled by 1/(ls_k sqrt 2) and its own exp(-t); both agree with the reference's values
+// to a few ulp (tests: 5e-15 absolute on entries <= 1).
 #include "gpbo_internal.h"
+
+#include <cstdlib>
 
 struct LsArgs {
     double il2[GPBO_MAX_D];  // 1 / ls_k^2, computed on the host in fp64
+    double isc[GPBO_MAX_D];  // 1 / (ls_k sqrt 2): coordinates scaled by this give exp(-sum diff^2)
 };
 
 template <int D>
@@ -52,58 +57,159 @@ __global__ __launch_bounds__(256) void kxx_kernel(const double *__restrict__ X, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2+K5: KsT[n][c] = k(x_n, x*_c) for one candidate chunk, plus per-slice partial means.
-// grid (ldk_used/512, Np/128), block 256: thread = two adjacent candidates (16-byte stores, two
-// independent exp chains), blockIdx.y = slice of 128 observations.
+// exp(-t) for t >= 0 in fp64, <= 1 ulp: 2^(n/32) table (LDS) x degree-6 polynomial, scaled through the
+// exponent field.  12 full-rate fp64 instructions against ~24 (some quarter-rate) for the library exp.
 // ---------------------------------------------------------------------------------------------
-template <int D>
+__device__ const double kExp2Tab[32] = {
+    1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237,
+    1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775,
+    1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332,
+    1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832,
+    1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228,
+    1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965,
+    1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072,
+    1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002};
+
+__device__ __forceinline__ double exp_neg(double t, const double *tab /* LDS, 32 entries */) {
+    // n = rint(-t * 32/ln2) by the 1.5*2^52 trick: the integer sits in the low dword of z, and z - magic is
+    // exact.  (v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64 issue at a quarter of the fp64 FMA rate on gfx950;
+    // this form needs none of them.)
+    const double u = -t;
+    const double z = fma(u, 46.16624130844683, 6755399441055744.0);
+    const int ni = __double2loint(z);
+    const double fn = z - 6755399441055744.0;
+    double r = fma(fn, -0.02166084939249829, u);   // u - n * (ln2/32), hi part
+    r = fma(fn, -7.247021293269686e-19, r);        //                 , lo part
+    const double T = tab[ni & 31];
+    double q = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    q = fma(r, q, 1.0 / 24.0);
+    q = fma(r, q, 1.0 / 6.0);
+    q = fma(r, q, 0.5);
+    q = fma(r, q, 1.0);
+    const double v = fma(T * r, q, T);             // in [1, 2): scale by 2^(n >> 5) through the exponent field
+    const double s = __hiloint2double(__double2hiint(v) + ((ni >> 5) << 20), __double2loint(v));
+    // t <= 708: the result is a normal number.  Above, the reference's np.exp returns values below DBL_MIN
+    // (denormals, then 0); they are flushed to 0 here - invisible at every tolerance of the path.
+    return (t <= 708.0) ? s : ((t > 708.0) ? 0.0 : t);  // last arm: NaN propagates
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2+K5: KsT[n][c] = k(x_n, x*_c) for one candidate chunk, plus per-slice partial means.
+// grid (ldk_used/512, Np/64), block 256: thread = two adjacent candidates (16-byte stores, two
+// independent exp chains), blockIdx.y = slice of 64 observations.
+// Coordinates are pre-scaled by 1/(ls_k sqrt 2) (the candidates here, the observations by
+// scale_points_kernel), so an entry is exp(-sum_k (a_k - b_k)^2): 2 fp64 instructions per feature.
+// ---------------------------------------------------------------------------------------------
+constexpr int KS_SLICE = GPBO_KS_SLICE;
+
+template <int D, int VARIANT, bool HAS_DIAG>
 __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict__ Xs, int64_t Mc,
-                                                       const double *__restrict__ X, int N, LsArgs ls,
+                                                       const double *__restrict__ Xsc, int N, LsArgs ls,
                                                        const double *__restrict__ alpha, double diag_add,
                                                        int64_t cand_base, double *__restrict__ KsT, int64_t ldk,
                                                        double *__restrict__ mu_part) {
+    __shared__ double tab[32];
+    if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
     const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
-    const int n0 = blockIdx.y * 128;
+    const int n0 = blockIdx.y * KS_SLICE;
     double xa[D], xb[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        xa[k] = (c0 < Mc) ? Xs[c0 * D + k] : 0.0;
-        xb[k] = (c0 + 1 < Mc) ? Xs[(c0 + 1) * D + k] : 0.0;
+        xa[k] = ((c0 < Mc) ? Xs[c0 * D + k] : 0.0) * ls.isc[k];
+        xb[k] = ((c0 + 1 < Mc) ? Xs[(c0 + 1) * D + k] : 0.0) * ls.isc[k];
     }
+    __syncthreads();
     double mua = 0.0, mub = 0.0;
-    const bool has_diag = diag_add != 0.0;  // uniform
-#pragma unroll 2
-    for (int n = n0; n < n0 + 128; ++n) {
-        d2_t kv = {0.0, 0.0};
-        if (n < N) {  // wave-uniform: padded observations contribute exact zeros
-            const double *xo = X + (int64_t)n * D;
-            const double sa = sqdist<D>(xa, xo, ls);
-            const double sb = sqdist<D>(xb, xo, ls);
-            double ka = exp(-0.5 * sa);
-            double kb = exp(-0.5 * sb);
-            if (has_diag) {  // N == M shape-coincidence quirk (point_selector.py:173,191-193)
-                if ((int64_t)n == cand_base + c0) ka += diag_add;
-                if ((int64_t)n == cand_base + c0 + 1) kb += diag_add;
-            }
-            const double an = alpha[n];
-            mua = fma(ka, an, mua);
-            mub = fma(kb, an, mub);
-            kv.x = ka;
-            kv.y = kb;
+    double *out = KsT + (int64_t)n0 * ldk + c0;
+    int nend = n0 + KS_SLICE;
+    if (nend > N) nend = N;  // observations beyond N are padding: exact zeros, written below
+    // two observations per trip: four independent distance/exp chains per thread (the loop is bound by the
+    // latency of dependent fp64 instructions, not by their count)
+    int n = n0;
+    for (; n + 1 < nend; n += 2) {
+        const double *xo0 = Xsc + (int64_t)n * D;  // wave-uniform rows -> scalar loads
+        const double *xo1 = xo0 + D;
+        double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const double o0 = xo0[k], o1 = xo1[k];
+            const double d00 = xa[k] - o0, d01 = xb[k] - o0, d10 = xa[k] - o1, d11 = xb[k] - o1;
+            s00 = fma(d00, d00, s00);
+            s01 = fma(d01, d01, s01);
+            s10 = fma(d10, d10, s10);
+            s11 = fma(d11, d11, s11);
         }
-        *reinterpret_cast<d2_t *>(KsT + (int64_t)n * ldk + c0) = kv;
+        double k00 = exp_neg(s00, tab), k01 = exp_neg(s01, tab), k10 = exp_neg(s10, tab), k11 = exp_neg(s11, tab);
+        if (HAS_DIAG) {  // N == M shape-coincidence quirk (point_selector.py:173,191-193)
+            if ((int64_t)n == cand_base + c0) k00 += diag_add;
+            if ((int64_t)n == cand_base + c0 + 1) k01 += diag_add;
+            if ((int64_t)n + 1 == cand_base + c0) k10 += diag_add;
+            if ((int64_t)n + 1 == cand_base + c0 + 1) k11 += diag_add;
+        }
+        const double a0 = alpha[n], a1 = alpha[n + 1];
+        mua = fma(k00, a0, mua);
+        mub = fma(k01, a0, mub);
+        mua = fma(k10, a1, mua);
+        mub = fma(k11, a1, mub);
+        const d2_t kv0 = {k00, k01}, kv1 = {k10, k11};
+        if (VARIANT != 1) {
+            *reinterpret_cast<d2_t *>(out) = kv0;
+            *reinterpret_cast<d2_t *>(out + ldk) = kv1;
+        } else {
+            mua += (k00 + k10) * 1e-300;
+            mub += (k01 + k11) * 1e-300;
+        }
+        out += 2 * ldk;
+    }
+    if (n < nend) {  // odd tail
+        const double *xo = Xsc + (int64_t)n * D;
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const double da = xa[k] - xo[k], db = xb[k] - xo[k];
+            sa = fma(da, da, sa);
+            sb = fma(db, db, sb);
+        }
+        double ka = exp_neg(sa, tab), kb = exp_neg(sb, tab);
+        if (HAS_DIAG) {
+            if ((int64_t)n == cand_base + c0) ka += diag_add;
+            if ((int64_t)n == cand_base + c0 + 1) kb += diag_add;
+        }
+        const double an = alpha[n];
+        mua = fma(ka, an, mua);
+        mub = fma(kb, an, mub);
+        const d2_t kv = {ka, kb};
+        *reinterpret_cast<d2_t *>(out) = kv;
+        out += ldk;
+        ++n;
+    }
+    const d2_t zero = {0.0, 0.0};
+    for (n = (nend > n0 ? nend : n0); n < n0 + KS_SLICE; ++n) {
+        *reinterpret_cast<d2_t *>(out) = zero;
+        out += ldk;
     }
     d2_t m = {mua, mub};
     *reinterpret_cast<d2_t *>(mu_part + (int64_t)blockIdx.y * ldk + c0) = m;
 }
 
+// Xsc[n][k] = X[n][k] / (ls_k sqrt 2), rows n >= N zero.   One thread per element.
+__global__ __launch_bounds__(256) void scale_points_kernel(const double *__restrict__ X, int64_t N, int64_t Np, int d,
+                                                          LsArgs ls, double *__restrict__ Xsc) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= Np * d) return;
+    const int64_t n = e / d;
+    const int k = (int)(e - n * d);
+    Xsc[e] = (n < N) ? X[e] * ls.isc[k] : 0.0;
+}
+
 static int make_ls(const double *ls_host, int d, LsArgs *out) {
     if (!ls_host || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
-    for (int k = 0; k < GPBO_MAX_D; ++k) out->il2[k] = 0.0;
+    for (int k = 0; k < GPBO_MAX_D; ++k) out->il2[k] = out->isc[k] = 0.0;
     for (int k = 0; k < d; ++k) {
         const double l = ls_host[k];
         if (!(l > 0.0)) return GPBO_ERR_ARG;
         out->il2[k] = 1.0 / (l * l);
+        out->isc[k] = 1.0 / (l * 1.4142135623730950488);
     }
     return GPBO_OK;
 }
@@ -140,24 +246,43 @@ extern "C" int gpbo_kxx_f64(const double *X, int64_t N, int32_t d, const double 
     hipLaunchKernelGGL(kxx_kernel<DD>, grid, dim3(256), 0, gpbo_stream(stream), X, (int)N, ls, jitter1, jitter2, Kp, (int)Np)
     GPBO_DISPATCH_D(d, CALL)
 #undef CALL
+#undef KSTAR_LAUNCH
     GPBO_CHECK_LAUNCH();
     return GPBO_OK;
 }
 
-extern "C" int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *X, int64_t N, int64_t Np, int32_t d,
+extern "C" int gpbo_scale_points_f64(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host,
+                                     double *Xsc, void *stream) {
+    if (!X || !Xsc || N < 1 || Np < N) return GPBO_ERR_ARG;
+    LsArgs ls;
+    int rc = make_ls(ls_host, d, &ls);
+    if (rc != GPBO_OK) return rc;
+    const int64_t tot = Np * d;
+    hipLaunchKernelGGL(scale_points_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, gpbo_stream(stream), X, N,
+                       Np, (int)d, ls, Xsc);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
+extern "C" int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
                                  const double *ls_host, const double *alpha, double diag_add, int64_t cand_base,
                                  double *KsT, int64_t ldk, double *mu_part, void *stream) {
-    if (!Xs || !X || !alpha || !KsT || !mu_part) return GPBO_ERR_ARG;
+    if (!Xs || !Xsc || !alpha || !KsT || !mu_part) return GPBO_ERR_ARG;
     if (Mc < 1 || N < 1 || Np < N || Np % 128 != 0 || ldk % GPBO_CHUNK_GRANULE != 0 || Mc > ldk)
         return GPBO_ERR_ARG;
     LsArgs ls;
     int rc = make_ls(ls_host, d, &ls);
     if (rc != GPBO_OK) return rc;
     const int64_t used = (Mc + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
-    dim3 grid((unsigned)(used / 512), (unsigned)(Np / 128));
-#define CALL(DD)                                                                                              \
-    hipLaunchKernelGGL(kstar_mu_kernel<DD>, grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, X, (int)N, ls, alpha, \
-                       diag_add, cand_base, KsT, ldk, mu_part)
+    dim3 grid((unsigned)(used / 512), (unsigned)(Np / KS_SLICE));
+    static const int variant = getenv("GPBO_KSTAR_VARIANT") ? atoi(getenv("GPBO_KSTAR_VARIANT")) : 0;
+#define KSTAR_LAUNCH(DD, V, H)                                                                                       \
+    hipLaunchKernelGGL((kstar_mu_kernel<DD, V, H>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, Xsc, (int)N, ls, \
+                       alpha, diag_add, cand_base, KsT, ldk, mu_part)
+#define CALL(DD)                                        \
+    if (diag_add != 0.0) KSTAR_LAUNCH(DD, 0, true);     \
+    else if (variant == 1) KSTAR_LAUNCH(DD, 1, false);  \
+    else KSTAR_LAUNCH(DD, 0, false)
     GPBO_DISPATCH_D(d, CALL)
 #undef CALL
     GPBO_CHECK_LAUNCH();

@@ -366,7 +366,7 @@ Helper *helper_for_current_device() {
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct PosteriorLayout {
-    int64_t kst_off[2], mup_off[2], pval_off, pidx_off, nan_off, total, nparts_cap;
+    int64_t kst_off[2], mup_off[2], xsc_off, pval_off, pidx_off, nan_off, total, nparts_cap;
 };
 
 PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M) {
@@ -379,9 +379,10 @@ PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M) {
     const int nbuf = nchunks > 1 ? 2 : 1;
     for (int b = 0; b < 2; ++b) {
         L.kst_off[b] = off; if (b < nbuf) off += align_up((int64_t)sizeof(double) * Np * chunk, 256);
-        L.mup_off[b] = off; if (b < nbuf) off += align_up((int64_t)sizeof(double) * (Np / 128) * chunk, 256);
+        L.mup_off[b] = off; if (b < nbuf) off += align_up((int64_t)sizeof(double) * (Np / GPBO_KS_SLICE) * chunk, 256);
     }
     if (nbuf == 1) { L.kst_off[1] = L.kst_off[0]; L.mup_off[1] = L.mup_off[0]; }
+    L.xsc_off = off; off += align_up((int64_t)sizeof(double) * Np * GPBO_MAX_D, 256);
     L.pval_off = off; off += align_up((int64_t)sizeof(double) * L.nparts_cap, 256);
     L.pidx_off = off; off += align_up((int64_t)sizeof(int64_t) * L.nparts_cap, 256);
     L.nan_off = off; off += 256;
@@ -414,10 +415,15 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
     char *w = reinterpret_cast<char *>(work);
     double *KsT[2] = {reinterpret_cast<double *>(w + L.kst_off[0]), reinterpret_cast<double *>(w + L.kst_off[1])};
     double *mu_part[2] = {reinterpret_cast<double *>(w + L.mup_off[0]), reinterpret_cast<double *>(w + L.mup_off[1])};
+    double *Xsc = reinterpret_cast<double *>(w + L.xsc_off);
     double *part_val = reinterpret_cast<double *>(w + L.pval_off);
     int64_t *part_idx = reinterpret_cast<int64_t *>(w + L.pidx_off);
     unsigned long long *nan_count = reinterpret_cast<unsigned long long *>(w + L.nan_off);
     if (hipMemsetAsync(nan_count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
+    {
+        int rc0 = gpbo_scale_points_f64(X, N, Np, d, ls_host, Xsc, stream);  // observations / (ls sqrt 2), once
+        if (rc0 != GPBO_OK) return rc0;
+    }
 
     static const int variant = getenv("GPBO_SIGMA_VARIANT") ? atoi(getenv("GPBO_SIGMA_VARIANT")) : 0;
     // Measured on MI355X (N=512, M=2^20): running K(X*,X) of chunk c+1 beside the variance kernel of chunk c gains
@@ -437,7 +443,7 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
         const int64_t s = c * chunk;
         const int64_t Mc = (M - s < chunk) ? (M - s) : chunk;
         const int b = (int)(c & 1);
-        int rc = gpbo_kstar_mu_f64(Xs + s * d, Mc, X, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT[b], chunk,
+        int rc = gpbo_kstar_mu_f64(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT[b], chunk,
                                    mu_part[b], ks);
         if (rc != GPBO_OK) return rc;
         if (hp && hipEventRecord(hp->kdone[b], ks) != hipSuccess) return GPBO_ERR_LAUNCH;
@@ -463,7 +469,7 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
             return GPBO_ERR_LAUNCH;
 #define GPBO_SIGMA_LAUNCH(V)                                                                                        \
     hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(512), 0, st, KsT[b], chunk, U, (int)Np,          \
-                       mu_part[b], (int)(Np / 128), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,               \
+                       mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,               \
                        mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                              \
                        acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count)
         if (variant == 1) GPBO_SIGMA_LAUNCH(1);

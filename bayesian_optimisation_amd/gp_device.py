@@ -248,9 +248,13 @@ class DeviceGP:
         ldk = (M + _lib.CHUNK_GRANULE - 1) // _lib.CHUNK_GRANULE * _lib.CHUNK_GRANULE
         with torch.cuda.device(self.device):
             kst = torch.empty((self.Np, ldk), dtype=torch.float64, device=self.device)
-            mup = torch.empty((self.Np // 128, ldk), dtype=torch.float64, device=self.device)
-            st = self.lib.gpbo_kstar_mu_f64(self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d,
-                                            self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.alpha),
-                                            float(diag_add), 0, self._ptr(kst), ldk, self._ptr(mup), self._stream())
+            mup = torch.empty((self.Np // 64, ldk), dtype=torch.float64, device=self.device)
+            xsc = torch.empty((self.Np, self.d), dtype=torch.float64, device=self.device)
+            lsp = self.ls_h.ctypes.data_as(C.c_void_p)
+            _lib.check(self.lib.gpbo_scale_points_f64(self._ptr(self.X), self.N, self.Np, self.d, lsp, self._ptr(xsc),
+                                                      self._stream()), "gpbo_scale_points_f64")
+            st = self.lib.gpbo_kstar_mu_f64(self._ptr(Xsd), M, self._ptr(xsc), self.N, self.Np, self.d, lsp,
+                                            self._ptr(self.alpha), float(diag_add), 0, self._ptr(kst), ldk,
+                                            self._ptr(mup), self._stream())
             _lib.check(st, "gpbo_kstar_mu_f64")
             return kst[: self.N, :M].t().contiguous().cpu().numpy()

@@ -96,15 +96,20 @@ int gpbo_factorise_f64(const double *X, const double *y, int64_t N, int32_t d, c
                        double jitter1, double jitter2, int64_t Np, double *Kp, double *U, double *alpha,
                        int32_t *info, void *work, int64_t work_bytes, void *stream);
 
+/* Xsc[Np x d] = X / (ls sqrt 2) (rows >= N zero): the pre-scaled observations gpbo_kstar_mu_f64 reads. */
+int gpbo_scale_points_f64(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host, double *Xsc,
+                          void *stream);
+
 /* K2+K5 - replaces kernel_rbf(X, X*).T and the mean product (point_selector.py:81, :90).
  * Builds the transposed cross-covariance chunk KsT[Np x ldk] (row n = observation n, column c =
- * candidate c of the chunk; rows n >= N are zero) and per-128-observation partial sums of
- * mu_c = sum_n k(x*_c, x_n) alpha_n into mu_part[(Np/128) x ldk].
- * Xs: [Mc x d] candidates of this chunk; Mc <= ldk, ldk a multiple of 512.
+ * candidate c of the chunk; rows n >= N are zero) and per-64-observation partial sums of
+ * mu_c = sum_n k(x*_c, x_n) alpha_n into mu_part[(Np/64) x ldk].
+ * Xs: [Mc x d] candidates of this chunk (unscaled); Xsc: output of gpbo_scale_points_f64;
+ * Mc <= ldk, ldk a multiple of 512.
  * diag_add / cand_base: when the caller's full candidate set has the SAME SHAPE as X the reference
  * adds 1e-4 where observation index == global candidate index (point_selector.py:173,191-193);
  * pass diag_add = 0 otherwise. */
-int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *X, int64_t N, int64_t Np, int32_t d,
+int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
                       const double *ls_host, const double *alpha, double diag_add, int64_t cand_base,
                       double *KsT, int64_t ldk, double *mu_part, void *stream);
 

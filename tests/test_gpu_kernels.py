@@ -149,9 +149,14 @@ def test_kstar_mu(env, N, M, d):
     alpha[:N] = rng.standard_normal(N)
     ldk = (M + 511) // 512 * 512
     kst = t.full((Np, ldk), np.nan, dtype=t.float64, device=env.dev)
-    mup = t.full((Np // 128, ldk), np.nan, dtype=t.float64, device=env.dev)
+    mup = t.full((Np // 64, ldk), np.nan, dtype=t.float64, device=env.dev)
     dXs, dX, dal = env.to(Xs), env.to(X), env.to(alpha)  # keep the device buffers alive across the call
-    st = lib.gpbo_kstar_mu_f64(env.p(dXs), M, env.p(dX), N, Np, d, env.hp(ls), env.p(dal),
+    dXsc = t.full((Np, d), np.nan, dtype=t.float64, device=env.dev)
+    assert lib.gpbo_scale_points_f64(env.p(dX), N, Np, d, env.hp(ls), env.p(dXsc), env.stream()) == 0
+    xsc = dXsc.cpu().numpy()
+    np.testing.assert_allclose(xsc[:N], X / (ls * np.sqrt(2.0)), rtol=5e-16, atol=0)
+    assert np.array_equal(xsc[N:], np.zeros((Np - N, d)))
+    st = lib.gpbo_kstar_mu_f64(env.p(dXs), M, env.p(dXsc), N, Np, d, env.hp(ls), env.p(dal),
                                0.0, 0, env.p(kst), ldk, env.p(mup), env.stream())
     assert st == 0
     got = kst.cpu().numpy()
