@@ -1,0 +1,151 @@
+"""The SELECT_PARAMETERS driver: on-disk formats and branch logic of /root/reference/select_parameters.py.
+CPU tests inject a selector built on the oracle (file-format logic needs no GPU); the gpu-marked test runs
+the same sequence through the real PointSelector and must choose the same points."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from bayesian_optimisation_amd import select_parameters as SP
+from oracle import gp_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class OracleSelector:
+    """Attribute-protocol stand-in backed by the CPU oracle (tests only)."""
+
+    def __init__(self):
+        self.kernel_params = None
+
+    def update_surrogate(self):
+        self._out = O.select_next(np.array(self.measured_pts), np.array(self.measured_vals), self.predicted_pts,
+                                  self.feature_domain, length_scales=self.length_scales)
+        self.kernel_params = self._out["kernel_params"]
+        self.mean_func, self.cov_func = self._out["mean_func"], self._out["cov_func"]
+
+    def lower_confidence_bound(self, explore=4):
+        self.acq_func_eval = self._out["acq_func_eval"]
+        return self._out["index"]
+
+
+def _fresh(tmp_path):
+    shutil.copy(os.path.join(GOLDEN, "opto_log_clean.json"), tmp_path / "opto_log.JSON")
+    return str(tmp_path)
+
+
+def _fake_time_residuals(base, npy_name, objective):
+    """What time_residuals.py:204-217 does to the state: write the objective into the last row and
+    advance the sampling iteration."""
+    path = os.path.join(base, "measured_points", npy_name)
+    pts = np.load(path)
+    pts[-1, -1] = objective
+    np.save(path, pts)
+    with open(os.path.join(base, "opto_log.JSON")) as f:
+        info = json.load(f)
+    info["parameters"]["obj"] = objective
+    info["iteration_info"]["current_block"]["param_sampling"]["param_sample_iter"] += 1
+    with open(os.path.join(base, "opto_log.JSON"), "w") as f:
+        json.dump(info, f, indent=4)
+
+
+def _run_sequence(base, factory):
+    schema0 = json.load(open(os.path.join(base, "opto_log.JSON")))
+    # iteration 0 of the very first block: random grid point, no GP
+    s0 = SP.select_parameters(base, selector_factory=factory, rng=np.random.default_rng(7))
+    npy = "T1_T2_ALGO_0_BLOCK_0.npy"
+    pts = np.load(os.path.join(base, "measured_points", npy))
+    assert pts.shape == (1, 3) and pts.dtype == np.float64 and pts[0, 2] == 1000
+    info = json.load(open(os.path.join(base, "opto_log.JSON")))
+    assert info["parameters"]["T1"] == pts[0, 0] and info["parameters"]["T2"] == pts[0, 1]
+    assert info["iteration_info"]["initial_parameters"]["T1"] == pts[0, 0]
+    assert info["iteration_info"]["current_block"]["prev_params"]["T2"] == pts[0, 1]
+    assert s0["selector"] is None
+    chosen = []
+    objective = [812.0, 640.5, 701.25]
+    for it in range(3):
+        _fake_time_residuals(base, npy, objective[it])
+        before = json.load(open(os.path.join(base, "opto_log.JSON")))
+        s = SP.select_parameters(base, selector_factory=factory)
+        pts = np.load(os.path.join(base, "measured_points", npy))
+        assert pts.shape == (it + 2, 3) and pts[-1, 2] == 10000          # placeholder objective
+        assert pts[-1, 0] in SP.domains()["T1"] and pts[-1, 1] in SP.domains()["T2"]
+        after = json.load(open(os.path.join(base, "opto_log.JSON")))
+        assert after["parameters"]["T1"] == pts[-1, 0] and after["parameters"]["T2"] == pts[-1, 1]
+        last = np.array([before["parameters"]["T1"], before["parameters"]["T2"]])
+        within = bool(np.all(np.abs(last - pts[-1, :2]) / last <= 0.05))
+        cp_before = before["iteration_info"]["current_block"]["param_sampling"]["conv_points"]
+        cp_after = after["iteration_info"]["current_block"]["param_sampling"]["conv_points"]
+        assert cp_after == (cp_before + 1 if within else 0)
+        chosen.append(s["index"])
+    # schema unchanged: same keys at every level as the reference's state file
+    def keys(d):
+        return {k: keys(v) for k, v in d.items()} if isinstance(d, dict) else None
+    assert keys(json.load(open(os.path.join(base, "opto_log.JSON")))) == keys(schema0)
+    assert os.path.exists(os.path.join(base, "algo_log.txt"))
+    return chosen, np.load(os.path.join(base, "measured_points", npy))
+
+
+def _run_1d(base, factory, curr, feature, max_weight):
+    with open(os.path.join(base, "opto_log.JSON")) as f:
+        info = json.load(f)
+    ps = info["iteration_info"]["current_block"]["param_sampling"]
+    ps["current_parameters"], ps["param_sample_iter"] = curr, 0
+    info["iteration_info"]["current_block"]["block_best_params"]["obj"] = 950.0
+    with open(os.path.join(base, "opto_log.JSON"), "w") as f:
+        json.dump(info, f, indent=4)
+    s = SP.select_parameters(base, selector_factory=factory)
+    npy = f"{feature}_ALGO_0_BLOCK_0.npy"
+    pts = np.load(os.path.join(base, "measured_points", npy))
+    assert pts.shape == (2, 2) and pts[0, 1] == 950.0 and pts[1, 1] == 10000
+    after = json.load(open(os.path.join(base, "opto_log.JSON")))
+    assert after["parameters"][feature] == pts[1, 0]
+    if max_weight is not None:
+        partner = str(SP.PARAMETER_NAMES[curr[1]])
+        assert after["parameters"][partner] == max_weight - pts[1, 0]
+    _fake_time_residuals(base, npy, 700.0)
+    s2 = SP.select_parameters(base, selector_factory=factory)
+    assert np.load(os.path.join(base, "measured_points", npy)).shape == (3, 2)
+    return [s["index"], s2["index"]]
+
+
+def test_candidate_grid_is_row_major():
+    a, b = np.arange(3.0), np.arange(10.0, 14.0)
+    g = SP.candidate_grid(a, b)
+    assert g.shape == (12, 2) and np.array_equal(g[5], [1.0, 11.0])      # index i*len(b)+j
+    assert np.array_equal(g.reshape(3, 4, 2)[2, 3], [2.0, 13.0])
+
+
+def test_driver_file_formats_with_oracle_selector(tmp_path):
+    base = _fresh(tmp_path)
+    chosen, pts = _run_sequence(base, OracleSelector)
+    assert len(chosen) == 3 and all(len(c) == 2 for c in chosen)
+    idx_tr = _run_1d(base, OracleSelector, [4], "TR", None)
+    idx_a = _run_1d(_fresh(tmp_path), OracleSelector, [5, 6], "A1", 0.9)
+    assert len(idx_tr) == 2 and len(idx_a) == 2
+
+
+def test_driver_writes_macro_when_template_present(tmp_path):
+    base = _fresh(tmp_path)
+    with open(os.path.join(base, "bi214_template.mac"), "w") as f:
+        f.write("decay ${T1} ${T2} ${T3} ${T4} rise ${TR} amp ${A1} ${A2} ${A3} ${A4} mat ${MATERIAL}\n")
+    SP.select_parameters(base, selector_factory=OracleSelector, rng=np.random.default_rng(1))
+    text = open(os.path.join(base, "macros", "T1_T2.mac")).read()
+    info = json.load(open(os.path.join(base, "opto_log.JSON")))
+    assert str(info["parameters"]["T1"]) in text and "labppo_2p2_scintillator" in text
+    assert "T1_T2.mac" in open(os.path.join(base, "submit_files", "simulate.submit")).read()
+
+
+@pytest.mark.gpu
+def test_driver_on_gpu_matches_oracle_selector(tmp_path):
+    from bayesian_optimisation_amd import PointSelector
+
+    (tmp_path / "cpu").mkdir()
+    (tmp_path / "gpu").mkdir()
+    c_cpu, p_cpu = _run_sequence(_fresh(tmp_path / "cpu"), OracleSelector)
+    c_gpu, p_gpu = _run_sequence(_fresh(tmp_path / "gpu"), PointSelector)
+    assert c_cpu == c_gpu and np.array_equal(p_cpu, p_gpu)
+    assert _run_1d(_fresh(tmp_path / "cpu"), OracleSelector, [7, 8], "A3", 0.1) == \
+        _run_1d(_fresh(tmp_path / "gpu"), PointSelector, [7, 8], "A3", 0.1)
