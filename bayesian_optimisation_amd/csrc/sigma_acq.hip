@@ -392,6 +392,13 @@ PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M) {
 
 }  // namespace
 
+int gpbo_launch_argmax_finish(const double *part_val, const int64_t *part_idx, int64_t nparts,
+                              const unsigned long long *nan_count, gpbo_result *result, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_finish_kernel, dim3(1), dim3(256), 0, st, part_val, part_idx, nparts, nan_count, result);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
 extern "C" int64_t gpbo_posterior_workspace_bytes(int64_t Np, int64_t chunk, int64_t M) {
     if (Np < GPBO_NPAD || Np % GPBO_NPAD || chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || M < 1)
         return GPBO_ERR_ARG;

@@ -113,6 +113,7 @@ class DeviceGP:
             self.U = torch.empty((Np, Np), dtype=torch.float64, device=self.device)
             self.alpha = torch.empty(Np, dtype=torch.float64, device=self.device)
             self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.U32 = None
             wbytes = int(self.lib.gpbo_factorise_workspace_bytes(Np))
             work = torch.empty(wbytes // 8, dtype=torch.float64, device=self.device)
             st = self.lib.gpbo_factorise_f64(self._ptr(Xd), self._ptr(yd), N, d, ls_h.ctypes.data_as(C.c_void_p),
@@ -174,6 +175,60 @@ class DeviceGP:
             _lib.check(st, "gpbo_posterior_acq_f64")
         self._keep = Xsd  # keep the candidate tensor alive until the stream has consumed it
         return self._result, mu, sigma, acq
+
+    # -- fp32 scoring (BASELINE config 4): fp64 factors rounded once, M-proportional work in fp32 -------------
+    def prepare_f32(self):
+        """Round U and alpha to fp32 (re-padded to a multiple of 256) for score_async_f32."""
+        torch = self.torch
+        Np32 = int(self.lib.gpbo_padded_n_f32(self.N))
+        with torch.cuda.device(self.device):
+            self.U32 = torch.empty((Np32, Np32), dtype=torch.float32, device=self.device)
+            self.alpha32 = torch.empty(Np32, dtype=torch.float32, device=self.device)
+            st = self.lib.gpbo_prepare_f32(self._ptr(self.U), self._ptr(self.alpha), self.Np, self._ptr(self.U32),
+                                           self._ptr(self.alpha32), Np32, self._stream())
+            _lib.check(st, "gpbo_prepare_f32")
+        self.Np32 = Np32
+        self._work_post32 = None
+        return self
+
+    def score_async_f32(self, Xs, acquisition: str = "lcb", explore: float = 4.0, f_best: Optional[float] = None,
+                        xi: float = 0.0, dense: bool = False, idx_offset: int = 0, diag_add: float = 0.0,
+                        prior_var: float = PRIOR_VAR):
+        """fp32 counterpart of score_async (dense outputs are float32 tensors)."""
+        torch = self.torch
+        if getattr(self, "U32", None) is None:
+            self.prepare_f32()
+        Xsd = self._dev(Xs)
+        M = int(Xsd.shape[0])
+        if acquisition == "lcb":
+            kind, p0, p1 = _lib.ACQ_LCB, float(explore), 0.0
+        else:
+            kind, p0, p1 = _lib.ACQ_EI, float(f_best), float(xi)
+        with torch.cuda.device(self.device):
+            chunk = min(self.chunk, (M + 1023) // 1024 * 1024)
+            chunk = (chunk + 1023) // 1024 * 1024
+            need = int(self.lib.gpbo_posterior_workspace_bytes_f32(self.Np32, chunk, M))
+            if need < 0:
+                raise _lib.GpboError("gpbo_posterior_workspace_bytes_f32: invalid sizes")
+            if self._work_post32 is None or self._work_post32.numel() * 8 < need:
+                self._work_post32 = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
+            mu = sigma = acq = None
+            if dense:
+                mu, sigma, acq = (torch.empty(M, dtype=torch.float32, device=self.device) for _ in range(3))
+            st = self.lib.gpbo_posterior_acq_f32(
+                self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np32, self.d,
+                self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.U32), self._ptr(self.alpha32), prior_var,
+                kind, p0, p1, float(diag_add), int(idx_offset), chunk, self._ptr(mu), self._ptr(sigma),
+                self._ptr(acq), self._ptr(self._result), self._ptr(self._work_post32), need, self._profile,
+                self._stream())
+            _lib.check(st, "gpbo_posterior_acq_f32")
+        self._keep = Xsd
+        return self._result, mu, sigma, acq
+
+    def score_f32(self, Xs, **kw) -> ScoreResult:
+        res, mu, sigma, acq = self.score_async_f32(Xs, **kw)
+        v, i, n = self.read_result(res)
+        return ScoreResult(v, i, n, mu, sigma, acq)
 
     def read_result(self, result_tensor) -> tuple:
         r = result_tensor.cpu()  # synchronises

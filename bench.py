@@ -22,6 +22,7 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak = fp64 vector peak (half the 157.3 TF fp32 rate
 #                               listed in MI355X_MICROARCH.md; AMD data sheet value)
 
@@ -61,6 +62,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="f32: fp64 factorisation, fp32 K*/mean/variance (BASELINE configs[3] shape)")
     args = ap.parse_args()
 
     import numpy as np
@@ -94,9 +97,18 @@ def main():
     Xd, yd, Xsd = gp._dev(X), gp._dev(y), gp._dev(Xs_local)  # inputs resident in HBM before timing
     gp.enable_profile(8192)
 
+    f32 = args.dtype == "f32"
+
+    def score_async():
+        if f32:
+            return gp.score_async_f32(Xsd, acquisition="lcb", explore=4.0, idx_offset=lo)
+        return gp.score_async(Xsd, acquisition="lcb", explore=4.0, idx_offset=lo)
+
     def step():
         gp.factorise(Xd, yd, ls, check=False)
-        res, _, _, _ = gp.score_async(Xsd, acquisition="lcb", explore=4.0, idx_offset=lo)
+        if f32:
+            gp.prepare_f32()
+        res, _, _, _ = score_async()
         v, i, n = gp.read_result(res)               # 32-byte read-back (synchronises this rank)
         if int(gp.info.item()) != 0:
             raise RuntimeError("Cholesky failed")
@@ -131,40 +143,45 @@ def main():
     achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
     traffic = None
     pmc = os.path.join(REPO, "profiles", "pmc_sigma_acq.json")
-    if os.path.exists(pmc):
+    default_shape = (N, d, args.m_per_gpu, args.dtype, args.chunk) == (512, 8, 1 << 20, "f64", 0)
+    if os.path.exists(pmc) and default_shape:  # the committed PMC pass was taken on the default workload
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:  # noqa: BLE001
             traffic = None
-    roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                    kernel="sigma_acq_kernel", launches=int(k_launches), avg_launch_ms=round(k_avg_ms, 4),
+    peak = FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS
+    roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
+                    frac=round(achieved / peak, 4), traffic=traffic,
+                    kernel="sigma_acq_f32_kernel" if f32 else "sigma_acq_kernel", launches=int(k_launches), avg_launch_ms=round(k_avg_ms, 4),
                     flop_per_candidate=flop_per_cand, candidates_per_launch=cand_per_launch)
 
     # time of the scoring part alone (factorisation excluded), for the record
     fence()
     t1 = time.perf_counter()
     for _ in range(max(3, args.steps // 4)):
-        res, _, _, _ = gp.score_async(Xsd, acquisition="lcb", explore=4.0, idx_offset=lo)
+        res, _, _, _ = score_async()
         gp.read_result(res)
     torch.cuda.synchronize(dev)
     ms_score = (time.perf_counter() - t1) / max(3, args.steps // 4) * 1e3
 
+    cfg_name = {(512, 8, "f64"): "configs[1]", (4096, 8, "f64"): "configs[2] (per-GPU shard)",
+                (8192, 16, "f32"): "configs[3] (per-GPU shard)"}.get((N, d, args.dtype), "custom")
     out = None
     if rank == 0:
         out = {
             "metric": "candidate acquisitions/sec", "value": value, "unit": "candidates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: d={d}, N={N} Sobol observations, M=2^{int(np.log2(args.m_per_gpu))} "
-                                   f"Sobol candidates per GPU, ARD-SE GP, LCB(explore=4) arg-max, fp64; "
-                                   f"step = factorise + score all candidates + reduce",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": (f"{cfg_name}: d={d}, N={N} Sobol observations, M=2^{int(np.log2(args.m_per_gpu))} "
+                                    f"Sobol candidates per GPU, ARD-SE GP, LCB(explore=4) arg-max, "
+                                    f"{'fp64 factorisation + fp32 scoring' if f32 else 'fp64'}; "
+                                    f"step = factorise + score all candidates + reduce"),
                        "candidates_total": M_total, "parallelism": f"candidate-sharded x{world}"},
             "ms_per_step_scoring_only": ms_score,
             "value_excl_factorisation": (hi - lo) * world / (ms_score * 1e-3),
             "argmax_index": best[1], "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not f32:
             ns = min(args.cpu_sample, hi - lo)
             cb, idx_cpu = cpu_baseline(X, y, Xs_local[:ns], ls)
             r = gp.score(Xsd[:ns], acquisition="lcb", explore=4.0)

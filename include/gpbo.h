@@ -127,6 +127,20 @@ int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double *X, int64_t
                            gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof /* or NULL */,
                            void *stream);
 
+/* fp32 scoring path (BASELINE config 4): the factorisation stays fp64; U and alpha are rounded to fp32 once
+ * per step (gpbo_prepare_f32, re-padded to Np32 = gpbo_padded_n_f32(N), a multiple of 256) and the
+ * M-proportional work - K(X*,X), mean, variance on the fp32 matrix cores, acquisition, arg-max - runs in fp32.
+ * Candidates and observations are still given in fp64; dense outputs are fp32. chunk: a multiple of 1024. */
+int64_t gpbo_padded_n_f32(int64_t N);
+int gpbo_prepare_f32(const double *U, const double *alpha, int64_t Np, float *U32, float *alpha32, int64_t Np32,
+                     void *stream);
+int64_t gpbo_posterior_workspace_bytes_f32(int64_t Np32, int64_t chunk, int64_t M);
+int gpbo_posterior_acq_f32(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np32, int32_t d,
+                           const double *ls_host, const float *U32, const float *alpha32, double prior_var,
+                           int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset, int64_t chunk,
+                           float *mu_out, float *sigma_out, float *acq_out, gpbo_result *result, void *work,
+                           int64_t work_bytes, gpbo_profile *prof /* or NULL */, void *stream);
+
 /* K7+K8 on a posterior already on the device: acq = LCB/EI of (mu, sigma), first-index arg-max
  * (point_selector.py:204-207).  Used for a second acquisition on the same surrogate.
  * work: gpbo_acq_workspace_bytes() bytes, 256-byte aligned. */
