@@ -66,7 +66,8 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     const double *__restrict__ KsT, int64_t ldk, const double *__restrict__ U, int Np,
     const double *__restrict__ mu_part, int nsl, int64_t Mc, double prior_var, int acq_kind, double p0, double p1,
     int64_t idx_base, double *__restrict__ mu_out, double *__restrict__ sigma_out, double *__restrict__ acq_out,
-    double *__restrict__ part_val, int64_t *__restrict__ part_idx, unsigned long long *__restrict__ nan_count) {
+    double *__restrict__ part_val, int64_t *__restrict__ part_idx, unsigned long long *__restrict__ nan_count,
+    double *__restrict__ vbuf /* optional [chunk x Np]: V = K* U itself, for the joint (qEI) posterior */) {
     __shared__ double smem[3 * STAGE];
 
     const int tid = threadIdx.x;
@@ -195,6 +196,16 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         mfma8(a1, b1, 2);
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 == kt_end) {  // column block finished: fold |V|^2 into the row sums
+            if (vbuf) {  // (wave-uniform) keep the block of V: row = candidate, 16 consecutive columns per lane group
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            vbuf[(cand0 + wr * 64 + mi * 16 + l4 + 4 * r) * (int64_t)Np + jb * BN + (WQ * ni + wq) * 16 + l15] =
+                                acc[mi][ni][r];
+            }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -390,6 +401,162 @@ PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M) {
     return L;
 }
 
+
+// ================================================================================================
+// q-point Monte-Carlo Expected Improvement (BASELINE config 5; not in the reference).
+// Candidates are grouped consecutively in batches of q = 8.  For a batch b
+//     mu_b  = K*_b alpha,      Sigma_b = K_bb - V_b V_b^T,   V_b = rows of V = K* U belonging to the batch,
+//     K_bb  = k(x_i, x_j) with the reference's prior diagonal (1 + 1e-4) + 1e-6,
+//     qEI_b = 1/S sum_s max(0, max_j (f_best - xi - (mu_b + chol(Sigma_b) z_s)_j)),   z_s fixed base samples.
+// V comes from the variance kernel (vbuf); one wave per batch: Gram of 8 rows of V (coalesced row reads),
+// wave reduction, 8x8 Cholesky in registers, S samples spread over the lanes, fixed-order reductions.
+// ================================================================================================
+constexpr int QQ = 8, QT = QQ * (QQ + 1) / 2;  // 36 lower-triangle entries, index i*(i+1)/2 + j, j <= i
+
+struct QeiLs {
+    double il2[GPBO_MAX_D];
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void qei_kernel(const double *__restrict__ V, int Np, const double *__restrict__ mu,
+                                                  const double *__restrict__ Xs, int d, QeiLs ls, int64_t nbatch,
+                                                  double prior_var, double f_best, double xi,
+                                                  const double *__restrict__ Z, int S, int64_t batch_base,
+                                                  double *__restrict__ qei_out, double *__restrict__ part_val,
+                                                  int64_t *__restrict__ part_idx,
+                                                  unsigned long long *__restrict__ nan_count) {
+    __shared__ double s_val[4];
+    __shared__ int64_t s_idx[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wid;
+    const bool valid = b < nbatch;
+    const int64_t bb = valid ? b : 0;  // idle waves recompute batch 0 (keeps every shuffle full-wave)
+    const double *vrow = V + bb * QQ * (int64_t)Np;
+
+    double g[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) g[t] = 0.0;
+    for (int col = lane; col < Np; col += 64) {
+        double v[QQ];
+#pragma unroll
+        for (int j = 0; j < QQ; ++j) v[j] = vrow[(int64_t)j * Np + col];
+#pragma unroll
+        for (int i = 0; i < QQ; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) g[i * (i + 1) / 2 + j] = fma(v[i], v[j], g[i * (i + 1) / 2 + j]);
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) g[t] = wave_sum(g[t]);
+
+    // prior covariance of the batch, entry (i, j) by lane t = i(i+1)/2 + j, then gathered by every lane
+    double kmine = 0.0;
+    if (lane < QT) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= lane) ++i;
+        const int j = lane - i * (i + 1) / 2;
+        if (i == j) {
+            kmine = prior_var;
+        } else {
+            const double *xi_ = Xs + (bb * QQ + i) * d, *xj_ = Xs + (bb * QQ + j) * d;
+            double accd = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double diff = xi_[k] - xj_[k];
+                accd = fma(diff * diff, ls.il2[k], accd);
+            }
+            kmine = exp(-0.5 * accd);
+        }
+    }
+    double L[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) L[t] = __shfl(kmine, t) - g[t];  // Sigma_b, lower triangle
+
+    // in-register Cholesky (every lane redundantly; no divergence)
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < QQ; ++c) {
+        const double piv = L[c * (c + 1) / 2 + c];
+        if (!(piv > 0.0)) bad = true;
+        const double dd = sqrt(piv), inv = 1.0 / dd;
+        L[c * (c + 1) / 2 + c] = dd;
+#pragma unroll
+        for (int r = c + 1; r < QQ; ++r) L[r * (r + 1) / 2 + c] *= inv;
+#pragma unroll
+        for (int r = c + 1; r < QQ; ++r)
+#pragma unroll
+            for (int q2 = c + 1; q2 <= r; ++q2)
+                L[r * (r + 1) / 2 + q2] = fma(-L[r * (r + 1) / 2 + c], L[q2 * (q2 + 1) / 2 + c], L[r * (r + 1) / 2 + q2]);
+    }
+    double m[QQ];
+#pragma unroll
+    for (int j = 0; j < QQ; ++j) m[j] = f_best - xi - mu[bb * QQ + j];
+
+    double accs = 0.0;
+    for (int s = lane; s < S; s += 64) {
+        const double *z = Z + (int64_t)s * QQ;
+        double zz[QQ];
+#pragma unroll
+        for (int j = 0; j < QQ; ++j) zz[j] = z[j];
+        double best = 0.0;
+#pragma unroll
+        for (int j = 0; j < QQ; ++j) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k <= j; ++k) t = fma(L[j * (j + 1) / 2 + k], zz[k], t);
+            const double imp = m[j] - t;
+            best = (imp > best) ? imp : best;  // NaN never raises `best`; it is caught through `bad`
+        }
+        accs += best;
+    }
+    double qei = wave_sum(accs) / (double)S;
+    bool nanflag = bad || (qei != qei);
+#pragma unroll
+    for (int j = 0; j < QQ; ++j) nanflag = nanflag || (m[j] != m[j]);
+    if (nanflag) qei = __builtin_nan("");
+    if (lane == 0) {
+        if (valid && qei_out) qei_out[b] = qei;
+        if (valid && nanflag) atomicAdd(nan_count, 1ULL);
+        s_val[wid] = (valid && !nanflag) ? qei : -std::numeric_limits<double>::infinity();
+        s_idx[wid] = (valid && !nanflag) ? batch_base + b : std::numeric_limits<int64_t>::max();
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = s_val[0];
+        int64_t bi = s_idx[0];
+        for (int w = 1; w < 4; ++w)
+            if (better(s_val[w], s_idx[w], bv, bi)) { bv = s_val[w]; bi = s_idx[w]; }
+        part_val[blockIdx.x] = bv;
+        part_idx[blockIdx.x] = bi;
+    }
+}
+
+struct QeiLayout {
+    int64_t kst_off, mup_off, xsc_off, v_off, mu_off, spv_off, spi_off, pval_off, pidx_off, nan_off, total;
+};
+
+QeiLayout qei_layout(int64_t Np, int64_t chunk, int64_t M) {
+    QeiLayout L;
+    const int64_t nchunks = (M + chunk - 1) / chunk;
+    int64_t off = 0;
+    L.kst_off = off; off += align_up((int64_t)sizeof(double) * Np * chunk, 256);
+    L.mup_off = off; off += align_up((int64_t)sizeof(double) * (Np / GPBO_KS_SLICE) * chunk, 256);
+    L.xsc_off = off; off += align_up((int64_t)sizeof(double) * Np * GPBO_MAX_D, 256);
+    L.v_off = off; off += align_up((int64_t)sizeof(double) * Np * chunk, 256);
+    L.mu_off = off; off += align_up((int64_t)sizeof(double) * chunk, 256);
+    L.spv_off = off; off += align_up((int64_t)sizeof(double) * (chunk / BM), 256);
+    L.spi_off = off; off += align_up((int64_t)sizeof(int64_t) * (chunk / BM), 256);
+    const int64_t nparts = nchunks * ((chunk / QQ + 3) / 4);
+    L.pval_off = off; off += align_up((int64_t)sizeof(double) * nparts, 256);
+    L.pidx_off = off; off += align_up((int64_t)sizeof(int64_t) * nparts, 256);
+    L.nan_off = off; off += 256;
+    L.total = off;
+    return L;
+}
+
 }  // namespace
 
 int gpbo_launch_argmax_finish(const double *part_val, const int64_t *part_idx, int64_t nparts,
@@ -478,7 +645,7 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
     hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(512), 0, st, KsT[b], chunk, U, (int)Np,          \
                        mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,               \
                        mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                              \
-                       acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count)
+                       acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count, (double *)nullptr)
         if (variant == 1) GPBO_SIGMA_LAUNCH(1);
         else if (variant == 2) GPBO_SIGMA_LAUNCH(2);
         else if (variant == 3) GPBO_SIGMA_LAUNCH(3);
@@ -525,4 +692,65 @@ extern "C" int gpbo_acq_argmax_f64(const double *mu, const double *sigma, int64_
     hipLaunchKernelGGL(argmax_finish_kernel, dim3(1), dim3(256), 0, st, part_val, part_idx, nblk, nan_count, result);
     GPBO_CHECK_LAUNCH();
     return GPBO_OK;
+}
+
+extern "C" int64_t gpbo_qei_workspace_bytes(int64_t Np, int64_t chunk, int64_t M) {
+    if (Np < GPBO_NPAD || Np % GPBO_NPAD || chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || M < 1)
+        return GPBO_ERR_ARG;
+    return qei_layout(Np, chunk, M).total;
+}
+
+extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                                      const double *ls_host, const double *U, const double *alpha, double prior_var,
+                                      double f_best, double xi, const double *Z, int32_t S, int64_t batch_offset,
+                                      int64_t chunk, double *qei_out, gpbo_result *result, void *work,
+                                      int64_t work_bytes, void *stream) {
+    if (!Xs || !X || !U || !alpha || !Z || !result || !work) return GPBO_ERR_ARG;
+    if (M < QQ || M % QQ || N < 1 || Np != gpbo_padded_n(N) || S < 1 || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
+    if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE) return GPBO_ERR_ARG;
+    if (((uintptr_t)work & 255) || ((uintptr_t)U & 15)) return GPBO_ERR_ARG;
+    const QeiLayout L = qei_layout(Np, chunk, M);
+    if (work_bytes < L.total) return GPBO_ERR_WORKSPACE;
+    QeiLs ls;
+    for (int k = 0; k < GPBO_MAX_D; ++k) ls.il2[k] = 0.0;
+    for (int k = 0; k < d; ++k) {
+        if (!(ls_host[k] > 0.0)) return GPBO_ERR_ARG;
+        ls.il2[k] = 1.0 / (ls_host[k] * ls_host[k]);
+    }
+    hipStream_t st = gpbo_stream(stream);
+    char *w = reinterpret_cast<char *>(work);
+    double *KsT = reinterpret_cast<double *>(w + L.kst_off);
+    double *mu_part = reinterpret_cast<double *>(w + L.mup_off);
+    double *Xsc = reinterpret_cast<double *>(w + L.xsc_off);
+    double *Vb = reinterpret_cast<double *>(w + L.v_off);
+    double *mu = reinterpret_cast<double *>(w + L.mu_off);
+    double *spv = reinterpret_cast<double *>(w + L.spv_off);
+    int64_t *spi = reinterpret_cast<int64_t *>(w + L.spi_off);
+    double *part_val = reinterpret_cast<double *>(w + L.pval_off);
+    int64_t *part_idx = reinterpret_cast<int64_t *>(w + L.pidx_off);
+    unsigned long long *nan_count = reinterpret_cast<unsigned long long *>(w + L.nan_off);
+    unsigned long long *nan_scratch = nan_count + 8;  // NaN count of the single-point pass (not reported)
+    if (hipMemsetAsync(nan_count, 0, 256, st) != hipSuccess) return GPBO_ERR_LAUNCH;
+    int rc = gpbo_scale_points_f64(X, N, Np, d, ls_host, Xsc, stream);
+    if (rc != GPBO_OK) return rc;
+    int64_t nparts = 0;
+    for (int64_t s = 0; s < M; s += chunk) {
+        const int64_t Mc = (M - s < chunk) ? (M - s) : chunk;
+        rc = gpbo_kstar_mu_f64(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, 0.0, 0, KsT, chunk, mu_part, stream);
+        if (rc != GPBO_OK) return rc;
+        const int64_t nblk = (Mc + BM - 1) / BM;
+        // the variance kernel also leaves V (vbuf) and mu; its own single-point acquisition result is ignored
+        hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk), dim3(512), 0, st, KsT, chunk, U, (int)Np, mu_part,
+                           (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
+                           (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb);
+        GPBO_CHECK_LAUNCH();
+        const int64_t nbatch = Mc / QQ;
+        const int64_t qblk = (nbatch + 3) / 4;
+        hipLaunchKernelGGL(qei_kernel, dim3((unsigned)qblk), dim3(256), 0, st, Vb, (int)Np, mu, Xs + s * d, (int)d, ls, nbatch,
+                           prior_var, f_best, xi, Z, (int)S, batch_offset + s / QQ, qei_out ? qei_out + s / QQ : nullptr,
+                           part_val + nparts, part_idx + nparts, nan_count);
+        GPBO_CHECK_LAUNCH();
+        nparts += qblk;
+    }
+    return gpbo_launch_argmax_finish(part_val, part_idx, nparts, nan_count, result, st);
 }

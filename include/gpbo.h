@@ -127,6 +127,16 @@ int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double *X, int64_t
                            gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof /* or NULL */,
                            void *stream);
 
+/* q = 8 Monte-Carlo Expected Improvement over consecutive batches of 8 candidates (BASELINE config 5; not in the
+ * reference).  qEI_b = mean_s max(0, max_j(f_best - xi - (mu_b + chol(Sigma_b) z_s)_j)); Z: [S x 8] fixed base
+ * samples (device); M a multiple of 8 (chunks must not split a batch: chunk is a multiple of 512).
+ * result.best_idx = batch_offset + index of the first batch attaining the maximum; qei_out: optional [M/8]. */
+int64_t gpbo_qei_workspace_bytes(int64_t Np, int64_t chunk, int64_t M);
+int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                           const double *ls_host, const double *U, const double *alpha, double prior_var, double f_best,
+                           double xi, const double *Z, int32_t S, int64_t batch_offset, int64_t chunk, double *qei_out,
+                           gpbo_result *result, void *work, int64_t work_bytes, void *stream);
+
 /* fp32 scoring path (BASELINE config 4): the factorisation stays fp64; U and alpha are rounded to fp32 once
  * per step (gpbo_prepare_f32, re-padded to Np32 = gpbo_padded_n_f32(N), a multiple of 256) and the
  * M-proportional work - K(X*,X), mean, variance on the fp32 matrix cores, acquisition, arg-max - runs in fp32.

@@ -204,3 +204,42 @@ def select_next(X, y, Xs, feature_domain, length_scales=None, kernel_params=None
         acq = expected_improvement(mu, sig, float(np.min(y)), xi)
     return dict(kernel_params=np.asarray(kernel_params), nlogml=nlogml, mean_func=mu, cov_func=sig,
                 acq_func_eval=acq, index=argmax_first(acq))
+
+
+def qei_base_samples(n_samples: int = 512, q: int = 8, seed: int = 7) -> np.ndarray:
+    """Fixed base samples of the Monte-Carlo qEI: default_rng(7).standard_normal((512, 8))."""
+    return np.random.default_rng(seed).standard_normal((n_samples, q))
+
+
+def qei_mc(X, y, Xs, ls, Z, f_best=None, xi=0.0, q: int = 8):
+    """q-point Monte-Carlo Expected Improvement over consecutive batches of q candidates (this build's
+    definition, not in the reference): joint posterior of a batch from the Cholesky route,
+    Sigma_b = K_bb - V_b^T V_b with the reference's prior diagonal, L_b = chol(Sigma_b),
+    qEI_b = mean_s max(0, max_j (f_best - xi - (mu_b + L_b z_s)_j)).  Returns the (M/q,) array."""
+    X = np.asarray(X, dtype=np.float64)
+    Xs = np.asarray(Xs, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    if f_best is None:
+        f_best = float(np.min(y))
+    _, L, alpha = factorise(X, y, ls)
+    M = len(Xs)
+    assert M % q == 0
+    out = np.empty(M // q)
+    for b in range(M // q):
+        P = Xs[b * q:(b + 1) * q]
+        ksx = kernel_rbf(X, P, ls)                      # (N, q); no jitter (shapes differ unless N == q)
+        if X.shape == P.shape:
+            ksx = ksx - JITTER_KERNEL * np.eye(len(X))  # the batch never triggers the reference's N == M quirk
+        mu = ksx.T @ alpha
+        V = sla.solve_triangular(L, ksx, lower=True, check_finite=False)
+        lsq = np.asarray(ls, dtype=np.float64).reshape(-1)
+        d2 = np.zeros((q, q))
+        for k in range(P.shape[1]):
+            d2 += (P[:, k, None] - P[None, :, k]) ** 2 / lsq[k] ** 2
+        Kbb = np.exp(-0.5 * d2)
+        Kbb[np.arange(q), np.arange(q)] = PRIOR_VAR
+        Sig = Kbb - V.T @ V
+        Lb = np.linalg.cholesky(Sig)
+        f = mu[None, :] + Z @ Lb.T                      # (S, q)
+        out[b] = np.mean(np.maximum(0.0, np.max(f_best - xi - f, axis=1)))
+    return out

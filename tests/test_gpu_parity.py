@@ -261,3 +261,36 @@ def test_fp32_chunk_invariance_and_ties(golden):
     g = golden("g4_tie_tiny_ls")
     r = DeviceGP(chunk=1024).factorise(g["X"], g["y"], g["kernel_params"]).score_f32(g["Xs"], dense=True)
     assert r.best_idx == 0 and len(np.unique(r.acq.cpu().numpy())) == 1
+
+
+# ----------------------------------------------------------------------------------------------
+# q = 8 Monte-Carlo qEI (BASELINE config 5 shape: d=8; parity pinned by the oracle's restatement only)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,M,d,chunk,S", [(64, 1024, 8, 512, 512), (300, 2048, 8, 1024, 512), (33, 808, 3, 512, 100)])
+def test_qei_vs_oracle(N, M, d, chunk, S):
+    X, y, Xs, ls = make_problem(N, M, d)
+    Z = O.qei_base_samples(S, 8, 7)
+    f_best = float(y.min())
+    gp = DeviceGP(chunk=chunk).factorise(X, y, ls)
+    r = gp.score_qei(Xs, Z, f_best, xi=0.0, dense=True, batch_offset=5)
+    got = r.acq.cpu().numpy()
+    ref = O.qei_mc(X, y, Xs, ls, Z, f_best)
+    assert r.nan_count == 0 and got.shape == (M // 8,)
+    assert np.max(np.abs(got - ref)) <= 1e-9 * max(1.0, np.abs(y).max())   # fp64: same samples, same algebra
+    assert r.best_idx == 5 + _first_argmax(got) and r.best_val == got.max()
+    top2 = np.sort(ref)[-2:]
+    if top2[1] - top2[0] > 1e-7:
+        assert r.best_idx - 5 == _first_argmax(ref)
+
+
+def test_qei_nan_and_single_sample_limit():
+    X, y, Xs, ls = make_problem(50, 512, 4)
+    gp = DeviceGP().factorise(X, y, ls)
+    # one sample z = 0: qEI_b = max(0, max_j (f_best - mu_j)) exactly
+    r = gp.score_qei(Xs, np.zeros((1, 8)), 0.3, dense=True)
+    mu = gp.score(Xs, dense=True).mu.cpu().numpy().reshape(-1, 8)
+    np.testing.assert_allclose(r.acq.cpu().numpy(), np.maximum(0.0, (0.3 - mu).max(1)), rtol=0, atol=1e-12)
+    y2 = y.copy()
+    y2[0] = np.nan
+    r2 = DeviceGP().factorise(X, y2, ls).score_qei(Xs, O.qei_base_samples(64), 0.0)
+    assert r2.nan_count == 512 // 8

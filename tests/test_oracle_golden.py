@@ -94,3 +94,23 @@ def test_ei_closed_form_limits():
     ei = O.expected_improvement(mu, sg, f_best=0.0)
     assert abs(ei[0] - 1.0 / np.sqrt(2 * np.pi)) < 1e-15
     assert ei[1] == 0.0 and ei[2] == 1.0 and ei[3] == 0.0
+
+
+def test_qei_oracle_limits():
+    """qEI is this build's own definition (not in the reference): pin its restatement by closed-form limits."""
+    X, y, Xs, ls = make_problem(40, 64, 3)
+    mu, sig = O.posterior_chol(X, y, Xs, ls)
+    # one sample z = 0 -> max(0, max_j(f_best - mu_j)) per batch
+    q0 = O.qei_mc(X, y, Xs, ls, np.zeros((1, 8)), f_best=0.25)
+    np.testing.assert_allclose(q0, np.maximum(0.0, (0.25 - mu.reshape(-1, 8)).max(1)), rtol=0, atol=1e-12)
+    # qEI >= best single-point improvement of the batch evaluated on the same samples' mean (Jensen) and is
+    # monotone in f_best
+    Z = O.qei_base_samples(256)
+    a = O.qei_mc(X, y, Xs, ls, Z, f_best=0.0)
+    b = O.qei_mc(X, y, Xs, ls, Z, f_best=0.5)
+    assert np.all(b >= a) and np.all(a >= 0.0)
+    # antithetic pair of samples: mean of max(0, m - L z) and max(0, m + L z) for q-batches is symmetric in z
+    Z2 = np.concatenate([Z[:8], -Z[:8]])
+    c = O.qei_mc(X, y, Xs, ls, Z2, f_best=0.1)
+    d = O.qei_mc(X, y, Xs, ls, -Z2, f_best=0.1)
+    np.testing.assert_allclose(c, d, rtol=1e-13, atol=1e-15)
