@@ -294,3 +294,21 @@ def test_qei_nan_and_single_sample_limit():
     y2[0] = np.nan
     r2 = DeviceGP().factorise(X, y2, ls).score_qei(Xs, O.qei_base_samples(64), 0.0)
     assert r2.nan_count == 512 // 8
+
+
+def test_config3_shape_n4096_subsampled():
+    """BASELINE config 3 per-GPU shape (d=8, N=4096): oracle on a sub-sample that contains the top candidates."""
+    N, M, d = 4096, 1 << 16, 8
+    X, y, Xs, ls = make_problem(N, M, d)
+    gp = DeviceGP(chunk=1 << 15).factorise(X, y, ls)
+    r = gp.score(Xs, dense=True)
+    mu, sig, acq = r.mu.cpu().numpy(), r.sigma.cpu().numpy(), r.acq.cpu().numpy()
+    assert r.nan_count == 0 and r.best_idx == _first_argmax(acq)
+    sub = np.unique(np.concatenate([np.random.default_rng(3).choice(M, 2048, replace=False), np.argsort(acq)[-32:]]))
+    mu_o, sig_o = O.posterior_chol(X, y, Xs[sub], ls)
+    assert np.max(np.abs(mu[sub] - mu_o)) <= 1e-9 * max(1.0, np.abs(y).max())
+    assert np.max(np.abs(sig[sub] - sig_o)) <= 1e-8
+    acq_o = O.lcb(mu_o, sig_o, 4)
+    top2 = np.sort(acq_o)[-2:]
+    if top2[1] - top2[0] > 1e-7:
+        assert sub[_first_argmax(acq_o)] == r.best_idx
