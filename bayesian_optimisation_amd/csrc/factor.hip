@@ -17,36 +17,42 @@ constexpr int NB = GPBO_NB;  // 64
 constexpr int LDS_LD = NB + 1;
 
 // ---------------------------------------------------------------------------------------------
-// Diagonal block: unblocked Cholesky of one 64x64 block in LDS + its triangular inverse.
-// One workgroup of 256 threads.  a[][] holds the running Schur complement, l[][] the factor.
-// One barrier per column: column c of a[][] is never written again after step c, the scaled column
-// goes to l[][].
-// The inverse is built by doubling: blocks of size s are inverted, then
-// W21 = -W22 * (L21 * W11) joins two of them into a block of size 2s.
+// Diagonal block: Cholesky of one 64x64 block AND the inverse of its factor, in one elimination.
+// One workgroup of 256 threads.  The eliminated matrix is the 128x64 stack [A; I]: carrying the identity
+// rows through the same column operations leaves I * L^-T in them, i.e. inv(L)^T, so no separate
+// triangular inversion (and none of its dependent LDS chains) is needed.
+// Thread (ti, tj) keeps two 4x4 tiles in registers: rows 4ti.. of A and rows 4ti.. of the identity part,
+// columns 4tj...  Per column c the 16 owning threads publish the UNSCALED column through LDS (double
+// buffered, one barrier per column); everybody updates with a_ic * a_jc / piv, so only a reciprocal of the
+// pivot is on the critical path - the square roots are taken once at the end for all 64 columns.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_refined(double p) {
+    double y = __builtin_amdgcn_rcp(p);
+    double e = fma(-p, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-p, y, 1.0);
+    return fma(y, e, y);
+}
+
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ K, int64_t ld, int jb,
                                                          double *__restrict__ dinv, int32_t *__restrict__ info) {
-    __shared__ double l[NB * LDS_LD];
-    __shared__ double w[NB * LDS_LD];
-    __shared__ double t[NB * LDS_LD];
-    __shared__ double colbuf[2][NB];
+    __shared__ double lraw[NB * LDS_LD];   // unscaled columns of the A part:  lraw[r][c] = a_rc at step c
+    __shared__ double braw[NB * LDS_LD];   // unscaled columns of the identity part
+    __shared__ double colbuf[2][2 * NB];
+    __shared__ double pv[NB];
     const int tid = threadIdx.x;
     double *Kd = K + ((int64_t)jb * NB) * ld + (int64_t)jb * NB;
-
-    // Factorisation with the Schur complement held in registers: thread (ti, tj) owns the 4x4 tile
-    // rows 4ti.., cols 4tj.. (only tj <= ti carries data).  Per column c: the 16 threads that own it
-    // publish the (unscaled) column through LDS, everybody scales on the fly and updates its tile.
-    // One barrier per column (colbuf is double-buffered); no LDS read-modify-write chains.
     const int ti = tid >> 4, tj = tid & 15;
-    double a[4][4];
+    double a[4][4], b[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = 4 * ti + i, q = 4 * tj + j;
             a[i][j] = (q <= r) ? Kd[(int64_t)r * ld + q] : 0.0;
+            b[i][j] = (q == r) ? 1.0 : 0.0;
         }
-    for (int e = tid; e < NB * LDS_LD; e += 256) { l[e] = 0.0; w[e] = 0.0; }
+    for (int e = tid; e < NB * LDS_LD; e += 256) { lraw[e] = 0.0; braw[e] = 0.0; }
     bool bad = false;
     for (int cj = 0; cj < NB / 4; ++cj) {
 #pragma unroll
@@ -55,69 +61,59 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ K,
             double *cb = colbuf[c & 1];
             if (tj == cj) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) cb[4 * ti + i] = a[i][cc];
+                for (int i = 0; i < 4; ++i) {
+                    cb[4 * ti + i] = a[i][cc];
+                    cb[NB + 4 * ti + i] = b[i][cc];
+                }
             }
             __syncthreads();
             const double piv = cb[c];
             if (!(piv > 0.0) || !(piv < 1.0e300)) bad = true;  // non-positive, NaN or Inf pivot
             if (bad && tid == 0) atomicCAS(info, 0, jb * NB + c + 1);
-            const double dd = sqrt(piv);
-            const double inv = 1.0 / dd;
-            double lr[4], lq[4];
+            const double rp = rcp_refined(piv);
+            double ta[4], tb[4], aq[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { lr[i] = cb[4 * ti + i] * inv; lq[i] = cb[4 * tj + i] * inv; }
-            if (tj == cj) {  // column c of L
+            for (int i = 0; i < 4; ++i) {
+                ta[i] = cb[4 * ti + i] * rp;
+                tb[i] = cb[NB + 4 * ti + i] * rp;
+                aq[i] = cb[4 * tj + i];
+            }
+            if (tj == cj) {  // keep the unscaled column c (rows >= c of A, rows <= c of the identity part)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * ti + i;
-                    if (r == c) l[r * LDS_LD + c] = dd;
-                    else if (r > c) l[r * LDS_LD + c] = lr[i];
+                    if (r >= c) lraw[r * LDS_LD + c] = cb[r];
+                    if (r <= c) braw[r * LDS_LD + c] = cb[NB + r];
                 }
+                if (ti == cj) pv[c] = piv;  // (four threads write the same value)
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool upd = (tj > cj) || (tj == cj && j > cc);  // columns to the right of c
                 if (upd) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i][j] = fma(-lr[i], lq[j], a[i][j]);
+                    for (int i = 0; i < 4; ++i) {
+                        a[i][j] = fma(-ta[i], aq[j], a[i][j]);
+                        b[i][j] = fma(-tb[i], aq[j], b[i][j]);
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    // write L back (lower triangle incl. diagonal)
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        if (c <= r) Kd[(int64_t)r * ld + c] = l[r * LDS_LD + c];
-    }
-    // inverse: size-1 blocks
-    if (tid < NB) w[tid * LDS_LD + tid] = 1.0 / l[tid * LDS_LD + tid];
-    for (int s = 1; s < NB; s <<= 1) {
-        __syncthreads();
-        // T = L21 * W11 for every pair; pair p covers rows/cols [2ps, 2ps+2s)
-        const int npairs = NB / (2 * s);
-        for (int e = tid; e < npairs * s * s; e += 256) {
-            const int p = e / (s * s), rem = e - p * s * s;
-            const int i = rem / s, j = rem - i * s;
-            const int o = 2 * p * s;
-            double sum = 0.0;
-            for (int m = j; m < s; ++m) sum = fma(l[(o + s + i) * LDS_LD + o + m], w[(o + m) * LDS_LD + o + j], sum);
-            t[(o + s + i) * LDS_LD + o + j] = sum;
-        }
-        __syncthreads();
-        // W21 = -W22 * T
-        for (int e = tid; e < npairs * s * s; e += 256) {
-            const int p = e / (s * s), rem = e - p * s * s;
-            const int i = rem / s, j = rem - i * s;
-            const int o = 2 * p * s;
-            double sum = 0.0;
-            for (int m = 0; m <= i; ++m) sum = fma(w[(o + s + i) * LDS_LD + o + s + m], t[(o + s + m) * LDS_LD + o + j], sum);
-            w[(o + s + i) * LDS_LD + o + j] = -sum;
-        }
+    // scale: L[r][c] = a_rc / sqrt(piv_c);  inv(L)[c][i] = b_ic / sqrt(piv_c)
+    if (tid < NB) {
+        const double dd = sqrt(pv[tid]);
+        pv[tid] = 1.0 / dd;
     }
     __syncthreads();
     double *dv = dinv + (int64_t)jb * NB * NB;
-    for (int e = tid; e < NB * NB; e += 256) dv[e] = w[(e >> 6) * LDS_LD + (e & 63)];
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        if (c <= r) Kd[(int64_t)r * ld + c] = lraw[r * LDS_LD + c] * pv[c];
+        // dinv row r, column c = inv(L)[r][c] = braw[c][r] / sqrt(piv_r)   (lower triangular: c <= r)
+        dv[e] = (c <= r) ? braw[c * LDS_LD + r] * pv[r] : 0.0;
+    }
 }
 
 // W <- block-diagonal of dinv, zero elsewhere.   grid (Np/64, Np/64), block 256.

@@ -40,6 +40,10 @@ def cpu_baseline(X, y, Xs_sample, ls):
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:  # noqa: BLE001
         threads = os.cpu_count() or 1
+    try:
+        threads = min(threads, len(os.sched_getaffinity(0)))  # BLAS threads that can actually run
+    except Exception:  # noqa: BLE001
+        pass
     _, L, alpha = O.factorise(X, y, ls)
     t0 = time.perf_counter()
     mu, sig = O.posterior_chol(X, y, Xs_sample, ls, L=L, alpha=alpha)
@@ -60,7 +64,8 @@ def main():
     ap.add_argument("--m-per-gpu", type=int, default=1 << 20)
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 16)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 19,
+                    help="candidates timed on the host for cpu_baseline (about 10-20 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="f32: fp64 factorisation, fp32 K*/mean/variance (BASELINE configs[3] shape)")
