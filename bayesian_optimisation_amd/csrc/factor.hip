@@ -36,10 +36,11 @@ __device__ __forceinline__ double rcp_refined(double p) {
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ K, int64_t ld, int jb,
                                                          double *__restrict__ dinv, int32_t *__restrict__ info) {
-    __shared__ double lraw[NB * LDS_LD];   // unscaled columns of the A part:  lraw[r][c] = a_rc at step c
-    __shared__ double braw[NB * LDS_LD];   // unscaled columns of the identity part
-    __shared__ double colbuf[2][2 * NB];
-    __shared__ double pv[NB];
+    // colT[c][0..63]  = unscaled column c of the A part, colT[c][64..127] = of the identity part, as published
+    // at step c.  Every column has its own slot, so the slot doubles as the record the final scaling reads
+    // (no copy, no double buffering) and the loop body stays short: with one wave per SIMD nothing hides
+    // instruction count, which is what bounded the earlier versions (~330 instructions per column).
+    __shared__ double colT[NB][2 * NB];
     const int tid = threadIdx.x;
     double *Kd = K + ((int64_t)jb * NB) * ld + (int64_t)jb * NB;
     const int ti = tid >> 4, tj = tid & 15;
@@ -52,14 +53,16 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ K,
             a[i][j] = (q <= r) ? Kd[(int64_t)r * ld + q] : 0.0;
             b[i][j] = (q == r) ? 1.0 : 0.0;
         }
-    for (int e = tid; e < NB * LDS_LD; e += 256) { lraw[e] = 0.0; braw[e] = 0.0; }
-    bool bad = false;
+    int first_bad = 0;  // 1-based column of the first non-positive / non-finite pivot
     for (int cj = 0; cj < NB / 4; ++cj) {
+        // columns to the right of the current one inside this thread's tile: all four if tj > cj, none if
+        // tj < cj, (j > cc) on the diagonal tile column - applied as a mask on the broadcast column values
+        const bool right = tj > cj, same = tj == cj;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
             const int c = 4 * cj + cc;
-            double *cb = colbuf[c & 1];
-            if (tj == cj) {
+            double *cb = colT[c];
+            if (same) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     cb[4 * ti + i] = a[i][cc];
@@ -68,51 +71,37 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ K,
             }
             __syncthreads();
             const double piv = cb[c];
-            if (!(piv > 0.0) || !(piv < 1.0e300)) bad = true;  // non-positive, NaN or Inf pivot
-            if (bad && tid == 0) atomicCAS(info, 0, jb * NB + c + 1);
+            const bool ok = (piv > 0.0) && (piv < 1.0e300);
+            first_bad = (!ok && first_bad == 0) ? c + 1 : first_bad;
             const double rp = rcp_refined(piv);
             double ta[4], tb[4], aq[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 ta[i] = cb[4 * ti + i] * rp;
                 tb[i] = cb[NB + 4 * ti + i] * rp;
-                aq[i] = cb[4 * tj + i];
+                const bool upd = right || (same && i > cc);
+                aq[i] = upd ? cb[4 * tj + i] : 0.0;
             }
-            if (tj == cj) {  // keep the unscaled column c (rows >= c of A, rows <= c of the identity part)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * ti + i;
-                    if (r >= c) lraw[r * LDS_LD + c] = cb[r];
-                    if (r <= c) braw[r * LDS_LD + c] = cb[NB + r];
+                    a[i][j] = fma(-ta[i], aq[j], a[i][j]);
+                    b[i][j] = fma(-tb[i], aq[j], b[i][j]);
                 }
-                if (ti == cj) pv[c] = piv;  // (four threads write the same value)
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool upd = (tj > cj) || (tj == cj && j > cc);  // columns to the right of c
-                if (upd) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        a[i][j] = fma(-ta[i], aq[j], a[i][j]);
-                        b[i][j] = fma(-tb[i], aq[j], b[i][j]);
-                    }
-                }
-            }
         }
     }
     __syncthreads();
-    // scale: L[r][c] = a_rc / sqrt(piv_c);  inv(L)[c][i] = b_ic / sqrt(piv_c)
-    if (tid < NB) {
-        const double dd = sqrt(pv[tid]);
-        pv[tid] = 1.0 / dd;
-    }
+    if (tid == 0 && first_bad) atomicCAS(info, 0, jb * NB + first_bad);
+    // scale: d_c = sqrt(piv_c);  L[r][c] = a_rc / d_c (r >= c);  inv(L)[r][c] = b_cr / d_r (c <= r)
+    __shared__ double rs[NB];
+    if (tid < NB) rs[tid] = 1.0 / sqrt(colT[tid][tid]);
     __syncthreads();
     double *dv = dinv + (int64_t)jb * NB * NB;
     for (int e = tid; e < NB * NB; e += 256) {
         const int r = e >> 6, c = e & 63;
-        if (c <= r) Kd[(int64_t)r * ld + c] = lraw[r * LDS_LD + c] * pv[c];
-        // dinv row r, column c = inv(L)[r][c] = braw[c][r] / sqrt(piv_r)   (lower triangular: c <= r)
-        dv[e] = (c <= r) ? braw[c * LDS_LD + r] * pv[r] : 0.0;
+        if (c <= r) Kd[(int64_t)r * ld + c] = colT[c][r] * rs[c];
+        dv[e] = (c <= r) ? colT[r][NB + c] * rs[r] : 0.0;
     }
 }
 
