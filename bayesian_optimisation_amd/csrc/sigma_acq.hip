@@ -22,6 +22,7 @@
 
 #include <cstdlib>
 #include <limits>
+#include <type_traits>
 
 namespace {
 
@@ -121,7 +122,6 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     auto advance = [&](int &j, int &k) {
         if (++k == (j + 1) * (BN / BK)) { ++j; k = 0; }
     };
-    int jb = 0, kt = 0, cur = 0;
     int pj = 0, pk = 0, pbuf = 0;  // next tile to stage
     stage(pj, pk, pbuf);
     advance(pj, pk);
@@ -144,8 +144,17 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[(kk + l4) * LDB + (WQ * ni + wq) * 16 + l15];
     };
     lds_frag(a0, b0, 0, 0);
-    while (true) {
-        const int kt_end = (jb + 1) * (BN / BK);  // k tiles of this column block
+    int dbg_it = 0;
+    int cur = 0;
+    // One tile.  FULL = every 16x16 tile of U in it is non-zero (all k tiles left of the diagonal block): the
+    // MFMA stream is then free of branches; on the diagonal block, MFMA groups of 16-column tiles that lie wholly
+    // below U's diagonal are branched over (wave-uniform).  LDS reads, barrier and DMA are the same in both.
+    auto tile_body = [&](auto full_tag, int jb, int kt) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        if (VARIANT == 6 && vbuf && tid == 0) {  // diagnostic: cycle stamp per tile (timing build only)
+            vbuf[(int64_t)blockIdx.x * 1024 + dbg_it] = (double)__builtin_amdgcn_s_memtime();
+            ++dbg_it;
+        }
         const int nxt = (cur == 2) ? 0 : cur + 1;
         // first 16-column tile of this wave that still has non-zero rows of U in this k tile (>= 4: none)
         // (wave column group wq owns the 16-column tiles WQ ni + wq of the block, so on the diagonal all waves
@@ -153,12 +162,10 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         int ni_min = (kt - jb * (BN / BK) - wq + WQ - 1) / WQ;
         ni_min = ni_min < 0 ? 0 : ni_min;
         if (VARIANT == 2) ni_min = 0;
-        // MFMA groups of 16-column tiles that lie wholly below U's diagonal are branched over (wave-uniform);
-        // LDS reads, barrier and DMA are unconditional, so there is one code path and one accumulator set.
         auto mfma8 = [&](const double (&af)[4], const double (&bf)[4], int nlo) {
 #pragma unroll
             for (int ni = nlo; ni < nlo + 2; ++ni) {
-                if (ni >= ni_min) {
+                if (FULL || ni >= ni_min) {
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf[ni], acc[mi][ni]);
                 }
@@ -195,29 +202,31 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         __builtin_amdgcn_sched_barrier(0);
         mfma8(a1, b1, 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 == kt_end) {  // column block finished: fold |V|^2 into the row sums
-            if (vbuf) {  // (wave-uniform) keep the block of V: row = candidate, 16 consecutive columns per lane group
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            vbuf[(cand0 + wr * 64 + mi * 16 + l4 + 4 * r) * (int64_t)Np + jb * BN + (WQ * ni + wq) * 16 + l15] =
-                                acc[mi][ni][r];
-            }
+        cur = nxt;
+    };
+    for (int jb = 0; jb < nJ; ++jb) {
+        const int heavy = jb * (BN / BK);
+        for (int kt = 0; kt < heavy; ++kt) tile_body(std::true_type{}, jb, kt);
+        for (int kt = heavy; kt < heavy + BN / BK; ++kt) tile_body(std::false_type{}, jb, kt);
+        // column block finished: fold |V|^2 into the row sums
+        if (vbuf && VARIANT != 6) {  // (wave-uniform) keep the block of V: row = candidate, 16 consecutive columns per lane group
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
+                for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ss[mi][r] = fma(acc[mi][ni][r], acc[mi][ni][r], ss[mi][r]);
-                    acc[mi][ni] = d4_t{0.0, 0.0, 0.0, 0.0};
-                }
+                    for (int r = 0; r < 4; ++r)
+                        vbuf[(cand0 + wr * 64 + mi * 16 + l4 + 4 * r) * (int64_t)Np + jb * BN + (WQ * ni + wq) * 16 + l15] =
+                            acc[mi][ni][r];
         }
-        advance(jb, kt);
-        if (jb >= nJ) break;
-        cur = nxt;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss[mi][r] = fma(acc[mi][ni][r], acc[mi][ni][r], ss[mi][r]);
+                acc[mi][ni] = d4_t{0.0, 0.0, 0.0, 0.0};
+            }
     }
 
     // ---- row sums: across the 16 lanes that share a candidate row, then across the two column halves
@@ -645,11 +654,13 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
     hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(512), 0, st, KsT[b], chunk, U, (int)Np,          \
                        mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,               \
                        mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                              \
-                       acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count, (double *)nullptr)
+                       acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count,                     \
+                       (V == 6 && c == nchunks - 1 && nchunks > 1) ? KsT[(c + 1) & 1] : (double *)nullptr)
         if (variant == 1) GPBO_SIGMA_LAUNCH(1);
         else if (variant == 2) GPBO_SIGMA_LAUNCH(2);
         else if (variant == 3) GPBO_SIGMA_LAUNCH(3);
         else if (variant == 4) GPBO_SIGMA_LAUNCH(4);
+        else if (variant == 6) GPBO_SIGMA_LAUNCH(6);
         else GPBO_SIGMA_LAUNCH(0);
 #undef GPBO_SIGMA_LAUNCH
         if (rec) {
