@@ -14,6 +14,7 @@
 
 #include <cstdlib>
 #include <limits>
+#include <type_traits>
 
 namespace {
 
@@ -167,7 +168,6 @@ __global__ __launch_bounds__(512) void sigma_acq_f32_kernel(
     auto advance = [&](int &j, int &k) {
         if (++k == (j + 1) * (BN / BK)) { ++j; k = 0; }
     };
-    int jb = 0, kt = 0, cur = 0;
     int pj = 0, pk = 0, pbuf = 0;
     stage(pj, pk, pbuf);
     advance(pj, pk);
@@ -190,15 +190,17 @@ __global__ __launch_bounds__(512) void sigma_acq_f32_kernel(
         for (int ni = 0; ni < NI; ++ni) bf[ni] = Bs[(kk + l4) * LDB + (WQ * ni + wq) * 16 + l15];
     };
     lds_frag(a0, b0, 0, 0);
-    while (true) {
-        const int kt_end = (jb + 1) * (BN / BK);
+    int cur = 0;
+    // FULL tiles (left of the diagonal block) run a branch-free MFMA stream; see sigma_acq.hip
+    auto tile_body = [&](auto full_tag, int jb, int kt) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const int nxt = (cur == 2) ? 0 : cur + 1;
         int ni_min = (kt - jb * (BN / BK) - wq + WQ - 1) / WQ;  // column tile WQ ni + wq is needed iff >= kt'
         ni_min = ni_min < 0 ? 0 : ni_min;
         auto mfma_half = [&](const float (&af)[4], const float (&bf)[NI], int nlo) {
 #pragma unroll
             for (int ni = nlo; ni < nlo + NI / 2; ++ni) {
-                if (ni >= ni_min) {
+                if (FULL || ni >= ni_min) {
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
@@ -234,19 +236,20 @@ __global__ __launch_bounds__(512) void sigma_acq_f32_kernel(
         __builtin_amdgcn_sched_barrier(0);
         mfma_half(a1, b1, NI / 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 == kt_end) {
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ss[mi][r] = fmaf(acc[mi][ni][r], acc[mi][ni][r], ss[mi][r]);
-                    acc[mi][ni] = f4_t{0.f, 0.f, 0.f, 0.f};
-                }
-        }
-        advance(jb, kt);
-        if (jb >= nJ) break;
         cur = nxt;
+    };
+    for (int jb = 0; jb < nJ; ++jb) {
+        const int heavy = jb * (BN / BK);
+        for (int kt = 0; kt < heavy; ++kt) tile_body(std::true_type{}, jb, kt);
+        for (int kt = heavy; kt < heavy + BN / BK; ++kt) tile_body(std::false_type{}, jb, kt);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss[mi][r] = fmaf(acc[mi][ni][r], acc[mi][ni][r], ss[mi][r]);
+                acc[mi][ni] = f4_t{0.f, 0.f, 0.f, 0.f};
+            }
     }
 
     __syncthreads();
