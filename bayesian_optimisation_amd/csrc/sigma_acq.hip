@@ -81,9 +81,24 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     // staging: global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPRs).
     // LDS image rows are padded, and every wave instruction's 1 KiB lies inside one row:
     //   A tile (K*^T): 16 rows x BM/128 pieces, B tile (U): 16 rows x BN/128 pieces; wave w takes pieces w + 8r
-    const double *a_src = KsT + cand0;  // wave-uniform bases; the lane offset rides in the VGPR operand
-    const double *b_src = U;
-    const int lane2 = lane * 2;
+    // The tile base pointers are wave-uniform and advance incrementally (scalar adds); each lane's share of a
+    // piece is a 32-bit element offset fixed for the whole kernel, so one DMA costs a few scalar instructions.
+    const double *a_base = KsT + cand0;
+    constexpr int AP = BM / 128, BP = BN / 128;  // 1 KiB pieces per row
+    unsigned voffA[2 * AP], voffB[2 * BP];        // element offsets inside a tile (row * ld + piece * 128 + lane * 2)
+    int ldsA[2 * AP], ldsB[2 * BP];               // LDS element offsets of the pieces inside a stage
+#pragma unroll
+    for (int r = 0; r < 2 * AP; ++r) {
+        const int u = wid + 8 * r, row = u / AP, piece = u % AP;
+        voffA[r] = (unsigned)(row * (unsigned)ldk + piece * 128 + lane * 2);
+        ldsA[r] = row * LDA + piece * 128;
+    }
+#pragma unroll
+    for (int r = 0; r < 2 * BP; ++r) {
+        const int u = wid + 8 * r, row = u / BP, piece = u % BP;
+        voffB[r] = (unsigned)(row * (unsigned)Np + piece * 128 + lane * 2);
+        ldsB[r] = A_TILE + row * LDB + piece * 128;
+    }
     d4_t acc[4][4];
     double ss[4][4];
 #pragma unroll
@@ -95,19 +110,24 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         }
 
     const int nJ = Np / BN;
-    auto stage = [&](int jb, int kt, int buf) {
-        double *As = smem + buf * STAGE;
-        double *Bs = As + A_TILE;
-        constexpr int AP = BM / 128, BP = BN / 128;  // 1 KiB pieces per row
+    // staging iterator: tile (pj, pk) goes to stage pbuf; pa / pb are its global bases
+    const double *pa = a_base, *pb = U;
+    int pj = 0, pk = 0, pbuf = 0;
+    auto stage_next = [&]() {
+        double *St = smem + pbuf * STAGE;
 #pragma unroll
-        for (int r = 0; r < 2 * AP; ++r) {
-            const int u = wid + 8 * r, row = u / AP, piece = u % AP;
-            glds16(a_src + (int64_t)(kt * BK + row) * ldk + piece * 128 + lane2, As + row * LDA + piece * 128);
-        }
+        for (int r = 0; r < 2 * AP; ++r) glds16(pa + voffA[r], St + ldsA[r]);
 #pragma unroll
-        for (int r = 0; r < 2 * BP; ++r) {
-            const int u = wid + 8 * r, row = u / BP, piece = u % BP;
-            glds16(b_src + (int64_t)(kt * BK + row) * Np + jb * BN + piece * 128 + lane2, Bs + row * LDB + piece * 128);
+        for (int r = 0; r < 2 * BP; ++r) glds16(pb + voffB[r], St + ldsB[r]);
+        pbuf = (pbuf == 2) ? 0 : pbuf + 1;
+        if (++pk == (pj + 1) * (BN / BK)) {  // next column block: k restarts, columns move right
+            ++pj;
+            pk = 0;
+            pa = a_base;
+            pb = U + (int64_t)pj * BN;
+        } else {
+            pa += (int64_t)BK * ldk;
+            pb += (int64_t)BK * Np;
         }
     };
 
@@ -119,18 +139,8 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     //   - each wave has first waited for its own LDS-DMA of tile t+1 (issued one tile earlier), so after the
     //     barrier tile t+1 is complete for everyone, half a tile before anyone reads it;
     //   - every wave has left tile t-1, so its stage may be overwritten: the DMA of tile t+2 is issued now.
-    auto advance = [&](int &j, int &k) {
-        if (++k == (j + 1) * (BN / BK)) { ++j; k = 0; }
-    };
-    int pj = 0, pk = 0, pbuf = 0;  // next tile to stage
-    stage(pj, pk, pbuf);
-    advance(pj, pk);
-    pbuf = 1;
-    if (pj < nJ) {
-        stage(pj, pk, pbuf);
-        advance(pj, pk);
-        pbuf = 2;
-    }
+    stage_next();
+    if (pj < nJ) stage_next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -186,11 +196,7 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own share of tile t+1 has landed
             __builtin_amdgcn_s_barrier();
         }
-        if (pj < nJ && VARIANT != 1 && VARIANT != 4) {
-            stage(pj, pk, pbuf);  // tile t+2 into the stage tile t-1 occupied
-            advance(pj, pk);
-            pbuf = (pbuf == 2) ? 0 : pbuf + 1;
-        }
+        if (pj < nJ && VARIANT != 1 && VARIANT != 4) stage_next();  // tile t+2 into the stage tile t-1 occupied
         __builtin_amdgcn_sched_barrier(0);
         mfma8(a0, b0, 0);
         lds_frag(a1, b1, cur, 12);
