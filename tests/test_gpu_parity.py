@@ -312,3 +312,48 @@ def test_config3_shape_n4096_subsampled():
     top2 = np.sort(acq_o)[-2:]
     if top2[1] - top2[0] > 1e-7:
         assert sub[_first_argmax(acq_o)] == r.best_idx
+
+
+# ----------------------------------------------------------------------------------------------
+# edge shapes: padding boundaries of N (128), of the candidate tiles (256) and chunks (512), every feature count
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [2, 127, 128, 129, 256, 257])
+@pytest.mark.parametrize("M", [1, 255, 256, 257, 511, 513, 1025])
+def test_padding_boundaries(N, M):
+    rng = np.random.default_rng(N * 1000 + M)
+    d = 3
+    X, Xs = rng.uniform(0, 1, (N, d)), rng.uniform(0, 1, (M, d))
+    y = rng.standard_normal(N)
+    ls = np.array([0.25, 0.5, 1.0])
+    gp = DeviceGP(chunk=512).factorise(X, y, ls)
+    # N == M: the reference's kernel_rbf adds its 1e-4 jitter to K(X, X*) too (shape-equality rule); the oracle
+    # reproduces that and the caller of the C ABI asks for it through diag_add (PointSelector does)
+    quirk = 1e-4 if N == M else 0.0
+    r = gp.score(Xs, dense=True, diag_add=quirk)
+    mu_o, sig_o = O.posterior_chol(X, y, Xs, ls)
+    assert np.max(np.abs(r.mu.cpu().numpy() - mu_o)) <= 1e-9 * max(1.0, np.abs(y).max())
+    assert np.max(np.abs(r.sigma.cpu().numpy() - sig_o)) <= 1e-8
+    acq = r.acq.cpu().numpy()
+    assert r.nan_count == 0 and r.best_idx == _first_argmax(acq) and r.best_val == acq.max()
+    r32 = gp.score_f32(Xs, dense=True, diag_add=quirk)
+    assert np.max(np.abs(r32.sigma.cpu().numpy() - sig_o)) <= 5e-3
+    assert r32.best_idx == _first_argmax(r32.acq.cpu().numpy())
+
+
+@pytest.mark.parametrize("d", list(range(1, 17)))
+def test_every_feature_count(d):
+    X, y, Xs, ls = make_problem(70, 600, d)
+    gp = DeviceGP(chunk=512).factorise(X, y, ls)
+    r = gp.score(Xs, dense=True)
+    mu_o, sig_o = O.posterior_chol(X, y, Xs, ls)
+    assert np.max(np.abs(r.mu.cpu().numpy() - mu_o)) <= 1e-9 * max(1.0, np.abs(y).max())
+    assert np.max(np.abs(r.sigma.cpu().numpy() - sig_o)) <= 1e-8
+    np.testing.assert_allclose(gp.cov_meas_host(), O.kernel_rbf(X, X, ls) + 1e-6 * np.eye(70), rtol=0, atol=5e-15)
+    r32 = gp.score_f32(Xs, dense=True)
+    assert np.max(np.abs(r32.mu.cpu().numpy() - mu_o)) <= 5e-3 * max(1.0, np.abs(y).max())
+
+
+def test_unsupported_feature_count_raises():
+    X, y, Xs, ls = make_problem(10, 20, 17)
+    with pytest.raises(ValueError):
+        DeviceGP().factorise(X, y, ls)
