@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1 << 19,
                     help="candidates timed on the host for cpu_baseline (about 10-20 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only to rehearse N>1 on one GPU")
+    ap.add_argument("--all-on-device", type=int, default=-1,
+                    help="rehearsal only: put every rank on this GPU index instead of LOCAL_RANK")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="f32: fp64 factorisation, fp32 K*/mean/variance (BASELINE configs[3] shape)")
     args = ap.parse_args()
@@ -80,11 +83,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.all_on_device < 0 else args.all_on_device
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from bayesian_optimisation_amd import DeviceGP
     from bayesian_optimisation_amd import distributed as D
@@ -134,7 +141,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_step = dt / args.steps * 1e3
