@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
         const double *xo1 = xo0 + D;
         double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
+        for (int k = 0; k < (VARIANT == 3 ? 1 : D); ++k) {
             const double o0 = xo0[k], o1 = xo1[k];
             const double d00 = xa[k] - o0, d01 = xb[k] - o0, d10 = xa[k] - o1, d11 = xb[k] - o1;
             s00 = fma(d00, d00, s00);
@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
             s10 = fma(d10, d10, s10);
             s11 = fma(d11, d11, s11);
         }
-        double k00 = exp_neg(s00, tab), k01 = exp_neg(s01, tab), k10 = exp_neg(s10, tab), k11 = exp_neg(s11, tab);
+        double k00, k01, k10, k11;
+        if (VARIANT == 3) { k00 = s00; k01 = s01; k10 = s10; k11 = s11; }
+        else { k00 = exp_neg(s00, tab); k01 = exp_neg(s01, tab); k10 = exp_neg(s10, tab); k11 = exp_neg(s11, tab); }
         if (HAS_DIAG) {  // N == M shape-coincidence quirk (point_selector.py:173,191-193)
             if ((int64_t)n == cand_base + c0) k00 += diag_add;
             if ((int64_t)n == cand_base + c0 + 1) k01 += diag_add;
@@ -283,6 +285,7 @@ extern "C" int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *Xsc
 #define CALL(DD)                                        \
     if (diag_add != 0.0) KSTAR_LAUNCH(DD, 0, true);     \
     else if (variant == 1) KSTAR_LAUNCH(DD, 1, false);  \
+    else if (variant == 3) KSTAR_LAUNCH(DD, 3, false);  \
     else KSTAR_LAUNCH(DD, 0, false)
     GPBO_DISPATCH_D(d, CALL)
 #undef CALL
