@@ -220,11 +220,15 @@ __global__ __launch_bounds__(512) void sigma_acq_f32_kernel(
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of tile t+1 have landed
         __builtin_amdgcn_s_barrier();
-        if (pj < nJ) {
+        // column group 0 issues its DMA pieces of tile t+2 here, column group 1 at the end of the tile, so that the
+        // two waves of a SIMD do not stop feeding the matrix pipe at the same moment
+        const bool do_stage = pj < nJ;
+        auto stage_adv = [&]() {
             stage(pj, pk, pbuf);
             advance(pj, pk);
             pbuf = (pbuf == 2) ? 0 : pbuf + 1;
-        }
+        };
+        if (do_stage && wq == 0) stage_adv();
         __builtin_amdgcn_sched_barrier(0);
         mfma_half(a0, b0, 0);
         lds_frag(a1, b1, cur, 12);
@@ -236,6 +240,7 @@ __global__ __launch_bounds__(512) void sigma_acq_f32_kernel(
         __builtin_amdgcn_sched_barrier(0);
         mfma_half(a1, b1, NI / 2);
         __builtin_amdgcn_sched_barrier(0);
+        if (do_stage && wq != 0) stage_adv();
         cur = nxt;
     };
     for (int jb = 0; jb < nJ; ++jb) {

@@ -196,7 +196,11 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own share of tile t+1 has landed
             __builtin_amdgcn_s_barrier();
         }
-        if (pj < nJ && VARIANT != 1 && VARIANT != 4) stage_next();  // tile t+2 into the stage tile t-1 occupied
+        // tile t+2 goes into the stage tile t-1 occupied (free since this barrier).  Issuing the six DMAs keeps a
+        // wave from feeding the matrix pipe for a few hundred cycles and the two waves of a SIMD leave the
+        // barrier together: column group 0 issues here, column group 1 at the end of the tile.
+        const bool do_stage = pj < nJ && VARIANT != 1 && VARIANT != 4;
+        if (do_stage && wq == 0) stage_next();
         __builtin_amdgcn_sched_barrier(0);
         mfma8(a0, b0, 0);
         lds_frag(a1, b1, cur, 12);
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         __builtin_amdgcn_sched_barrier(0);
         mfma8(a1, b1, 2);
         __builtin_amdgcn_sched_barrier(0);
+        if (do_stage && wq != 0) stage_next();
         cur = nxt;
     };
     for (int jb = 0; jb < nJ; ++jb) {
