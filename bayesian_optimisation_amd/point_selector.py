@@ -205,6 +205,26 @@ class PointSelector:
             raise RuntimeError("call update_surrogate() first")
         return self._finish(("lcb", float(explore), 0.0), "lcb", explore=float(explore))
 
+    def q_expected_improvement(self, n_samples=512, seed=7, xi=0.0):
+        """Not in the reference: q = 8 Monte-Carlo Expected Improvement.  The candidates are grouped
+        consecutively (row-major order of `predicted_pts`) into batches of 8; returns the (8, ndim) multi-indices
+        of the first batch with the largest qEI, and leaves the per-batch values in `acq_func_eval` (1-D).
+        Fixed base samples: default_rng(seed).standard_normal((n_samples, 8)).  Single GPU."""
+        if self._cached is None:
+            raise RuntimeError("call update_surrogate() first")
+        fd = [int(v) for v in self.feature_domain]
+        M = int(np.prod(fd))
+        if M % 8:
+            raise ValueError("q_expected_improvement needs a candidate count that is a multiple of 8")
+        Z = np.random.default_rng(seed).standard_normal((int(n_samples), 8))
+        f_best = float(np.min(np.asarray(self.measured_vals, dtype=np.float64)))
+        res = self._gp.score_qei(np.asarray(self.predicted_pts, dtype=np.float64), Z, f_best, xi=float(xi), dense=True)
+        self.acq_func_eval = res.acq.cpu().numpy()
+        if res.nan_count > 0 or res.best_idx >= M // 8:
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0 (acquisition contains NaN)")
+        flat = res.best_idx * 8 + np.arange(8)
+        return np.stack(np.unravel_index(flat, fd), axis=1).astype(np.int64)
+
     def expected_improvement(self, xi=0.0):
         """Not in the reference (docs/README.md:363-365 'future work'): EI for minimisation,
         f_best = min(measured_vals)."""

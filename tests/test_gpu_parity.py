@@ -357,3 +357,78 @@ def test_unsupported_feature_count_raises():
     X, y, Xs, ls = make_problem(10, 20, 17)
     with pytest.raises(ValueError):
         DeviceGP().factorise(X, y, ls)
+
+
+# ----------------------------------------------------------------------------------------------
+# N > 1 end to end on one GPU: two gloo ranks share cuda:0, each scores its contiguous shard through the
+# real kernels; the drop-in class must return exactly what a single process returns.
+# ----------------------------------------------------------------------------------------------
+def _sharded_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, y, Xs, ls = make_problem(48, 2500, 2)
+        ps = PointSelector(device="cuda:0")
+        ps.measured_pts, ps.measured_vals = X, y
+        ps.feature_domain, ps.predicted_pts = [50, 50], Xs
+        ps.set_kernel_params(ls)
+        ps.update_surrogate()
+        idx = ps.lower_confidence_bound()
+        idx2 = ps.lower_confidence_bound(explore=1.5)
+        q.put((rank, idx.tolist(), idx2.tolist(), ps.mean_func.copy(), ps.cov_func.copy(), ps.acq_func_eval.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dropin_sharded_over_two_ranks_matches_single_process():
+    import socket
+
+    import torch.multiprocessing as mp
+
+    X, y, Xs, ls = make_problem(48, 2500, 2)
+    ps = PointSelector()
+    ps.measured_pts, ps.measured_vals = X, y
+    ps.feature_domain, ps.predicted_pts = [50, 50], Xs
+    ps.set_kernel_params(ls)
+    ps.update_surrogate()
+    ref_idx = ps.lower_confidence_bound().tolist()
+    ref_mu, ref_sd = ps.mean_func.copy(), ps.cov_func.copy()
+    ref_idx2 = ps.lower_confidence_bound(explore=1.5).tolist()
+    ref_acq2 = ps.acq_func_eval.copy()
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, idx, idx2, mu, sd, acq2 in res:
+        assert idx == ref_idx and idx2 == ref_idx2
+        assert np.array_equal(mu, ref_mu) and np.array_equal(sd, ref_sd) and np.array_equal(acq2, ref_acq2)
+
+
+def test_dropin_q_expected_improvement():
+    X, y, Xs, ls = make_problem(30, 1600, 2)
+    ps = PointSelector()
+    ps.measured_pts, ps.measured_vals = X, y
+    ps.feature_domain, ps.predicted_pts = [40, 40], Xs
+    ps.set_kernel_params(ls)
+    ps.update_surrogate()
+    pts = ps.q_expected_improvement(n_samples=256, seed=7)
+    ref = O.qei_mc(X, y, Xs, ls, O.qei_base_samples(256, 8, 7), float(np.min(y)))
+    assert pts.shape == (8, 2) and pts.dtype == np.int64
+    np.testing.assert_allclose(ps.acq_func_eval, ref, rtol=0, atol=1e-9)
+    b = int(np.flatnonzero(ps.acq_func_eval == ps.acq_func_eval.max())[0])
+    assert np.array_equal(np.ravel_multi_index(tuple(pts.T), (40, 40)), b * 8 + np.arange(8))
