@@ -52,10 +52,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int
     // B (no-trans) tile = 16 k-rows x 64 cols: thread -> k-row tid/16, 4 doubles at col (tid%16)*4
     const int bk = tid >> 4, bn = (tid & 15) * 4;
 
-    for (int64_t k0 = 0; k0 < K; k0 += BK) {
+    // register prefetch: the global loads of k tile t+1 are in flight while tile t is multiplied (the panel
+    // products of the factorisation have K = 64: without this every one of their four k tiles exposes a full
+    // global-memory round trip)
+    d2_t a0, a1, b0, b1;
+    auto gload = [&](int64_t k0) {
         const d2_t *ap = reinterpret_cast<const d2_t *>(A + (int64_t)ar * lda + k0 + ak);
-        d2_t a0 = ap[0], a1 = ap[1];
-        d2_t b0, b1;
+        a0 = ap[0]; a1 = ap[1];
         if (TRANSB) {
             const d2_t *bp = reinterpret_cast<const d2_t *>(B + (int64_t)ar * ldb + k0 + ak);
             b0 = bp[0]; b1 = bp[1];
@@ -63,6 +66,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int
             const d2_t *bp = reinterpret_cast<const d2_t *>(B + (k0 + bk) * ldb + bn);
             b0 = bp[0]; b1 = bp[1];
         }
+    };
+    gload(0);
+    for (int64_t k0 = 0; k0 < K; k0 += BK) {
         __syncthreads();  // previous tile fully consumed
         As[ar * LDA_S + ak + 0] = a0.x; As[ar * LDA_S + ak + 1] = a0.y;
         As[ar * LDA_S + ak + 2] = a1.x; As[ar * LDA_S + ak + 3] = a1.y;
@@ -74,6 +80,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int
             *reinterpret_cast<d2_t *>(&Bs[bk * LDB_S + bn + 2]) = b1;
         }
         __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             double af[2], bf[2];
