@@ -163,6 +163,8 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         constexpr bool FULL = decltype(full_tag)::value;
         if (VARIANT == 6 && vbuf && tid == 0) {  // diagnostic: cycle stamp per tile (timing build only)
             vbuf[(int64_t)blockIdx.x * 1024 + dbg_it] = (double)__builtin_amdgcn_s_memtime();
+            if (dbg_it == 0 || (jb == nJ - 1 && kt == nJ * (BN / BK) - 1))  // 100 MHz wall clock at both ends
+                vbuf[(int64_t)blockIdx.x * 1024 + (dbg_it == 0 ? 1000 : 1001)] = (double)__builtin_amdgcn_s_memrealtime();
             ++dbg_it;
         }
         const int nxt = (cur == 2) ? 0 : cur + 1;

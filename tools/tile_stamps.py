@@ -18,13 +18,17 @@ al = lambda v: (v + 255) // 256 * 256
 off = 0                                                         # stamps land in chunk buffer 0 (free after chunk 0)
 w = gp._work_post
 nJ = Np // 128
-T = 8 * nJ * (nJ + 1) // 2
-st = w[off // 8: off // 8 + 512 * 1024].cpu().numpy().reshape(512, 1024)[:, :T]
+T = min(8 * nJ * (nJ + 1) // 2, 1000)
+raw = w[off // 8: off // 8 + 512 * 1024].cpu().numpy().reshape(512, 1024)
+st = raw[:, :T]
+Tall = 8 * nJ * (nJ + 1) // 2
+clk = ((raw[:256, T - 1] - raw[:256, 0]) / (raw[:256, 1001] - raw[:256, 1000]) * 100e6) if Tall <= 1000 else np.array([np.nan])
+print(f"shader clock during the kernel (s_memtime / s_memrealtime): median {np.median(clk)/1e9:.3f} GHz")
 d = np.diff(st, axis=1)                                          # per-tile durations, memtime ticks
 med = np.median(d[:256], axis=0)
-tiles = [(jb, kt) for jb in range(nJ) for kt in range(8 * (jb + 1))]
+tiles = [(jb, kt) for jb in range(nJ) for kt in range(8 * (jb + 1))][:T]
 print("ticks per tile (median over the first 256 workgroups); tick = 10 ns @100 MHz")
-for jb in range(nJ):
+for jb in range(min(nJ, 4)):
     row = [med[i] for i, (j, k) in enumerate(tiles[:-1]) if j == jb]
     print(f"jb={jb}:", " ".join(f"{v:5.0f}" for v in row))
 print("total ticks per workgroup:", np.median(st[:256, -1] - st[:256, 0]))
