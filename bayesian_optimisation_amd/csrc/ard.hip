@@ -81,7 +81,42 @@ __global__ __launch_bounds__(256) void nlml_grid_kernel(const double *__restrict
     }
 }
 
+// One grid cell from an existing factorisation (any N): log det K = -2 sum log U_ii (U = L^-T), y^T K^-1 y = y . alpha.
+__global__ __launch_bounds__(256) void nlml_cell_kernel(const double *__restrict__ U, const double *__restrict__ alpha,
+                                                        const double *__restrict__ y, int64_t N, int64_t Np,
+                                                        const int32_t *__restrict__ info, float *__restrict__ out) {
+    __shared__ double s_ld[256], s_q[256];
+    const int tid = threadIdx.x;
+    double ld = 0.0, q = 0.0;
+    for (int64_t i = tid; i < N; i += 256) {
+        ld -= log(U[i * Np + i]);
+        q = fma(y[i], alpha[i], q);
+    }
+    s_ld[tid] = ld;
+    s_q[tid] = q;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) { s_ld[tid] += s_ld[tid + off]; s_q[tid] += s_q[tid + off]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double logdet = 2.0 * s_ld[0];
+        const double logdet_ref = log(exp(logdet));  // the reference takes log of a det that under/overflows
+        double nlml = 0.5 * (s_q[0] + logdet_ref + (double)N * 1.8378770664093453);
+        if (*info != 0) nlml = __builtin_nan("");   // not positive definite: the reference's log(det < 0) is NaN
+        *out = (float)nlml;
+    }
+}
+
 }  // namespace
+
+extern "C" int gpbo_nlml_cell_f64(const double *U, const double *alpha, const double *y, int64_t N, int64_t Np,
+                                  const int32_t *info, float *out, void *stream) {
+    if (!U || !alpha || !y || !info || !out || N < 1 || Np < N) return GPBO_ERR_ARG;
+    hipLaunchKernelGGL(nlml_cell_kernel, dim3(1), dim3(256), 0, gpbo_stream(stream), U, alpha, y, N, Np, info, out);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
 
 extern "C" int gpbo_nlml_grid_max_n(void) { return ARD_MAX_N; }
 

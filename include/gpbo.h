@@ -167,6 +167,11 @@ int gpbo_nlml_grid_max_n(void);
 int gpbo_nlml_grid_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells, int64_t G,
                        double jitter, float *out, void *stream);
 
+/* One cell of the same grid for any N, from a factorisation made with (jitter1, jitter2) = (1e-4, 0):
+ * log det K = -2 sum log U_ii, y^T K^-1 y = y . alpha; NaN when info != 0 (the reference's log of a negative det). */
+int gpbo_nlml_cell_f64(const double *U, const double *alpha, const double *y, int64_t N, int64_t Np,
+                       const int32_t *info, float *out, void *stream);
+
 /* Strided-batched fp64 MFMA GEMM used by the factorisation (exported for tests):
  * C_b = alpha * A_b * op(B_b) + beta * C_b, row-major, M and N multiples of 64, K a multiple of 16;
  * transB = 0: B is [K x N]; transB = 1: B is [N x K].  lower_only = 1 skips 64x64 tiles strictly above

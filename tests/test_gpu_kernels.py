@@ -200,3 +200,20 @@ def test_nlml_grid_det_underflow_like_reference(env):
             assert abs(out[k] - r) <= 1e-5 * abs(r) + 1e-3
         else:
             assert out[k] == r or (np.isnan(r) and np.isnan(out[k]))
+
+
+def test_nlml_grid_large_n_slow_path(env):
+    """N > 128: one full factorisation per cell; same float32 values / -inf pattern as the reference's formula."""
+    from bayesian_optimisation_amd import DeviceGP
+
+    X, y, _, _ = make_problem(150, 8, 2)
+    a1, a2 = np.array([0.02, 0.3, 4.0]), np.array([0.05, 0.5])
+    cells = np.stack(np.meshgrid(a1, a2, indexing="ij"), -1).reshape(-1, 2)
+    ref = O.nlml_grid(X, y, [a1, a2]).ravel()
+    out = DeviceGP().nlml_grid(X, y, cells)
+    assert out.dtype == np.float32 and out.shape == ref.shape
+    for o, r in zip(out, ref):
+        if np.isfinite(r):
+            assert abs(o - r) <= 1e-5 * abs(r) + 1e-3
+        else:
+            assert (np.isnan(r) and np.isnan(o)) or o == r
