@@ -14,7 +14,8 @@ Differences from the reference, all deliberate:
     is materialised only when M <= COV_PRED_MAX_M; `cov_meas_pred` (:81) only when M*N is small.
   * Failures raise instead of returning garbage: numpy.linalg.LinAlgError when K is not positive
     definite, IndexError when the acquisition contains NaN (the reference's own failure at :207).
-  * Extra, not in the reference: `expected_improvement(xi)`, `kernel_params` may be preset (then no
+  * Extra, not in the reference: `precision="fp32"` (fp64 factorisation, fp32 scoring), `expected_improvement(xi)`,
+    `q_expected_improvement()`, `kernel_params` may be preset (then no
     ARD search runs), optional multi-GPU candidate sharding when torch.distributed is initialised.
 There is no CPU implementation behind this class.
 """
@@ -41,7 +42,7 @@ def _plot_hooks():
 
 
 class PointSelector:
-    def __init__(self, device=None, verbose: bool = False, shard_candidates: bool = True):
+    def __init__(self, device=None, verbose: bool = False, shard_candidates: bool = True, precision: str = "fp64"):
         # attribute protocol of point_selector.py:15-40
         self.feature_domain = None
         self.predicted_pts = None
@@ -64,6 +65,9 @@ class PointSelector:
         self._device = device
         self._verbose = verbose
         self._shard = shard_candidates
+        if precision not in ("fp64", "fp32"):
+            raise ValueError("precision must be 'fp64' (reference arithmetic) or 'fp32' (fp64 factorisation, fp32 scoring)")
+        self._precision = precision
         self._gp = None
         self._mu_dev = self._sigma_dev = None
         self._cached = None  # (kind, p0, p1) -> (acq ndarray, flat index)
@@ -118,7 +122,11 @@ class PointSelector:
         diag_add = JITTER_KERNEL if Xs.shape == X.shape else 0.0          # :173 shape-coincidence quirk
         world, rank = self._world()
         lo, hi = D.shard_bounds(M, world, rank)
-        res = gp.score(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
+        if self._precision == "fp32":   # BASELINE config 4's mode: fp32 K*/mean/variance on the fp32 matrix cores
+            res = gp.score_f32(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
+            res.mu, res.sigma, res.acq = res.mu.double(), res.sigma.double(), res.acq.double()
+        else:
+            res = gp.score(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
         self._mu_dev, self._sigma_dev = res.mu, res.sigma
         mu, sigma, acq = res.mu.cpu().numpy(), res.sigma.cpu().numpy(), res.acq.cpu().numpy()
         best = D.allreduce_argmax(res.best_val, res.best_idx, res.nan_count)

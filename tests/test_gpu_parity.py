@@ -432,3 +432,19 @@ def test_dropin_q_expected_improvement():
     np.testing.assert_allclose(ps.acq_func_eval, ref, rtol=0, atol=1e-9)
     b = int(np.flatnonzero(ps.acq_func_eval == ps.acq_func_eval.max())[0])
     assert np.array_equal(np.ravel_multi_index(tuple(pts.T), (40, 40)), b * 8 + np.arange(8))
+
+
+def test_dropin_fp32_precision_mode(golden):
+    g = golden("g6_d16_n256_m2048")
+    X, y, Xs, ls = make_problem(int(g["N"]), int(g["M"]), int(g["d"]))
+    ps = PointSelector(precision="fp32")
+    ps.measured_pts, ps.measured_vals = X, y
+    ps.feature_domain, ps.predicted_pts = [int(g["M"])], Xs
+    ps.set_kernel_params(ls)
+    ps.update_surrogate()
+    idx = ps.lower_confidence_bound()
+    assert ps.mean_func.dtype == np.float64
+    assert np.max(np.abs(ps.mean_func - g["mean_func"])) <= 5e-3 * max(1.0, np.abs(y).max())
+    assert np.max(np.abs(ps.cov_func - g["cov_func"])) <= 5e-3
+    # the fp32 winner is within the fp32 error of the reference's maximum
+    assert g["acq_func_eval"][idx[0]] >= g["acq_func_eval"].max() - 2e-2 * max(1.0, np.abs(y).max())
