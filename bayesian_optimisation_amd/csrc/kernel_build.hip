@@ -91,7 +91,8 @@ __device__ __forceinline__ double exp_neg(double t, const double *tab /* LDS, 32
     const double s = __hiloint2double(__double2hiint(v) + ((ni >> 5) << 20), __double2loint(v));
     // t <= 708: the result is a normal number.  Above, the reference's np.exp returns values below DBL_MIN
     // (denormals, then 0); they are flushed to 0 here - invisible at every tolerance of the path.
-    return (t <= 708.0) ? s : ((t > 708.0) ? 0.0 : t);  // last arm: NaN propagates
+    // (a NaN argument also lands in the 0 arm: callers poison their outputs when an input coordinate is NaN)
+    return (t <= 708.0) ? s : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -121,6 +122,12 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
     }
     __syncthreads();
     double mua = 0.0, mub = 0.0;
+    bool nan_a = false, nan_b = false;  // NaN candidate coordinates: the reference's k is NaN, hence mu and the acquisition
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        nan_a = nan_a || (xa[k] != xa[k]);
+        nan_b = nan_b || (xb[k] != xb[k]);
+    }
     double *out = KsT + (int64_t)n0 * ldk + c0;
     int nend = n0 + KS_SLICE;
     if (nend > N) nend = N;  // observations beyond N are padding: exact zeros, written below
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
         *reinterpret_cast<d2_t *>(out) = zero;
         out += ldk;
     }
-    d2_t m = {mua, mub};
+    d2_t m = {nan_a ? __builtin_nan("") : mua, nan_b ? __builtin_nan("") : mub};
     *reinterpret_cast<d2_t *>(mu_part + (int64_t)blockIdx.y * ldk + c0) = m;
 }
 

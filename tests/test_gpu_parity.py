@@ -448,3 +448,11 @@ def test_dropin_fp32_precision_mode(golden):
     assert np.max(np.abs(ps.cov_func - g["cov_func"])) <= 5e-3
     # the fp32 winner is within the fp32 error of the reference's maximum
     assert g["acq_func_eval"][idx[0]] >= g["acq_func_eval"].max() - 2e-2 * max(1.0, np.abs(y).max())
+
+
+def test_nan_candidate_coordinate_is_counted():
+    X, y, Xs, ls = make_problem(20, 600, 3)
+    Xs = Xs.copy()
+    Xs[17, 1] = np.nan
+    r = DeviceGP(chunk=512).factorise(X, y, ls).score(Xs, dense=True)
+    assert r.nan_count == 1 and np.isnan(r.acq.cpu().numpy()[17]) and r.best_idx != 17
