@@ -217,7 +217,8 @@ class PointSelector:
         """Not in the reference: q = 8 Monte-Carlo Expected Improvement.  The candidates are grouped
         consecutively (row-major order of `predicted_pts`) into batches of 8; returns the (8, ndim) multi-indices
         of the first batch with the largest qEI, and leaves the per-batch values in `acq_func_eval` (1-D).
-        Fixed base samples: default_rng(seed).standard_normal((n_samples, 8)).  Single GPU."""
+        Fixed base samples: default_rng(seed).standard_normal((n_samples, 8)).  Batches are sharded over the
+        ranks like single candidates are."""
         if self._cached is None:
             raise RuntimeError("call update_surrogate() first")
         fd = [int(v) for v in self.feature_domain]
@@ -226,10 +227,18 @@ class PointSelector:
             raise ValueError("q_expected_improvement needs a candidate count that is a multiple of 8")
         Z = np.random.default_rng(seed).standard_normal((int(n_samples), 8))
         f_best = float(np.min(np.asarray(self.measured_vals, dtype=np.float64)))
-        res = self._gp.score_qei(np.asarray(self.predicted_pts, dtype=np.float64), Z, f_best, xi=float(xi), dense=True)
-        self.acq_func_eval = res.acq.cpu().numpy()
-        if res.nan_count > 0 or res.best_idx >= M // 8:
+        Xs = np.asarray(self.predicted_pts, dtype=np.float64)
+        world, rank = self._world()
+        blo, bhi = D.shard_bounds(M // 8, world, rank)          # whole batches per rank, contiguous
+        res = self._gp.score_qei(Xs[blo * 8: bhi * 8], Z, f_best, xi=float(xi), dense=True, batch_offset=blo)
+        qei = res.acq.cpu().numpy()
+        best_val, best_idx, nan_count = D.allreduce_argmax(res.best_val, res.best_idx, res.nan_count)
+        if world > 1:
+            qei = self._gather(qei, M // 8, world)
+        self.acq_func_eval = qei
+        if nan_count > 0 or best_idx >= M // 8:
             raise IndexError("index 0 is out of bounds for axis 0 with size 0 (acquisition contains NaN)")
+        res.best_idx = best_idx
         flat = res.best_idx * 8 + np.arange(8)
         return np.stack(np.unravel_index(flat, fd), axis=1).astype(np.int64)
 

@@ -372,15 +372,18 @@ def _sharded_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        X, y, Xs, ls = make_problem(48, 2500, 2)
+        X, y, Xs, ls = make_problem(48, 2400, 2)
         ps = PointSelector(device="cuda:0")
         ps.measured_pts, ps.measured_vals = X, y
-        ps.feature_domain, ps.predicted_pts = [50, 50], Xs
+        ps.feature_domain, ps.predicted_pts = [50, 48], Xs
         ps.set_kernel_params(ls)
         ps.update_surrogate()
         idx = ps.lower_confidence_bound()
         idx2 = ps.lower_confidence_bound(explore=1.5)
-        q.put((rank, idx.tolist(), idx2.tolist(), ps.mean_func.copy(), ps.cov_func.copy(), ps.acq_func_eval.copy()))
+        acq2 = ps.acq_func_eval.copy()
+        qpts = ps.q_expected_improvement(n_samples=64, seed=7)
+        q.put((rank, idx.tolist(), idx2.tolist(), ps.mean_func.copy(), ps.cov_func.copy(), acq2, qpts.tolist(),
+               ps.acq_func_eval.copy()))
     finally:
         dist.destroy_process_group()
 
@@ -390,16 +393,18 @@ def test_dropin_sharded_over_two_ranks_matches_single_process():
 
     import torch.multiprocessing as mp
 
-    X, y, Xs, ls = make_problem(48, 2500, 2)
+    X, y, Xs, ls = make_problem(48, 2400, 2)
     ps = PointSelector()
     ps.measured_pts, ps.measured_vals = X, y
-    ps.feature_domain, ps.predicted_pts = [50, 50], Xs
+    ps.feature_domain, ps.predicted_pts = [50, 48], Xs
     ps.set_kernel_params(ls)
     ps.update_surrogate()
     ref_idx = ps.lower_confidence_bound().tolist()
     ref_mu, ref_sd = ps.mean_func.copy(), ps.cov_func.copy()
     ref_idx2 = ps.lower_confidence_bound(explore=1.5).tolist()
     ref_acq2 = ps.acq_func_eval.copy()
+    ref_qpts = ps.q_expected_improvement(n_samples=64, seed=7).tolist()
+    ref_qei = ps.acq_func_eval.copy()
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -414,9 +419,10 @@ def test_dropin_sharded_over_two_ranks_matches_single_process():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    for rank, idx, idx2, mu, sd, acq2 in res:
+    for rank, idx, idx2, mu, sd, acq2, qpts, qei in res:
         assert idx == ref_idx and idx2 == ref_idx2
         assert np.array_equal(mu, ref_mu) and np.array_equal(sd, ref_sd) and np.array_equal(acq2, ref_acq2)
+        assert qpts == ref_qpts and np.array_equal(qei, ref_qei)
 
 
 def test_dropin_q_expected_improvement():
