@@ -27,11 +27,17 @@ extern "C" int gpbo_profile_create(int32_t capacity, gpbo_profile **out) {
     p->begin = new void *[capacity];
     p->end = new void *[capacity];
     p->cands = new int64_t[capacity];
+    p->kbegin = new void *[capacity];
+    p->kend = new void *[capacity];
     for (int i = 0; i < capacity; ++i) {
-        hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return GPBO_ERR_LAUNCH;
+        hipEvent_t a, b, c, d;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess || hipEventCreate(&c) != hipSuccess ||
+            hipEventCreate(&d) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
         p->begin[i] = a;
         p->end[i] = b;
+        p->kbegin[i] = c;
+        p->kend[i] = d;
         p->cands[i] = 0;
     }
     *out = p;
@@ -60,14 +66,36 @@ extern "C" int gpbo_profile_read(gpbo_profile *p, double *total_ms, int64_t *lau
     return GPBO_OK;
 }
 
+extern "C" int gpbo_profile_read_kstar(gpbo_profile *p, double *total_ms, int64_t *launches, int64_t *cands) {
+    if (!p || !total_ms || !launches || !cands) return GPBO_ERR_ARG;
+    double sum = 0.0;
+    int64_t nc = 0;
+    for (int i = 0; i < p->count; ++i) {
+        hipEvent_t a = reinterpret_cast<hipEvent_t>(p->kbegin[i]), b = reinterpret_cast<hipEvent_t>(p->kend[i]);
+        if (hipEventSynchronize(b) != hipSuccess) return GPBO_ERR_LAUNCH;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return GPBO_ERR_LAUNCH;
+        sum += ms;
+        nc += p->cands[i];
+    }
+    *total_ms = sum;
+    *launches = p->count;
+    *cands = nc;
+    return GPBO_OK;
+}
+
 extern "C" void gpbo_profile_destroy(gpbo_profile *p) {
     if (!p) return;
     for (int i = 0; i < p->capacity; ++i) {
         (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(p->begin[i]));
         (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(p->end[i]));
+        (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(p->kbegin[i]));
+        (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(p->kend[i]));
     }
     delete[] p->begin;
     delete[] p->end;
     delete[] p->cands;
+    delete[] p->kbegin;
+    delete[] p->kend;
     delete p;
 }

@@ -639,9 +639,15 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
         const int64_t s = c * chunk;
         const int64_t Mc = (M - s < chunk) ? (M - s) : chunk;
         const int b = (int)(c & 1);
+        // (K(X*,X) launches are timed only in the plain in-order mode: chunk c's events share slot prof->count)
+        const bool krec = prof && !hp && prof->count < prof->capacity;
+        if (krec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->kbegin[prof->count]), ks) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
         int rc = gpbo_kstar_mu_f64(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT[b], chunk,
                                    mu_part[b], ks);
         if (rc != GPBO_OK) return rc;
+        if (krec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->kend[prof->count]), ks) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
         if (hp && hipEventRecord(hp->kdone[b], ks) != hipSuccess) return GPBO_ERR_LAUNCH;
         return GPBO_OK;
     };

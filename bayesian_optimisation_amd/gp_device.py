@@ -73,6 +73,13 @@ class DeviceGP:
         _lib.check(self.lib.gpbo_profile_read(self._profile, C.byref(ms), C.byref(n), C.byref(c)), "gpbo_profile_read")
         return ms.value, n.value, c.value
 
+    def read_profile_kstar(self):
+        """(total ms, launches, candidates) of the K(X*,X) launches recorded beside the variance launches."""
+        ms, n, c = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(self.lib.gpbo_profile_read_kstar(self._profile, C.byref(ms), C.byref(n), C.byref(c)),
+                   "gpbo_profile_read_kstar")
+        return ms.value, n.value, c.value
+
     # -- helpers -------------------------------------------------------------------------------
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)

@@ -167,6 +167,19 @@ def main():
                     kernel="sigma_acq_f32_kernel" if f32 else "sigma_acq_kernel", launches=int(k_launches), avg_launch_ms=round(k_avg_ms, 4),
                     flop_per_candidate=flop_per_cand, candidates_per_launch=cand_per_launch)
 
+    # second kernel of the path: K(X*,X) build (HBM-write bound when materialised): algorithmic bytes per candidate
+    # = N*w written + d*w read (w = 8 for fp64), DESIGN.md section 4
+    kstar_roofline = None
+    if not f32:
+        ks_ms, ks_launches, ks_cands = gp.read_profile_kstar()
+        if ks_launches:
+            ks_avg = ks_ms / ks_launches
+            bytes_per_cand = 8.0 * (N + d)
+            gbs = bytes_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e9
+            kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=8000.0, unit="GB/s",
+                                  frac=round(gbs / 8000.0, 4), kernel="kstar_mu_kernel", launches=int(ks_launches),
+                                  avg_launch_ms=round(ks_avg, 4), bytes_per_candidate=bytes_per_cand)
+
     # time of the scoring part alone (factorisation excluded), for the record
     fence()
     t1 = time.perf_counter()
@@ -191,7 +204,7 @@ def main():
                        "candidates_total": M_total, "parallelism": f"candidate-sharded x{world}"},
             "ms_per_step_scoring_only": ms_score,
             "value_excl_factorisation": (hi - lo) * world / (ms_score * 1e-3),
-            "argmax_index": best[1], "roofline": roofline,
+            "argmax_index": best[1], "roofline": roofline, "kstar_roofline": kstar_roofline,
         }
         if world == 1 and not args.no_cpu_baseline and not f32:
             ns = min(args.cpu_sample, hi - lo)

@@ -53,13 +53,16 @@ typedef struct gpbo_result {
  * on the caller's stream by gpbo_posterior_acq_f64 when a profile is passed.  Host-side object. */
 typedef struct gpbo_profile {
     int32_t capacity, count;
-    void **begin, **end; /* hipEvent_t */
-    int64_t *cands;      /* candidates processed by each recorded launch */
+    void **begin, **end;   /* hipEvent_t pairs around the variance/acquisition launches */
+    int64_t *cands;        /* candidates processed by each recorded launch */
+    void **kbegin, **kend; /* hipEvent_t pairs around the K(X*,X) launches of the same chunks */
 } gpbo_profile;
 int gpbo_profile_create(int32_t capacity, gpbo_profile **out);
 void gpbo_profile_reset(gpbo_profile *p);
 /* Waits for the recorded events; sums elapsed ms, launches and candidates over all recorded launches. */
 int gpbo_profile_read(gpbo_profile *p, double *total_ms_host, int64_t *launches_host, int64_t *cands_host);
+/* Same for the K(X*,X) launches (fp64 path). */
+int gpbo_profile_read_kstar(gpbo_profile *p, double *total_ms_host, int64_t *launches_host, int64_t *cands_host);
 void gpbo_profile_destroy(gpbo_profile *p);
 
 int gpbo_version(void);
