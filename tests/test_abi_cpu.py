@@ -74,3 +74,11 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".sh")):
                 txt = open(os.path.join(root, f)).read()
                 assert "oracle" not in txt.replace("no CPU", ""), f"{f} mentions the oracle"
+
+
+def test_python_constants_match_the_header():
+    src = open(os.path.join(REPO, "include", "gpbo.h")).read()
+    defs = {k: int(v) for k, v in re.findall(r"#define\s+(GPBO_[A-Z_]+)\s+\(?(-?\d+)\)?", src)}
+    assert defs["GPBO_NPAD"] == _lib.NPAD and defs["GPBO_CHUNK_GRANULE"] == _lib.CHUNK_GRANULE
+    assert defs["GPBO_MAX_D"] == _lib.MAX_D and defs["GPBO_ACQ_LCB"] == _lib.ACQ_LCB and defs["GPBO_ACQ_EI"] == _lib.ACQ_EI
+    assert defs["GPBO_VERSION"] == _lib.load().gpbo_version()
