@@ -138,23 +138,24 @@ __global__ __launch_bounds__(256) void transpose_upper_kernel(const double *__re
     }
 }
 
-// tmp_i = sum_{m<=i} U[m][i] y_m   (= (L^-1 y)_i).  Block = 64 columns x 16 row groups; lanes run
-// over i (coalesced rows of U), row group g takes m = g, g+16, ...; fixed-order LDS reduction.
+// tmp_i = sum_{m<=i} U[m][i] y_m   (= (L^-1 y)_i).  Block = 16 columns (one 128-byte line per row of U) x 64 row
+// groups: lane -> column lane&15, row group 4*wave + lane>>4 takes m = rg, rg+64, ...; fixed-order LDS reduction.
+// (Np/16 workgroups: with 64 columns per workgroup a 4096-point problem kept only 64 of the 256 CUs busy.)
 __global__ __launch_bounds__(1024) void utv_kernel(const double *__restrict__ U, const double *__restrict__ y,
                                                    int64_t N, int64_t Np, double *__restrict__ tmp) {
-    __shared__ double part[16][64];
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    __shared__ double part[64][17];
+    const int lane = threadIdx.x & 63, col = lane & 15;
+    const int rg = (threadIdx.x >> 6) * 4 + (lane >> 4);
+    const int64_t i = (int64_t)blockIdx.x * 16 + col;
     double s = 0.0;
     const int64_t mend = (i < N ? i : N - 1);
-    for (int64_t m = g; m <= mend; m += 16) s = fma(U[m * Np + i], y[m], s);
-    part[g][lane] = s;
+    for (int64_t m = rg; m <= mend; m += 64) s = fma(U[m * Np + i], y[m], s);
+    part[rg][col] = s;
     __syncthreads();
-    if (g == 0) {
+    if (threadIdx.x < 16) {
         double r = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) r += part[k][lane];
-        tmp[i] = r;
+        for (int k = 0; k < 64; ++k) r += part[k][threadIdx.x];
+        tmp[(int64_t)blockIdx.x * 16 + threadIdx.x] = r;
     }
 }
 
@@ -248,7 +249,7 @@ extern "C" int gpbo_alpha_f64(const double *U, const double *y, int64_t N, int64
                               void *stream) {
     if (!U || !y || !tmp || !alpha || N < 1 || Np < N || Np % NB) return GPBO_ERR_ARG;
     hipStream_t st = gpbo_stream(stream);
-    hipLaunchKernelGGL(utv_kernel, dim3((unsigned)(Np / 64)), dim3(1024), 0, st, U, y, N, Np, tmp);
+    hipLaunchKernelGGL(utv_kernel, dim3((unsigned)(Np / 16)), dim3(1024), 0, st, U, y, N, Np, tmp);
     hipLaunchKernelGGL(uv_kernel, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, st, U, tmp, N, Np, alpha);
     GPBO_CHECK_LAUNCH();
     return GPBO_OK;

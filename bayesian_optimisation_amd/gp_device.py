@@ -55,6 +55,8 @@ class DeviceGP:
         self.chunk = int(chunk)
         self.N = self.Np = self.d = 0
         self._work_post = None
+        self._work_fact = None
+        self.K = self.U = self.alpha = None
         self._result = torch.zeros(4, dtype=torch.int64, device=self.device)
         self._profile = C.c_void_p(0)
 
@@ -116,13 +118,21 @@ class DeviceGP:
         with torch.cuda.device(self.device):
             self.X, self.y, self.ls_h = Xd, yd, ls_h
             self.N, self.Np, self.d = N, Np, d
-            self.K = torch.empty((Np, Np), dtype=torch.float64, device=self.device)
-            self.U = torch.empty((Np, Np), dtype=torch.float64, device=self.device)
-            self.alpha = torch.empty(Np, dtype=torch.float64, device=self.device)
-            self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.jitter1, self.jitter2 = float(jitter1), float(jitter2)
+            self._owns_xy = False
+            if getattr(self, "K", None) is None or self.K.shape[0] != Np or self.U.shape[0] != Np:
+                # the factor buffers (and the workspace) are kept from step to step: a BO loop refactorises
+                # at the same padded size many times, and fresh 100-MB allocations cost more than the kernels
+                self.K = torch.empty((Np, Np), dtype=torch.float64, device=self.device)
+                self.U = torch.empty((Np, Np), dtype=torch.float64, device=self.device)
+                self.alpha = torch.empty(Np, dtype=torch.float64, device=self.device)
+                self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
+                self._work_fact = None
             self.U32 = None
             wbytes = int(self.lib.gpbo_factorise_workspace_bytes(Np))
-            work = torch.empty(wbytes // 8, dtype=torch.float64, device=self.device)
+            if self._work_fact is None or self._work_fact.numel() * 8 < wbytes:
+                self._work_fact = torch.empty(wbytes // 8, dtype=torch.float64, device=self.device)
+            work = self._work_fact
             st = self.lib.gpbo_factorise_f64(self._ptr(Xd), self._ptr(yd), N, d, ls_h.ctypes.data_as(C.c_void_p),
                                              jitter1, jitter2, Np, self._ptr(self.K), self._ptr(self.U),
                                              self._ptr(self.alpha), self._ptr(self.info), self._ptr(work), wbytes,
@@ -134,8 +144,109 @@ class DeviceGP:
                     raise np.linalg.LinAlgError(
                         f"covariance matrix is not positive definite (pivot {info} of {N}); "
                         "the reference's np.linalg.inv would raise or return garbage here")
+        return self
+
+    # -- one more observation without refactorising ---------------------------------
+    def _grow(self, Np_new: int):
+        """Re-pad the factors into [Np_new x Np_new] buffers (identity on the new part of the diagonal)."""
+        torch = self.torch
+        Np = self.Np
+        for name in ("K", "U"):
+            old = getattr(self, name)
+            new = torch.zeros((Np_new, Np_new), dtype=torch.float64, device=self.device)
+            new[:Np, :Np] = old
+            new.diagonal()[Np:] = 1.0
+            setattr(self, name, new)
+        alpha = torch.zeros(Np_new, dtype=torch.float64, device=self.device)
+        alpha[:Np] = self.alpha
+        self.alpha = alpha
+        self.Np = Np_new
+        self._work_post = None
+
+    def append(self, x_new, y_new, check: bool = True):
+        """Add one observation to the factorised surrogate in O(N^2): column N of U, alpha recomputed.
+        The length scales and jitters stay those of the last factorise() - the caller decides when they may
+        (the reference re-tunes them every iteration, point_selector.py:60-62, and then a full factorise() is due)."""
+        torch = self.torch
+        if self.N < 1:
+            raise _lib.GpboError("append() needs a factorised surrogate")
+        xn = self._dev(x_new).reshape(-1)
+        if xn.numel() != self.d:
+            raise ValueError(f"x_new: expected {self.d} coordinates, got {xn.numel()}")
+        yn = self._dev(np.asarray([float(y_new)])) if not isinstance(y_new, torch.Tensor) else self._dev(y_new).reshape(-1)[:1]
+        with torch.cuda.device(self.device):
+            N = self.N
+            if N + 1 > self.Np:
+                self._grow(int(self.lib.gpbo_padded_n(N + 1)))
+            if not self._owns_xy or self.X.shape[0] < N + 1:
+                # private, padded copies: the caller's X / y tensors are never written to
+                Xb = torch.zeros((self.Np, self.d), dtype=torch.float64, device=self.device)
+                yb = torch.zeros(self.Np, dtype=torch.float64, device=self.device)
+                Xb[:N] = self.X[:N]
+                yb[:N] = self.y[:N]
+                self.X, self.y, self._owns_xy = Xb, yb, True
+            wbytes = int(self.lib.gpbo_append_workspace_bytes(self.Np))
+            work = torch.empty(wbytes // 8, dtype=torch.float64, device=self.device)
+            st = self.lib.gpbo_append_f64(self._ptr(self.X), self._ptr(self.y), N, self.d,
+                                          self.ls_h.ctypes.data_as(C.c_void_p), self.jitter1, self.jitter2, self.Np,
+                                          self._ptr(xn), self._ptr(yn), self._ptr(self.K), self._ptr(self.U),
+                                          self._ptr(self.alpha), self._ptr(self.info), self._ptr(work), wbytes,
+                                          self._stream())
+            _lib.check(st, "gpbo_append_f64")
+            self.U32 = None
+            if check:
+                info = int(self.info.item())  # synchronises
+                if info != 0:
+                    raise np.linalg.LinAlgError(
+                        f"appended observation makes the covariance matrix numerically singular (pivot {info}); "
+                        "call factorise() on the full data instead")
+            else:
+                torch.cuda.current_stream(self.device).synchronize()  # xn / yn / work must outlive the kernels
+            self.N = N + 1
             del work
         return self
+
+    # -- persistence across jobs: the DAG's select_parameters jobs are separate processes --------------------
+    def state_dict(self) -> dict:
+        """Host copy of everything append()/score() need (the N x N part of the factors, not the padding)."""
+        N = self.N
+        return dict(version=1, N=N, d=self.d, ls=np.array(self.ls_h), jitter1=self.jitter1, jitter2=self.jitter2,
+                    X=self.X[:N].cpu().numpy(), y=self.y[:N].cpu().numpy(), K=self.K[:N, :N].cpu().numpy(),
+                    U=self.U[:N, :N].cpu().numpy(), alpha=self.alpha[:N].cpu().numpy())
+
+    def load_state_dict(self, st: dict):
+        torch = self.torch
+        if int(st.get("version", 0)) != 1:
+            raise ValueError("unknown surrogate state version")
+        N, d = int(st["N"]), int(st["d"])
+        Np = int(self.lib.gpbo_padded_n(N))
+        with torch.cuda.device(self.device):
+            self.N, self.Np, self.d = N, Np, d
+            self.ls_h = np.ascontiguousarray(np.asarray(st["ls"], dtype=np.float64).reshape(-1))
+            self.jitter1, self.jitter2 = float(st["jitter1"]), float(st["jitter2"])
+            self.X = torch.zeros((Np, d), dtype=torch.float64, device=self.device)
+            self.y = torch.zeros(Np, dtype=torch.float64, device=self.device)
+            self.X[:N] = self._dev(st["X"])
+            self.y[:N] = self._dev(st["y"]).reshape(-1)
+            self._owns_xy = True
+            for name in ("K", "U"):
+                m = torch.zeros((Np, Np), dtype=torch.float64, device=self.device)
+                m[:N, :N] = self._dev(st[name])
+                m.diagonal()[N:] = 1.0
+                setattr(self, name, m)
+            self.alpha = torch.zeros(Np, dtype=torch.float64, device=self.device)
+            self.alpha[:N] = self._dev(st["alpha"]).reshape(-1)
+            self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.U32 = None
+            self._work_post = None
+        return self
+
+    def save_state(self, path: str):
+        np.savez(path, **self.state_dict())
+
+    def load_state(self, path: str):
+        with np.load(path) as z:
+            return self.load_state_dict({k: z[k] for k in z.files})
 
     # -- scoring ------------------------------------------------------------------------------------
     def _ensure_post_workspace(self, M):

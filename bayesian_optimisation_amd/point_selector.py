@@ -16,7 +16,9 @@ Differences from the reference, all deliberate:
     definite, IndexError when the acquisition contains NaN (the reference's own failure at :207).
   * Extra, not in the reference: `precision="fp32"` (fp64 factorisation, fp32 scoring), `expected_improvement(xi)`,
     `q_expected_improvement()`, `kernel_params` may be preset (then no
-    ARD search runs), optional multi-GPU candidate sharding when torch.distributed is initialised.
+    ARD search runs), optional multi-GPU candidate sharding when torch.distributed is initialised,
+    `incremental=True` / `state_path=...` (append new observations to the previous factorisation in O(N^2)
+    while the length scales stay the same, within one process or across jobs through a state file).
 There is no CPU implementation behind this class.
 """
 from __future__ import annotations
@@ -28,6 +30,7 @@ from .gp_device import JITTER_ASSEMBLY, JITTER_KERNEL, PRIOR_VAR, DeviceGP
 
 COV_PRED_MAX_M = 4096          # cov_pred is M x M: 128 MiB at this size
 COV_MEAS_PRED_MAX = 1 << 24    # entries of the (M, N) cross covariance kept for inspection
+MAX_APPEND_ROWS = 64           # more new rows than this: a fresh factorisation is cheaper than row-by-row appends
 
 
 def _plot_hooks():
@@ -42,7 +45,8 @@ def _plot_hooks():
 
 
 class PointSelector:
-    def __init__(self, device=None, verbose: bool = False, shard_candidates: bool = True, precision: str = "fp64"):
+    def __init__(self, device=None, verbose: bool = False, shard_candidates: bool = True, precision: str = "fp64",
+                 incremental: bool = False, state_path=None):
         # attribute protocol of point_selector.py:15-40
         self.feature_domain = None
         self.predicted_pts = None
@@ -72,6 +76,11 @@ class PointSelector:
         self._mu_dev = self._sigma_dev = None
         self._cached = None  # (kind, p0, p1) -> (acq ndarray, flat index)
         self._preset_kernel_params = False
+        # consecutive iterations differ by one observed row (select_parameters.py:163,299)
+        self._incremental = bool(incremental) or state_path is not None
+        self._state_path = state_path
+        self._inc = None               # (X, y, ls) of the factorisation held by self._gp
+        self.last_update = None        # "factorise" | "append": what the last update_surrogate() did
 
     # ------------------------------------------------------------------------------------------
     def _log(self, *a):
@@ -115,7 +124,7 @@ class PointSelector:
                 self.kernel_params = np.array([self.length_scales[len(self.length_scales) // 2]])
         ls = np.asarray(self.kernel_params, dtype=np.float64).reshape(-1)
 
-        gp.factorise(X, y, ls, JITTER_KERNEL, JITTER_ASSEMBLY, check=True)   # :79, :89 (raises LinAlgError)
+        self._factorise_or_append(gp, X, y, ls)                           # :79, :89 (raises LinAlgError)
         self.cov_meas = gp.cov_meas_host()
 
         M, N = len(Xs), len(X)
@@ -143,6 +152,41 @@ class PointSelector:
 
         self.measured_pts = self.measured_pts.tolist()                    # :101-102
         self.measured_vals = self.measured_vals.tolist()
+
+    def _factorise_or_append(self, gp, X, y, ls):
+        """Full factorisation, or - with incremental=True / a state file - O(N^2) appends when the new data are
+        the old data plus a few rows and the length scales are bit-identical to those of the held factors."""
+        import os
+
+        appended = False
+        if self._incremental:
+            if self._inc is None and self._state_path is not None and os.path.exists(self._state_path):
+                try:
+                    gp.load_state(self._state_path)
+                    self._inc = (gp.X[: gp.N].cpu().numpy(), gp.y[: gp.N].cpu().numpy(), np.array(gp.ls_h))
+                except Exception as exc:  # noqa: BLE001 - an unreadable state file only costs the shortcut
+                    self._log(f"state file {self._state_path!r} ignored: {exc}")
+                    self._inc = None
+            if self._inc is not None:
+                X0, y0, ls0 = self._inc
+                n0 = len(X0)
+                if (n0 < len(X) <= n0 + MAX_APPEND_ROWS and gp.N == n0 and X0.shape[1:] == X.shape[1:]
+                        and ls0.shape == ls.shape and np.array_equal(ls0, ls)
+                        and gp.jitter1 == JITTER_KERNEL and gp.jitter2 == JITTER_ASSEMBLY
+                        and np.array_equal(X[:n0], X0) and np.array_equal(y[:n0], y0)):
+                    try:
+                        for i in range(n0, len(X)):
+                            gp.append(X[i], y[i])
+                        appended = True
+                    except np.linalg.LinAlgError:
+                        pass  # numerically singular through the update: the full route decides (and raises if so)
+        if not appended:
+            gp.factorise(X, y, ls, JITTER_KERNEL, JITTER_ASSEMBLY, check=True)
+        self.last_update = "append" if appended else "factorise"
+        if self._incremental:
+            self._inc = (X.copy(), y.copy(), ls.copy())
+            if self._state_path is not None:
+                gp.save_state(self._state_path)
 
     @staticmethod
     def _gather(local: np.ndarray, M: int, world: int) -> np.ndarray:

@@ -99,6 +99,21 @@ int gpbo_factorise_f64(const double *X, const double *y, int64_t N, int32_t d, c
                        double jitter1, double jitter2, int64_t Np, double *Kp, double *U, double *alpha,
                        int32_t *info, void *work, int64_t work_bytes, void *stream);
 
+/* Append one observation to an existing factorisation in O(N^2) instead of refactorising (SURVEY.md §8f rank 4:
+ * consecutive BO iterations differ by one observed row, select_parameters.py:163,299, while
+ * point_selector.py:89 inverts the whole matrix again).  Valid only while the length scales and jitters are
+ * those the factors were built with.  In place, N -> N+1:
+ *   X [>= N+1 rows x d], y [>= N+1]: row N receives x_new / y_new (device pointers to d and 1 doubles);
+ *   U [Np x Np]: column N is written (U' = [U, -U l/lambda; 0, 1/lambda], l = U^T k, lambda^2 = K_NN - l.l);
+ *   alpha [Np]: recomputed as U'(U'^T y');   Kp [Np x Np] or NULL: row and column N of K.
+ * Needs N + 1 <= Np (Np a multiple of 64; the caller re-pads into larger buffers when the padding is used up:
+ * identity on the new diagonal).  info (device int32): 0, or N+1 when the new pivot is not positive - U is then
+ * unchanged, alpha is not meaningful, and the caller refactorises.  work: gpbo_append_workspace_bytes(Np). */
+int64_t gpbo_append_workspace_bytes(int64_t Np);
+int gpbo_append_f64(double *X, double *y, int64_t N, int32_t d, const double *ls_host, double jitter1,
+                    double jitter2, int64_t Np, const double *x_new, const double *y_new, double *Kp, double *U,
+                    double *alpha, int32_t *info, void *work, int64_t work_bytes, void *stream);
+
 /* Xsc[Np x d] = X / (ls sqrt 2) (rows >= N zero): the pre-scaled observations gpbo_kstar_mu_f64 reads. */
 int gpbo_scale_points_f64(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host, double *Xsc,
                           void *stream);
