@@ -48,6 +48,59 @@ def test_argument_validation_needs_no_gpu():
     assert lib.gpbo_nlml_grid_max_n() == 128
 
 
+def test_every_compute_entry_point_rejects_null_arguments():
+    """All-NULL / all-zero arguments come back as GPBO_ERR_ARG from every compute call, before any HIP call."""
+    import ctypes as C
+
+    lib = _lib.load()
+    skip = {"gpbo_version", "gpbo_nlml_grid_max_n", "gpbo_gemm_f64",  # gemm: M = 0 is a valid empty product
+            "gpbo_profile_create", "gpbo_profile_read", "gpbo_profile_read_kstar", "gpbo_profile_reset",
+            "gpbo_profile_destroy"}
+    checked = 0
+    for name, (res, args) in _lib.SIGNATURES.items():
+        if res is not C.c_int or name in skip:
+            continue
+        a = [None if t is C.c_void_p else (0.0 if t is C.c_double else 0) for t in args]
+        assert getattr(lib, name)(*a) == -1, name
+        checked += 1
+    assert checked >= 15
+
+
+def test_size_contracts_are_checked_on_the_host():
+    """Non-null pointers but sizes that break a documented contract: rejected without touching the pointers."""
+    import ctypes as C
+
+    lib = _lib.load()
+    buf = (C.c_char * 1024)()
+    p = C.c_void_p((C.addressof(buf) + 255) & ~255)  # 256-byte aligned like a device allocation; never dereferenced
+    ls = (C.c_double * 16)(*([0.5] * 16))
+    lsp = C.cast(ls, C.c_void_p)
+    # factorise: Np must be gpbo_padded_n(N); workspace must be large enough
+    assert lib.gpbo_factorise_f64(p, p, 100, 2, lsp, 1e-4, 1e-6, 256, p, p, p, p, p, 1 << 40, None) == -1
+    assert lib.gpbo_factorise_f64(p, p, 100, 2, lsp, 1e-4, 1e-6, 128, p, p, p, p, p, 8, None) == -3
+    # append: no room left in the padding; d beyond the compiled maximum; non-positive length scale
+    assert lib.gpbo_append_f64(p, p, 128, 2, lsp, 1e-4, 1e-6, 128, p, p, None, p, p, p, p, 1 << 30, None) == -1
+    assert lib.gpbo_append_f64(p, p, 10, 17, lsp, 1e-4, 1e-6, 128, p, p, None, p, p, p, p, 1 << 30, None) == -1
+    bad = (C.c_double * 2)(0.5, 0.0)
+    assert lib.gpbo_append_f64(p, p, 10, 2, C.cast(bad, C.c_void_p), 1e-4, 1e-6, 128, p, p, None, p, p, p, p, 1 << 30,
+                               None) == -1
+    assert lib.gpbo_append_f64(p, p, 10, 2, lsp, 1e-4, 1e-6, 128, p, p, None, p, p, p, p, 8, None) == -3
+    assert lib.gpbo_append_workspace_bytes(128) == 8 * (3 * 128 + 8)
+    # posterior: chunk granule, Np granule, unknown acquisition kind
+    def post(Np, chunk, kind, wbytes=1 << 40):
+        return lib.gpbo_posterior_acq_f64(p, 1000, p, 100, Np, 2, lsp, p, p, 1.0, kind, 4.0, 0.0, 0.0, 0, chunk,
+                                          None, None, None, p, p, wbytes, None, None)
+    assert post(100, 512, 0) == -1
+    assert post(128, 500, 0) == -1
+    assert post(128, 512, 7) == -1
+    assert post(128, 512, 0, wbytes=8) == -3
+    # potrf / trtri: Np a multiple of 64
+    assert lib.gpbo_potrf_f64(p, 100, p, p, None) == -1
+    assert lib.gpbo_trtri_f64(p, p, 100, p, p, None) == -1
+    # ARD grid: N beyond the in-LDS limit
+    assert lib.gpbo_nlml_grid_f64(p, p, 129, 2, p, 4, 1e-4, p, None) == -1
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
 
