@@ -36,16 +36,19 @@ def reduce_records(records):
     return best_val, best_idx, nan_total
 
 
-def allreduce_argmax(best_val: float, best_idx: int, nan_count: int, group=None, device=None):
+def allreduce_argmax(best_val: float, best_idx: int, nan_count: int, group=None, device=None,
+                     force_collective: bool = False):
     """All ranks obtain the global (max value, lowest index, total NaN count).
 
     One all_gather of 3 x int64 per rank (the fp64 value travels as its bit pattern, so no rounding
     and no NaN canonicalisation can happen in transit).  Works on nccl (= RCCL, device tensors)
-    and gloo (CPU tensors)."""
+    and gloo (CPU tensors).  force_collective: run the all-gather even in a one-rank group (used to exercise
+    the RCCL path on a single GPU)."""
     import torch
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1
+                                                                and not force_collective):
         return reduce_records([(best_val, best_idx, nan_count)])
     world = dist.get_world_size(group)
     if device is None:

@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--all-on-device", type=int, default=-1,
                     help="rehearsal only: put every rank on this GPU index instead of LOCAL_RANK")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="rehearsal only: initialise the process group and run the exchange step even at N=1")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="f32: fp64 factorisation, fp32 K*/mean/variance (BASELINE configs[3] shape)")
     args = ap.parse_args()
@@ -86,8 +88,12 @@ def main():
     dev_index = local_rank if args.all_on_device < 0 else args.all_on_device
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    use_pg = world > 1 or args.force_process_group
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -124,10 +130,10 @@ def main():
         v, i, n = gp.read_result(res)               # 32-byte read-back (synchronises this rank)
         if int(gp.info.item()) != 0:
             raise RuntimeError("Cholesky failed")
-        return D.allreduce_argmax(v, i, n)           # the one exchange step (no-op at N=1)
+        return D.allreduce_argmax(v, i, n, force_collective=args.force_process_group)  # the one exchange step (no-op at N=1)
 
     def fence():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -140,7 +146,7 @@ def main():
         best = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -213,7 +219,7 @@ def main():
             cb["argmax_match_on_sample"] = bool(r.best_idx == idx_cpu)
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -462,3 +462,29 @@ def test_nan_candidate_coordinate_is_counted():
     Xs[17, 1] = np.nan
     r = DeviceGP(chunk=512).factorise(X, y, ls).score(Xs, dense=True)
     assert r.nan_count == 1 and np.isnan(r.acq.cpu().numpy()[17]) and r.best_idx != 17
+
+
+def test_exchange_step_over_rccl_in_a_one_rank_group():
+    """The N>1 exchange (all_gather_into_tensor of device int64 records on the nccl = RCCL backend) exercised on
+    the one GPU of this box: a one-rank group with the collective forced.  Bit patterns survive the transit."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for rec in [(3.25, 17, 0), (-0.0, 2 ** 40 + 3, 5), (float("-inf"), 0, 0), (1e-310, 9, 1)]:
+            v, i, n = D.allreduce_argmax(*rec, force_collective=True)
+            assert (i, n) == (rec[1], rec[2]) and np.float64(v).tobytes() == np.float64(rec[0]).tobytes()
+        v, i, n = D.allreduce_argmax(float("nan"), 4, 2, force_collective=True)
+        assert n == 2 and v == float("-inf")  # a NaN record never wins; it is reported through the count
+        t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # bench.py's max-over-ranks timing
+        dist.barrier()
+        assert float(t.item()) == 1.5
+    finally:
+        dist.destroy_process_group()
