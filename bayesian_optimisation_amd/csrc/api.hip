@@ -28,16 +28,15 @@ extern "C" int gpbo_profile_create(int32_t capacity, gpbo_profile **out) {
     p->end = new void *[capacity];
     p->cands = new int64_t[capacity];
     p->kbegin = new void *[capacity];
-    p->kend = new void *[capacity];
+    p->kmode = new int32_t[capacity];
     for (int i = 0; i < capacity; ++i) {
-        hipEvent_t a, b, c, d;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess || hipEventCreate(&c) != hipSuccess ||
-            hipEventCreate(&d) != hipSuccess)
+        hipEvent_t a, b, c;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess || hipEventCreate(&c) != hipSuccess)
             return GPBO_ERR_LAUNCH;
         p->begin[i] = a;
         p->end[i] = b;
         p->kbegin[i] = c;
-        p->kend[i] = d;
+        p->kmode[i] = 0;
         p->cands[i] = 0;
     }
     *out = p;
@@ -69,17 +68,20 @@ extern "C" int gpbo_profile_read(gpbo_profile *p, double *total_ms, int64_t *lau
 extern "C" int gpbo_profile_read_kstar(gpbo_profile *p, double *total_ms, int64_t *launches, int64_t *cands) {
     if (!p || !total_ms || !launches || !cands) return GPBO_ERR_ARG;
     double sum = 0.0;
-    int64_t nc = 0;
+    int64_t nc = 0, nl = 0;
     for (int i = 0; i < p->count; ++i) {
-        hipEvent_t a = reinterpret_cast<hipEvent_t>(p->kbegin[i]), b = reinterpret_cast<hipEvent_t>(p->kend[i]);
+        if (p->kmode[i] == 0 || (p->kmode[i] == 2 && i == 0)) continue;
+        hipEvent_t a = reinterpret_cast<hipEvent_t>(p->kmode[i] == 2 ? p->end[i - 1] : p->kbegin[i]);
+        hipEvent_t b = reinterpret_cast<hipEvent_t>(p->begin[i]);
         if (hipEventSynchronize(b) != hipSuccess) return GPBO_ERR_LAUNCH;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return GPBO_ERR_LAUNCH;
         sum += ms;
         nc += p->cands[i];
+        ++nl;
     }
     *total_ms = sum;
-    *launches = p->count;
+    *launches = nl;
     *cands = nc;
     return GPBO_OK;
 }
@@ -90,12 +92,11 @@ extern "C" void gpbo_profile_destroy(gpbo_profile *p) {
         (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(p->begin[i]));
         (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(p->end[i]));
         (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(p->kbegin[i]));
-        (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(p->kend[i]));
     }
     delete[] p->begin;
     delete[] p->end;
     delete[] p->cands;
     delete[] p->kbegin;
-    delete[] p->kend;
+    delete[] p->kmode;
     delete p;
 }

@@ -422,6 +422,7 @@ extern "C" int gpbo_posterior_acq_f32(const double *Xs, int64_t M, const double 
             if (hipEventRecord(reinterpret_cast<hipEvent_t>(prof->end[prof->count]), st) != hipSuccess)
                 return GPBO_ERR_LAUNCH;
             prof->cands[prof->count] = Mc;
+            prof->kmode[prof->count] = 0;  // the fp32 K(X*,X) launches are not timed separately
             ++prof->count;
         }
         GPBO_CHECK_LAUNCH();

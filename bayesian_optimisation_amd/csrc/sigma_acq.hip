@@ -635,19 +635,27 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
         if (hipEventRecord(hp->fork, st) != hipSuccess || hipStreamWaitEvent(ks, hp->fork, 0) != hipSuccess)
             return GPBO_ERR_LAUNCH;
     }
+    bool prev_recorded = false;  // the previous chunk's variance launch has an end event in the slot before
     auto launch_kstar = [&](int64_t c) -> int {
         const int64_t s = c * chunk;
         const int64_t Mc = (M - s < chunk) ? (M - s) : chunk;
         const int b = (int)(c & 1);
-        // (K(X*,X) launches are timed only in the plain in-order mode: chunk c's events share slot prof->count)
+        // K(X*,X) launches are timed only in the plain in-order mode, where the launches of this call form one chain
+        // on the caller's stream: the event in front of the variance launch of the slot ends the K(X*,X) interval, and
+        // the interval begins at the previous variance launch's end event (chunks after the first) or at kbegin.
         const bool krec = prof && !hp && prof->count < prof->capacity;
-        if (krec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->kbegin[prof->count]), ks) != hipSuccess)
-            return GPBO_ERR_LAUNCH;
+        if (krec) {
+            const bool chained = c > 0 && prof->count > 0 && prev_recorded;
+            prof->kmode[prof->count] = chained ? 2 : 1;
+            if (!chained &&
+                hipEventRecord(reinterpret_cast<hipEvent_t>(prof->kbegin[prof->count]), ks) != hipSuccess)
+                return GPBO_ERR_LAUNCH;
+        } else if (prof && prof->count < prof->capacity) {
+            prof->kmode[prof->count] = 0;
+        }
         int rc = gpbo_kstar_mu_f64(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT[b], chunk,
                                    mu_part[b], ks);
         if (rc != GPBO_OK) return rc;
-        if (krec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->kend[prof->count]), ks) != hipSuccess)
-            return GPBO_ERR_LAUNCH;
         if (hp && hipEventRecord(hp->kdone[b], ks) != hipSuccess) return GPBO_ERR_LAUNCH;
         return GPBO_OK;
     };
@@ -688,6 +696,7 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
             prof->cands[prof->count] = Mc;
             ++prof->count;
         }
+        prev_recorded = rec;
         GPBO_CHECK_LAUNCH();
         if (hp && hipEventRecord(hp->sdone[b], st) != hipSuccess) return GPBO_ERR_LAUNCH;
         if (!hp && c + 1 < nchunks) {

@@ -49,13 +49,16 @@ typedef struct gpbo_result {
     int64_t reserved;
 } gpbo_result;
 
-/* Optional timing of the dominant kernel (sigma/acquisition): one hipEvent pair per launch, recorded
- * on the caller's stream by gpbo_posterior_acq_f64 when a profile is passed.  Host-side object. */
+/* Optional timing of the dominant kernel (sigma/acquisition) and of the K(X*,X) build: hipEvents recorded on
+ * the caller's stream by gpbo_posterior_acq_f64 when a profile is passed.  The launches of one call form a chain
+ * K*(0), variance(0), K*(1), variance(1), ... on one stream, so one event per boundary serves as the end of one
+ * launch and the beginning of the next (an event record costs a few microseconds of idle GPU).  Host-side object. */
 typedef struct gpbo_profile {
     int32_t capacity, count;
-    void **begin, **end;   /* hipEvent_t pairs around the variance/acquisition launches */
+    void **begin, **end;   /* hipEvent_t before / after each variance/acquisition launch */
     int64_t *cands;        /* candidates processed by each recorded launch */
-    void **kbegin, **kend; /* hipEvent_t pairs around the K(X*,X) launches of the same chunks */
+    void **kbegin;         /* hipEvent_t before the K(X*,X) launch of the slot (used when kmode == 1) */
+    int32_t *kmode;        /* K(X*,X) launch of the slot: 0 not timed, 1 kbegin[i]..begin[i], 2 end[i-1]..begin[i] */
 } gpbo_profile;
 int gpbo_profile_create(int32_t capacity, gpbo_profile **out);
 void gpbo_profile_reset(gpbo_profile *p);
