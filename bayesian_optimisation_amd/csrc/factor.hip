@@ -18,90 +18,140 @@ constexpr int LDS_LD = NB + 1;
 
 // ---------------------------------------------------------------------------------------------
 // Diagonal block: Cholesky of one 64x64 block AND the inverse of its factor, in one elimination.
-// One workgroup of 256 threads.  The eliminated matrix is the 128x64 stack [A; I]: carrying the identity
-// rows through the same column operations leaves I * L^-T in them, i.e. inv(L)^T, so no separate
-// triangular inversion (and none of its dependent LDS chains) is needed.
-// Thread (ti, tj) keeps two 4x4 tiles in registers: rows 4ti.. of A and rows 4ti.. of the identity part,
-// columns 4tj...  Per column c the 16 owning threads publish the UNSCALED column through LDS (double
-// buffered, one barrier per column); everybody updates with a_ic * a_jc / piv, so only a reciprocal of the
-// pivot is on the critical path - the square roots are taken once at the end for all 64 columns.
+// One workgroup of 256 threads = 4 waves.  The eliminated matrix is the 128x64 stack M = [A; I] in LDS: carrying
+// the identity rows through the same column operations leaves L^-T in them, so no separate triangular inversion
+// is needed.  The 64 columns are taken 16 at a time:
+//   (1) wave 0 eliminates the 16x16 diagonal sub-block and the identity rows under it in REGISTERS - lane = row,
+//       16 values per lane, pivots and multipliers broadcast with v_readlane: no LDS round trip and no barrier
+//       inside the 16 dependent column steps (the first version paid one barrier + LDS broadcast per column:
+//       64 x 380 ns);
+//   (2) the three non-zero 16x16 blocks of the panel are multiplied by the sub-block's L^-T on the matrix cores;
+//   (3) the trailing 16x16 blocks are updated on the matrix cores - wave 0 takes the next diagonal sub-block
+//       first and goes straight on to (1) for it while the other three waves do the rest.
+// Two barriers per 16 columns.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rcp_refined(double p) {
-    double y = __builtin_amdgcn_rcp(p);
-    double e = fma(-p, y, 1.0);
+constexpr int PB = 16;      // inner block
+constexpr int LDM = NB + 2; // row stride of M in LDS (doubles)
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double rsqrt_refined(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+    double e = fma(-(h * y), y, 0.5);
     y = fma(y, e, y);
-    e = fma(-p, y, 1.0);
+    e = fma(-(h * y), y, 0.5);
     return fma(y, e, y);
 }
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ K, int64_t ld, int jb,
                                                          double *__restrict__ dinv, int32_t *__restrict__ info) {
-    // colT[c][0..63]  = unscaled column c of the A part, colT[c][64..127] = of the identity part, as published
-    // at step c.  Every column has its own slot, so the slot doubles as the record the final scaling reads
-    // (no copy, no double buffering) and the loop body stays short: with one wave per SIMD nothing hides
-    // instruction count, which is what bounded the earlier versions (~330 instructions per column).
-    __shared__ double colT[NB][2 * NB];
+    __shared__ double M[2 * NB * LDM];  // rows 0..63: A -> L (lower);  rows 64..127: I -> L^-T (upper)
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
     double *Kd = K + ((int64_t)jb * NB) * ld + (int64_t)jb * NB;
-    const int ti = tid >> 4, tj = tid & 15;
-    double a[4][4], b[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = 4 * ti + i, q = 4 * tj + j;
-            a[i][j] = (q <= r) ? Kd[(int64_t)r * ld + q] : 0.0;
-            b[i][j] = (q == r) ? 1.0 : 0.0;
-        }
-    int first_bad = 0;  // 1-based column of the first non-positive / non-finite pivot
-    for (int cj = 0; cj < NB / 4; ++cj) {
-        // columns to the right of the current one inside this thread's tile: all four if tj > cj, none if
-        // tj < cj, (j > cc) on the diagonal tile column - applied as a mask on the broadcast column values
-        const bool right = tj > cj, same = tj == cj;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int c = 4 * cj + cc;
-            double *cb = colT[c];
-            if (same) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    cb[4 * ti + i] = a[i][cc];
-                    cb[NB + 4 * ti + i] = b[i][cc];
-                }
-            }
-            __syncthreads();
-            const double piv = cb[c];
-            const bool ok = (piv > 0.0) && (piv < 1.0e300);
-            first_bad = (!ok && first_bad == 0) ? c + 1 : first_bad;
-            const double rp = rcp_refined(piv);
-            double ta[4], tb[4], aq[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ta[i] = cb[4 * ti + i] * rp;
-                tb[i] = cb[NB + 4 * ti + i] * rp;
-                const bool upd = right || (same && i > cc);
-                aq[i] = upd ? cb[4 * tj + i] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a[i][j] = fma(-ta[i], aq[j], a[i][j]);
-                    b[i][j] = fma(-tb[i], aq[j], b[i][j]);
-                }
-        }
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        M[r * LDM + c] = (c <= r) ? Kd[(int64_t)r * ld + c] : 0.0;
+        M[(NB + r) * LDM + c] = (c == r) ? 1.0 : 0.0;
     }
     __syncthreads();
-    if (tid == 0 && first_bad) atomicCAS(info, 0, jb * NB + first_bad);
-    // scale: d_c = sqrt(piv_c);  L[r][c] = a_rc / d_c (r >= c);  inv(L)[r][c] = b_cr / d_r (c <= r)
-    __shared__ double rs[NB];
-    if (tid < NB) rs[tid] = 1.0 / sqrt(colT[tid][tid]);
+
+    int first_bad = 0;  // 1-based column of the first non-positive / non-finite pivot (wave 0)
+    // (1): lanes 0..15 hold rows 16s.. of A, lanes 16..31 the identity rows under them (lanes 32..63 mirror
+    // 0..31 and write nothing), columns 16s..16s+15
+    auto eliminate = [&](int s) {
+        const int l31 = lane & 31;
+        const int prow = (l31 < PB) ? (PB * s + l31) : (NB + PB * s + (l31 - PB));
+        double *row = M + prow * LDM + PB * s;
+        double x[PB];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) x[k] = row[k];
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            const double piv = readlane_f64(x[c], c);
+            const bool ok = (piv > 0.0) && (piv < 1.0e300);
+            first_bad = (!ok && first_bad == 0) ? PB * s + c + 1 : first_bad;
+            x[c] *= rsqrt_refined(piv);
+#pragma unroll
+            for (int k = c + 1; k < PB; ++k) x[k] = fma(-x[c], readlane_f64(x[c], k), x[k]);
+        }
+        if (lane < 2 * PB) {
+#pragma unroll
+            for (int k = 0; k < PB; ++k) row[k] = (lane < PB && k > lane) ? 0.0 : x[k];
+        }
+    };
+    // (2): X <- X * T, X = 16 rows from R0 in column block s, T = L_ss^-T (rows 64+16s.. of M)
+    auto panel = [&](int R0, int s) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < PB; kk += 4) {
+            const double a = M[(R0 + l15) * LDM + PB * s + kk + l4];
+            const double b = M[(NB + PB * s + kk + l4) * LDM + PB * s + l15];
+            acc = mfma_f64_16x16x4(a, b, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[(R0 + l4 + 4 * r) * LDM + PB * s + l15] = acc[r];
+    };
+    // (3): M[R0.., block c] -= M[R0.., block s] * A[block c, block s]^T
+    auto trail = [&](int R0, int c, int s) {
+        d4_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = M[(R0 + l4 + 4 * r) * LDM + PB * c + l15];
+#pragma unroll
+        for (int kk = 0; kk < PB; kk += 4) {
+            const double a = -M[(R0 + l15) * LDM + PB * s + kk + l4];
+            const double b = M[(PB * c + l15) * LDM + PB * s + kk + l4];
+            acc = mfma_f64_16x16x4(a, b, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[(R0 + l4 + 4 * r) * LDM + PB * c + l15] = acc[r];
+    };
+
+    constexpr int NS = NB / PB;  // 4
+    if (w == 0) eliminate(0);
     __syncthreads();
+    for (int s = 0; s < NS; ++s) {
+        // (2) the non-zero panel blocks: A row blocks s+1..3 and identity-part row blocks 0..s-1 - always three
+        if (w < NS - 1) {
+            const int t = w;  // 0..2
+            const int nA = NS - 1 - s;
+            panel(t < nA ? PB * (s + 1 + t) : NB + PB * (t - nA), s);
+        }
+        __syncthreads();
+        if (s == NS - 1) break;
+        // (3) trailing blocks; wave 0: the next diagonal sub-block, then its elimination
+        if (w == 0) {
+            trail(PB * (s + 1), s + 1, s);
+            eliminate(s + 1);
+        } else {
+            int q = 0;
+            for (int c = s + 1; c < NS; ++c) {
+                for (int R = c; R < NS; ++R) {  // A part, lower block triangle
+                    if (R == s + 1 && c == s + 1) continue;
+                    if (q % 3 == w - 1) trail(PB * R, c, s);
+                    ++q;
+                }
+                for (int m = 0; m <= s; ++m) {  // identity part: its rows 0..16(s+1)-1 are non-zero in block s
+                    if (q % 3 == w - 1) trail(NB + PB * m, c, s);
+                    ++q;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && first_bad) atomicCAS(info, 0, jb * NB + first_bad);
     double *dv = dinv + (int64_t)jb * NB * NB;
     for (int e = tid; e < NB * NB; e += 256) {
         const int r = e >> 6, c = e & 63;
-        if (c <= r) Kd[(int64_t)r * ld + c] = colT[c][r] * rs[c];
-        dv[e] = (c <= r) ? colT[r][NB + c] * rs[r] : 0.0;
+        if (c <= r) Kd[(int64_t)r * ld + c] = M[r * LDM + c];
+        dv[e] = (c <= r) ? M[(NB + c) * LDM + r] : 0.0;   // inv(L)[r][c] = (L^-T)[c][r]
     }
 }
 
@@ -179,10 +229,11 @@ __global__ void zero_i32_kernel(int32_t *p) { *p = 0; }
 
 }  // namespace
 
-extern "C" int gpbo_potrf_f64(double *Kp, int64_t Np, double *dinv, int32_t *info, void *stream) {
+// info_is_zero: the caller has already cleared *info on this stream (gpbo_factorise_f64 does it in the K(X,X) build)
+static int potrf_run(double *Kp, int64_t Np, double *dinv, int32_t *info, bool info_is_zero, void *stream) {
     if (!Kp || !dinv || !info || Np < NB || Np % NB) return GPBO_ERR_ARG;
     hipStream_t st = gpbo_stream(stream);
-    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(1), 0, st, info);
+    if (!info_is_zero) hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(1), 0, st, info);
     const int nb = (int)(Np / NB);
     for (int j = 0; j < nb; ++j) {
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, Kp, Np, j, dinv, info);
@@ -200,6 +251,10 @@ extern "C" int gpbo_potrf_f64(double *Kp, int64_t Np, double *dinv, int32_t *inf
         if (rc != GPBO_OK) return rc;
     }
     return GPBO_OK;
+}
+
+extern "C" int gpbo_potrf_f64(double *Kp, int64_t Np, double *dinv, int32_t *info, void *stream) {
+    return potrf_run(Kp, Np, dinv, info, false, stream);
 }
 
 int gpbo_launch_transpose_upper(const double *W, int64_t Np, double *U, hipStream_t st) {
@@ -266,16 +321,14 @@ extern "C" int gpbo_factorise_f64(const double *X, const double *y, int64_t N, i
     if (!X || !y || !Kp || !U || !alpha || !info || !work) return GPBO_ERR_ARG;
     if (Np != gpbo_padded_n(N)) return GPBO_ERR_ARG;
     if (work_bytes < gpbo_factorise_workspace_bytes(Np)) return GPBO_ERR_WORKSPACE;
-    hipStream_t st = gpbo_stream(stream);
     double *L = reinterpret_cast<double *>(work);
     double *W = L + Np * Np;
     double *dinv = W + Np * Np;
     double *tmp = dinv + Np * NB;
-    int rc = gpbo_kxx_f64(X, N, d, ls_host, jitter1, jitter2, Kp, Np, stream);
+    // one launch builds K twice (Kp stays as the reference's cov_meas, L is factorised in place) and clears info
+    int rc = gpbo_kxx_launch(X, N, d, ls_host, jitter1, jitter2, Kp, Np, L, info, stream);
     if (rc != GPBO_OK) return rc;
-    if (hipMemcpyAsync(L, Kp, sizeof(double) * Np * Np, hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return GPBO_ERR_LAUNCH;
-    rc = gpbo_potrf_f64(L, Np, dinv, info, stream);
+    rc = potrf_run(L, Np, dinv, info, true, stream);
     if (rc != GPBO_OK) return rc;
     rc = gpbo_trtri_f64(L, dinv, Np, U, W, stream);
     if (rc != GPBO_OK) return rc;
