@@ -5,5 +5,6 @@ Importing the package does not load the HIP library; the first use of `PointSele
 """
 from .point_selector import PointSelector  # noqa: F401
 from .gp_device import DeviceGP, ScoreResult  # noqa: F401
+from .host_binding import PointSelectorHost  # noqa: F401  (NumPy + ctypes only: no PyTorch needed)
 
-__all__ = ["PointSelector", "DeviceGP", "ScoreResult"]
+__all__ = ["PointSelector", "PointSelectorHost", "DeviceGP", "ScoreResult"]

@@ -1,0 +1,157 @@
+// Host-pointer entry points: one call = one SELECT_PARAMETERS surrogate step.
+//
+// The reference's boundary is a Python attribute protocol fed with NumPy arrays
+// (/root/reference/select_parameters.py:146-158, 282-294 -> /root/reference/point_selector.py:42-102, 197-207).
+// These two functions take exactly those arrays as plain host pointers, so a maintainer can bind the GPU path
+// with ctypes + NumPy alone (no PyTorch, no device-memory handling on the caller's side): device buffers are
+// allocated, filled, used and released inside the call, on the library's own stream.
+//   gpbo_select_next_host_f64  = update_surrogate() after the length scales are chosen + the acquisition arg-max
+//   gpbo_nlml_grid_host_f64    = tune_kernel()'s likelihood grid
+#include "gpbo_internal.h"
+
+#include <vector>
+
+namespace {
+
+// Device allocations of one call, released on every exit path.
+struct DeviceArena {
+    std::vector<void *> ptrs;
+    hipStream_t stream = nullptr;
+    bool ok = true;
+    DeviceArena() { ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess; }
+    ~DeviceArena() {
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    T *alloc(int64_t count) {
+        void *p = nullptr;
+        if (count < 1) count = 1;
+        if (hipMalloc(&p, sizeof(T) * (size_t)count) != hipSuccess) {
+            ok = false;
+            return nullptr;
+        }
+        ptrs.push_back(p);
+        return reinterpret_cast<T *>(p);
+    }
+    bool h2d(void *dst, const void *src, size_t bytes) {
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream) == hipSuccess;
+    }
+    bool d2h(void *dst, const void *src, size_t bytes) {
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream) == hipSuccess;
+    }
+    bool sync() { return hipStreamSynchronize(stream) == hipSuccess; }
+};
+
+}  // namespace
+
+extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls,
+                                         double jitter1, double jitter2, const double *Xs, int64_t M, int32_t acq_kind,
+                                         double p0, double p1, double diag_add, int64_t chunk, double *mu_out,
+                                         double *sigma_out, double *acq_out, double *cov_meas_out, gpbo_result *result,
+                                         int32_t *info) {
+    if (!X || !y || !ls || !Xs || !result || !info) return GPBO_ERR_ARG;
+    if (N < 1 || M < 1 || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
+    if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
+    if (chunk == 0) chunk = (int64_t)1 << 17;
+    if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE) return GPBO_ERR_ARG;
+    for (int k = 0; k < d; ++k)
+        if (!(ls[k] > 0.0)) return GPBO_ERR_ARG;
+    {  // no more chunk than the candidates need
+        const int64_t need = (M + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
+        if (chunk > need) chunk = need;
+    }
+    const int64_t Np = gpbo_padded_n(N);
+    const int64_t wfact = gpbo_factorise_workspace_bytes(Np);
+    const int64_t wpost = gpbo_posterior_workspace_bytes(Np, chunk, M);
+    if (wpost < 0) return GPBO_ERR_ARG;
+
+    DeviceArena A;
+    if (!A.ok) return GPBO_ERR_LAUNCH;
+    double *dX = A.alloc<double>(N * d), *dy = A.alloc<double>(N), *dXs = A.alloc<double>(M * d);
+    double *dK = A.alloc<double>(Np * Np), *dU = A.alloc<double>(Np * Np), *dalpha = A.alloc<double>(Np);
+    int32_t *dinfo = A.alloc<int32_t>(1);
+    gpbo_result *dres = A.alloc<gpbo_result>(1);
+    // the factorisation workspace is dead once U and alpha exist: the posterior workspace reuses the allocation
+    const int64_t wbytes = (wfact > wpost ? wfact : wpost) + 256;
+    char *dwork = A.alloc<char>(wbytes);
+    const bool dense = mu_out || sigma_out || acq_out;
+    double *dmu = dense ? A.alloc<double>(M) : nullptr;
+    double *dsig = dense ? A.alloc<double>(M) : nullptr;
+    double *dacq = dense ? A.alloc<double>(M) : nullptr;
+    if (!A.ok) return GPBO_ERR_WORKSPACE;
+    void *st = reinterpret_cast<void *>(A.stream);
+
+    if (!A.h2d(dX, X, sizeof(double) * N * d) || !A.h2d(dy, y, sizeof(double) * N) ||
+        !A.h2d(dXs, Xs, sizeof(double) * M * d))
+        return GPBO_ERR_LAUNCH;
+    int rc = gpbo_factorise_f64(dX, dy, N, d, ls, jitter1, jitter2, Np, dK, dU, dalpha, dinfo, dwork, wfact, st);
+    if (rc != GPBO_OK) return rc;
+    if (!A.d2h(info, dinfo, sizeof(int32_t)) || !A.sync()) return GPBO_ERR_LAUNCH;
+    if (cov_meas_out) {  // the reference's cov_meas attribute (point_selector.py:79), N x N without the padding
+        if (hipMemcpy2DAsync(cov_meas_out, sizeof(double) * N, dK, sizeof(double) * Np, sizeof(double) * N, (size_t)N,
+                             hipMemcpyDeviceToHost, A.stream) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
+    }
+    if (*info != 0) {  // not positive definite: nothing to score (the reference's inv() raises or returns garbage)
+        result->best_val = 0.0;
+        result->best_idx = -1;
+        result->nan_count = 0;
+        result->reserved = 0;
+        return A.sync() ? GPBO_OK : GPBO_ERR_LAUNCH;
+    }
+    const double prior_var = (1.0 + jitter1) + jitter2;  // diagonal of cov_pred as the reference rounds it
+    rc = gpbo_posterior_acq_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, diag_add, 0, chunk,
+                                dmu, dsig, dacq, dres, dwork, wpost, nullptr, st);
+    if (rc != GPBO_OK) return rc;
+    bool okc = A.d2h(result, dres, sizeof(gpbo_result));
+    if (mu_out) okc = okc && A.d2h(mu_out, dmu, sizeof(double) * M);
+    if (sigma_out) okc = okc && A.d2h(sigma_out, dsig, sizeof(double) * M);
+    if (acq_out) okc = okc && A.d2h(acq_out, dacq, sizeof(double) * M);
+    if (!okc || !A.sync()) return GPBO_ERR_LAUNCH;
+    return GPBO_OK;
+}
+
+extern "C" int gpbo_nlml_grid_host_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells,
+                                       int64_t G, double jitter, float *out) {
+    if (!X || !y || !ls_cells || !out || N < 1 || d < 1 || d > GPBO_MAX_D || G < 1 || G > (1 << 30))
+        return GPBO_ERR_ARG;
+    for (int64_t e = 0; e < G * d; ++e)
+        if (!(ls_cells[e] > 0.0)) return GPBO_ERR_ARG;
+    DeviceArena A;
+    if (!A.ok) return GPBO_ERR_LAUNCH;
+    double *dX = A.alloc<double>(N * d), *dy = A.alloc<double>(N);
+    float *dout = A.alloc<float>(G);
+    void *st = reinterpret_cast<void *>(A.stream);
+    if (!A.ok) return GPBO_ERR_WORKSPACE;
+    if (!A.h2d(dX, X, sizeof(double) * N * d) || !A.h2d(dy, y, sizeof(double) * N)) return GPBO_ERR_LAUNCH;
+    int rc;
+    if (N <= gpbo_nlml_grid_max_n()) {
+        double *dcells = A.alloc<double>(G * d);
+        if (!A.ok) return GPBO_ERR_WORKSPACE;
+        if (!A.h2d(dcells, ls_cells, sizeof(double) * G * d)) return GPBO_ERR_LAUNCH;
+        rc = gpbo_nlml_grid_f64(dX, dy, N, d, dcells, G, jitter, dout, st);
+        if (rc != GPBO_OK) return rc;
+    } else {
+        // beyond the in-LDS kernel: one full factorisation per cell (the reference's own det-based likelihood
+        // is -inf for most cells at such N, which gpbo_nlml_cell_f64 reproduces)
+        const int64_t Np = gpbo_padded_n(N);
+        const int64_t wfact = gpbo_factorise_workspace_bytes(Np);
+        double *dK = A.alloc<double>(Np * Np), *dU = A.alloc<double>(Np * Np), *dalpha = A.alloc<double>(Np);
+        int32_t *dinfo = A.alloc<int32_t>(1);
+        char *dwork = A.alloc<char>(wfact);
+        if (!A.ok) return GPBO_ERR_WORKSPACE;
+        for (int64_t g = 0; g < G; ++g) {
+            rc = gpbo_factorise_f64(dX, dy, N, d, ls_cells + g * d, jitter, 0.0, Np, dK, dU, dalpha, dinfo, dwork, wfact,
+                                    st);
+            if (rc != GPBO_OK) return rc;
+            rc = gpbo_nlml_cell_f64(dU, dalpha, dy, N, Np, dinfo, dout + g, st);
+            if (rc != GPBO_OK) return rc;
+        }
+    }
+    if (!A.d2h(out, dout, sizeof(float) * G) || !A.sync()) return GPBO_ERR_LAUNCH;
+    return GPBO_OK;
+}

@@ -112,17 +112,7 @@ class PointSelector:
             self._gp = DeviceGP(self._device)
         gp = self._gp
 
-        if self._preset_kernel_params:
-            pass
-        elif len(X[:, 0]) > 1:                                           # :60
-            self.tune_kernel()
-        else:                                                            # :63-73
-            if len(self.length_scales) == 2:
-                a1, a2 = self.length_scales[0], self.length_scales[1]
-                self.kernel_params = np.array([a1[len(a1) // 2], a2[len(a2) // 2]])
-            else:
-                self.kernel_params = np.array([self.length_scales[len(self.length_scales) // 2]])
-        ls = np.asarray(self.kernel_params, dtype=np.float64).reshape(-1)
+        ls = self._select_kernel_params(X)
 
         self._factorise_or_append(gp, X, y, ls)                           # :79, :89 (raises LinAlgError)
         self.cov_meas = gp.cov_meas_host()
@@ -152,6 +142,20 @@ class PointSelector:
 
         self.measured_pts = self.measured_pts.tolist()                    # :101-102
         self.measured_vals = self.measured_vals.tolist()
+
+    def _select_kernel_params(self, X) -> np.ndarray:
+        """point_selector.py:60-73: preset, ARD grid search (n > 1) or the middle of each length-scale axis."""
+        if self._preset_kernel_params:
+            pass
+        elif len(X[:, 0]) > 1:                                           # :60
+            self.tune_kernel()
+        else:                                                            # :63-73
+            if len(self.length_scales) == 2:
+                a1, a2 = self.length_scales[0], self.length_scales[1]
+                self.kernel_params = np.array([a1[len(a1) // 2], a2[len(a2) // 2]])
+            else:
+                self.kernel_params = np.array([self.length_scales[len(self.length_scales) // 2]])
+        return np.asarray(self.kernel_params, dtype=np.float64).reshape(-1)
 
     def _factorise_or_append(self, gp, X, y, ls):
         """Full factorisation, or - with incremental=True / a state file - O(N^2) appends when the new data are

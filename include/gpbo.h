@@ -180,6 +180,30 @@ int gpbo_acq_argmax_f64(const double *mu, const double *sigma, int64_t M, int32_
                         int64_t idx_offset, double *acq_out, gpbo_result *result, void *work, int64_t work_bytes,
                         void *stream);
 
+/* ---- Host-pointer entry points: the reference's call sequence on NumPy-style arrays, no device handling by the
+ * caller (device buffers and a private stream live inside the call).  What a ctypes stub in the reference binds.
+ *
+ * gpbo_select_next_host_f64 = PointSelector.update_surrogate() once kernel_params are chosen + the acquisition
+ * arg-max (point_selector.py:76-98, 197-207; caller: select_parameters.py:149-158, 285-294):
+ *   X [N x d], y [N], ls [d] (kernel_params), Xs [M x d] (predicted_pts, row-major grid) - host, fp64;
+ *   jitter1 / jitter2 = 1e-4 / 1e-6 for the reference's arithmetic; acq_kind / p0 / p1 as gpbo_posterior_acq_f64;
+ *   diag_add = 1e-4 when Xs has the same shape as X (point_selector.py:173), else 0; chunk = 0 for the default;
+ *   mu_out / sigma_out / acq_out: optional host [M] (mean_func, cov_func, acq_func_eval before reshaping);
+ *   cov_meas_out: optional host [N x N] (the cov_meas attribute);
+ *   result (host): best value, lowest flat index attaining it, NaN count (> 0: the reference raises IndexError);
+ *   info (host): 0, or the 1-based failing pivot (the reference's inv() raises LinAlgError or returns garbage) -
+ *   then nothing is scored and result->best_idx = -1.
+ * gpbo_nlml_grid_host_f64 = tune_kernel()'s float32 likelihood grid (point_selector.py:104-163): ls_cells [G x d]
+ *   host, out [G] host float32; any N (the in-LDS kernel up to gpbo_nlml_grid_max_n(), one factorisation per cell
+ *   beyond). */
+int gpbo_select_next_host_f64(const double *X_host, const double *y_host, int64_t N, int32_t d, const double *ls_host,
+                              double jitter1, double jitter2, const double *Xs_host, int64_t M, int32_t acq_kind,
+                              double p0, double p1, double diag_add, int64_t chunk, double *mu_out_host,
+                              double *sigma_out_host, double *acq_out_host, double *cov_meas_out_host,
+                              gpbo_result *result_host, int32_t *info_host);
+int gpbo_nlml_grid_host_f64(const double *X_host, const double *y_host, int64_t N, int32_t d,
+                            const double *ls_cells_host, int64_t G, double jitter, float *out_host);
+
 /* K9 - replaces tune_kernel / eval_log_marginal (point_selector.py:104-163): float32 grid of
  * nlml = 0.5 (y^T K^-1 y + log det K + N log 2pi), K = k(X,X) + jitter I, one value per grid cell.
  * ls_cells: [G x d] length scales of each cell (device); out: [G] float32 (device).

@@ -3,12 +3,12 @@ the sizes the reference's DAG actually runs (golden fixture inputs)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from bayesian_optimisation_amd import PointSelector
+from bayesian_optimisation_amd import PointSelector, PointSelectorHost
 
 for name in ("g1_m32", "g1_m50"):
     g = dict(np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", name + ".npz")))
-    def run(preset):
-        ps = PointSelector()
+    def run(preset, cls=PointSelector):
+        ps = cls()
         ps.name, ps.iteration = "T", 0
         ps.measured_pts, ps.measured_vals = g["X"], g["y"]
         ps.feature_domain = [int(v) for v in g["feature_domain"]]
@@ -26,3 +26,8 @@ for name in ("g1_m32", "g1_m50"):
             t = time.perf_counter(); idx = run(preset); ts.append(time.perf_counter() - t)
         print(f"{name} M={len(g['Xs'])} {'preset ls' if preset else 'with 50x50 ARD grid'}: median {np.median(ts)*1e3:.2f} ms, "
               f"index {idx.tolist()} (reference {g['index'].tolist()})")
+    for preset in (False, True):
+        run(preset, PointSelectorHost); ts = []
+        for _ in range(7):
+            t = time.perf_counter(); idx = run(preset, PointSelectorHost); ts.append(time.perf_counter() - t)
+        print(f"{name} host-pointer class, {'preset ls' if preset else 'with 50x50 ARD grid'}: median {np.median(ts)*1e3:.2f} ms, index {idx.tolist()}")
