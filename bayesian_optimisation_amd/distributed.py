@@ -60,3 +60,23 @@ def allreduce_argmax(best_val: float, best_idx: int, nan_count: int, group=None,
     rows = out.cpu().view(world, 3).tolist()
     recs = [(struct.unpack("<d", struct.pack("<q", b))[0], i, n) for b, i, n in rows]
     return reduce_records(recs)
+
+
+def gather_concat(local, total: int, group=None):
+    """Concatenation, in rank order, of the contiguous shards produced under shard_bounds (dense mu / sigma /
+    acquisition arrays, the ARD likelihood grid).  Every rank gets the full array; bytes travel unchanged.
+    A no-op outside a process group."""
+    import numpy as np
+    import torch.distributed as dist
+
+    local = np.ascontiguousarray(local)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if local.shape[0] != total:
+            raise ValueError("gather_concat: shard does not cover the whole array")
+        return local
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, local, group=group)
+    out = np.concatenate(parts)
+    if out.shape[0] != total:
+        raise ValueError(f"gather_concat: shards add up to {out.shape[0]} rows, expected {total}")
+    return out

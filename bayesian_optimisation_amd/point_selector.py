@@ -194,14 +194,16 @@ class PointSelector:
 
     @staticmethod
     def _gather(local: np.ndarray, M: int, world: int) -> np.ndarray:
-        import torch
-        import torch.distributed as dist
+        return D.gather_concat(local, M)
 
-        parts = [None] * world
-        dist.all_gather_object(parts, local)
-        out = np.concatenate(parts)
-        assert out.shape[0] == M
-        return out
+    def _nlml_cells(self, X, y, cells) -> np.ndarray:
+        """The likelihood of every grid cell; with several ranks each evaluates a contiguous block of cells
+        (independent factorisations) and the float32 values are concatenated on every rank."""
+        world, rank = self._world()
+        if world == 1 or len(cells) < world:
+            return self._gp.nlml_grid(X, y, cells)
+        lo, hi = D.shard_bounds(len(cells), world, rank)
+        return D.gather_concat(self._gp.nlml_grid(X, y, cells[lo:hi]), len(cells))
 
     # ------------------------------------------------------------------------------------------
     def tune_kernel(self):
@@ -214,7 +216,7 @@ class PointSelector:
             axis1 = np.asarray(self.length_scales[0], dtype=np.float64)
             axis2 = np.asarray(self.length_scales[1], dtype=np.float64)
             cells = np.stack(np.meshgrid(axis1, axis2, indexing="ij"), -1).reshape(-1, 2)
-            nlogml = self._gp.nlml_grid(X, y, cells).reshape(len(axis1), len(axis2))
+            nlogml = self._nlml_cells(X, y, cells).reshape(len(axis1), len(axis2))
             min_idx = np.argwhere(nlogml == np.amin(nlogml))[0]           # :141
             self.kernel_params = np.array([axis1[min_idx[0]], axis2[min_idx[1]]])
             self.nlogml = nlogml
@@ -225,7 +227,7 @@ class PointSelector:
                     pass
         else:
             axis = np.asarray(self.length_scales, dtype=np.float64)
-            nlogml = self._gp.nlml_grid(X, y, axis.reshape(-1, 1))
+            nlogml = self._nlml_cells(X, y, axis.reshape(-1, 1))
             min_idx = np.argwhere(nlogml == np.amin(nlogml))[0]           # :159
             self.kernel_params = np.array([axis[min_idx]])                # shape (1, 1), as at :161
             self.nlogml = nlogml

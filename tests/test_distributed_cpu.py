@@ -53,7 +53,16 @@ def _worker(rank, world, port, q):
         out = D.allreduce_argmax(float(loc[j]), lo + j, 1 if rank == 1 else 0)
         # the bit pattern of the value must survive the exchange
         out2 = D.allreduce_argmax(float(np.nextafter(1.0, 2.0)) if rank == 0 else 1.0, rank, 0)
-        q.put((rank, out, out2))
+        # dense arrays / the ARD grid: contiguous shards back into one array, bytes unchanged, dtype kept
+        full = (np.arange(1001, dtype=np.float32) * np.float32(0.1)) ** 2
+        got = D.gather_concat(full[lo:hi], M)
+        ok_gather = got.dtype == np.float32 and np.array_equal(got, full)
+        try:
+            D.gather_concat(full[lo:hi], M + 1)
+            ok_gather = False
+        except ValueError:
+            pass
+        q.put((rank, out, out2, ok_gather))
     finally:
         dist.destroy_process_group()
 
@@ -71,6 +80,14 @@ def test_two_process_gloo_exchange():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, out, out2 in res:
+    for rank, out, out2, ok_gather in res:
+        assert ok_gather
         assert out == (5.0, 100, 1)
         assert out2 == (float(np.nextafter(1.0, 2.0)), 0, 0)
+
+
+def test_gather_concat_without_a_process_group():
+    a = np.arange(7.0)
+    assert D.gather_concat(a, 7) is not None and np.array_equal(D.gather_concat(a, 7), a)
+    with pytest.raises(ValueError):
+        D.gather_concat(a, 8)
