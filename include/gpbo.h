@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPBO_VERSION 100 /* 0.1.0 */
+#define GPBO_VERSION 110 /* 0.1.1: + gpbo_append_f64, host-pointer entry points */
 
 #define GPBO_OK 0
 #define GPBO_ERR_ARG (-1)      /* null pointer, bad size/alignment, unsupported d */
