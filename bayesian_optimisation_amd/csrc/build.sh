@@ -4,6 +4,9 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
+# GPBO_DIAG=1: also compile the timing-only kernel variants that tools/tile_stamps.py and the GPBO_*_VARIANT
+# environment switches select (wrong results by design; never in the shipped library)
+if [ "${GPBO_DIAG:-0}" = "1" ]; then FLAGS="$FLAGS -DGPBO_DIAGNOSTICS"; fi
 mkdir -p build
 pids=()
 for f in api kernel_build gemm_f64 factor update sigma_acq ard posterior_f32 host_api; do

@@ -296,15 +296,28 @@ extern "C" int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *Xsc
     if (rc != GPBO_OK) return rc;
     const int64_t used = (Mc + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
     dim3 grid((unsigned)(used / 512), (unsigned)(Np / KS_SLICE));
+    // Timing-only variants (1 = no stores, 3 = stores with a trivial body; wrong results) exist only in a diagnostics
+    // build (GPBO_DIAG=1 bayesian_optimisation_amd/csrc/build.sh); the shipped library has no switch into them.
+#ifdef GPBO_DIAGNOSTICS
     static const int variant = getenv("GPBO_KSTAR_VARIANT") ? atoi(getenv("GPBO_KSTAR_VARIANT")) : 0;
+#else
+    constexpr int variant = 0;
+#endif
 #define KSTAR_LAUNCH(DD, V, H)                                                                                       \
     hipLaunchKernelGGL((kstar_mu_kernel<DD, V, H>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, Xsc, (int)N, ls, \
                        alpha, diag_add, cand_base, KsT, ldk, mu_part)
+#ifdef GPBO_DIAGNOSTICS
 #define CALL(DD)                                        \
     if (diag_add != 0.0) KSTAR_LAUNCH(DD, 0, true);     \
     else if (variant == 1) KSTAR_LAUNCH(DD, 1, false);  \
     else if (variant == 3) KSTAR_LAUNCH(DD, 3, false);  \
     else KSTAR_LAUNCH(DD, 0, false)
+#else
+#define CALL(DD)                                        \
+    if (diag_add != 0.0) KSTAR_LAUNCH(DD, 0, true);     \
+    else KSTAR_LAUNCH(DD, 0, false)
+#endif
+    (void)variant;
     GPBO_DISPATCH_D(d, CALL)
 #undef CALL
     GPBO_CHECK_LAUNCH();

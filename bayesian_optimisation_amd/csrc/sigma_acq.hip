@@ -621,7 +621,13 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
         if (rc0 != GPBO_OK) return rc0;
     }
 
+    // Timing-only variants of the variance kernel (wrong results; tools/tile_stamps.py uses 6) exist only in a
+    // diagnostics build (GPBO_DIAG=1 build.sh): the shipped library has no switch into them.
+#ifdef GPBO_DIAGNOSTICS
     static const int variant = getenv("GPBO_SIGMA_VARIANT") ? atoi(getenv("GPBO_SIGMA_VARIANT")) : 0;
+#else
+    constexpr int variant = 0;
+#endif
     // Measured on MI355X (N=512, M=2^20): running K(X*,X) of chunk c+1 beside the variance kernel of chunk c gains
     // nothing - the variance launches slow down by what the overlap hides (0.59 -> 0.70 ms), i.e. fp64 VALU work
     // and fp64 MFMA work do not co-execute on gfx950.  Kept as an opt-in (GPBO_OVERLAP=1) for other shapes.
@@ -683,12 +689,17 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
                        mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                              \
                        acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count,                     \
                        (V == 6 && c == nchunks - 1 && nchunks > 1) ? KsT[(c + 1) & 1] : (double *)nullptr)
+#ifdef GPBO_DIAGNOSTICS
         if (variant == 1) GPBO_SIGMA_LAUNCH(1);
         else if (variant == 2) GPBO_SIGMA_LAUNCH(2);
         else if (variant == 3) GPBO_SIGMA_LAUNCH(3);
         else if (variant == 4) GPBO_SIGMA_LAUNCH(4);
         else if (variant == 6) GPBO_SIGMA_LAUNCH(6);
         else GPBO_SIGMA_LAUNCH(0);
+#else
+        (void)variant;
+        GPBO_SIGMA_LAUNCH(0);
+#endif
 #undef GPBO_SIGMA_LAUNCH
         if (rec) {
             if (hipEventRecord(reinterpret_cast<hipEvent_t>(prof->end[prof->count]), st) != hipSuccess)

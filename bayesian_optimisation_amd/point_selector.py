@@ -88,9 +88,11 @@ class PointSelector:
             print(*a)
 
     def _world(self):
+        if not self._shard:
+            return 1, 0
         import torch.distributed as dist
 
-        if self._shard and dist.is_available() and dist.is_initialized():
+        if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(), dist.get_rank()
         return 1, 0
 

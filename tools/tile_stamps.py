@@ -1,4 +1,5 @@
-"""Diagnostic (GPBO_SIGMA_VARIANT=6): per-tile s_memtime stamps of the variance kernel's first launch.
+"""Diagnostic (needs a diagnostics build of the library: GPBO_DIAG=1 bash bayesian_optimisation_amd/csrc/build.sh;
+GPBO_SIGMA_VARIANT=6): per-tile s_memtime stamps of the variance kernel's first launch.
 Prints the median duration (shader cycles, 100 MHz memtime ticks are converted by the caller's reading) per tile."""
 import os, sys
 os.environ["GPBO_SIGMA_VARIANT"] = "6"
