@@ -10,8 +10,8 @@
 //
 // Workgroup = 512 threads = 8 waves, owns 256 candidates end to end:
 //   for each 128-column block jb of V:   k runs over [0, 128*(jb+1))  (U is upper triangular)
-//       16-deep k tiles: KsT tile [16 x 256] and U tile [16 x 128] staged global -> VGPR -> LDS,
-//       double-buffered in LDS (one barrier per k tile), MFMA 4x4 tiles of 16x16 per wave;
+//       16-deep k tiles: KsT tile [16 x 256] and U tile [16 x 128] go global -> LDS directly (global_load_lds,
+//       three-stage ring, one barrier in the middle of each k tile), MFMA 4x4 tiles of 16x16 per wave;
 //       inside the diagonal block, 16x16 tiles of U that lie wholly below the diagonal are skipped
 //   epilogue: row-sum of squares -> sigma -> mean from the per-slice partials -> LCB / EI -> optional
 //   dense stores -> block arg-max carrying (value, lowest index).
@@ -27,9 +27,22 @@
 namespace {
 
 constexpr int BM = 256, BN = 128, BK = 16;  // candidates x columns of V per workgroup, k depth of a tile
-constexpr int WR = BM / 64;                // row groups of waves (64 candidates each)
-constexpr int WQ = 8 / WR;                 // column groups of waves; WR * WQ = 8 waves
-static_assert(BN / 16 / WQ == 4, "each wave owns four 16-column tiles");
+// Waves per workgroup and their split.  Measured on MI355X (N = 512): 8 waves as 4 x 2 (wave tile 64 x 64, two
+// waves per SIMD) run 0.547 ms per 2^17 candidates; 4 waves with 128 x 64 or 64 x 128 wave tiles (one wave per SIMD,
+// 256 accumulator registers) run 1.06 / 0.99 ms: hipcc spills 70-100 VGPRs around the tile loop and one wave
+// alone does not keep a SIMD's matrix pipe fed across the LDS reads and the barrier.
+#ifndef GPBO_NW
+#define GPBO_NW 8
+#endif
+#ifndef GPBO_WQ
+#define GPBO_WQ 2
+#endif
+constexpr int NW = GPBO_NW;                // waves per workgroup
+constexpr int WQ = GPBO_WQ;                // column groups of waves
+constexpr int WR = NW / WQ;                // row groups of waves (BM / WR candidates each)
+constexpr int MI = BM / WR / 16;           // 16-row tiles per wave
+constexpr int NI = BN / WQ / 16;           // 16-column tiles per wave
+static_assert(NI % 2 == 0 && (BM % (WR * 16)) == 0, "tile split");
 // (measured on MI355X, N = 512: 256 x 128 runs 0.596 ms per 2^17 candidates, 128 x 256 runs 0.635 ms - the
 //  wider column block has more k tiles on the diagonal whose MFMA time is shorter than their 48 KB of loads)
 constexpr int LDA = BM + 16;  // padded so lanes l and l+16 (k, k+1) of a ds_read_b64 group hit disjoint banks
@@ -63,7 +76,7 @@ __device__ __forceinline__ double acquisition(int kind, double mu, double sigma,
 }
 
 template <int VARIANT>  // 0 = product; 1, 2 = timing-only diagnostics (GPBO_SIGMA_VARIANT), wrong results
-__global__ __launch_bounds__(512) void sigma_acq_kernel(
+__global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
     const double *__restrict__ KsT, int64_t ldk, const double *__restrict__ U, int Np,
     const double *__restrict__ mu_part, int nsl, int64_t Mc, double prior_var, int acq_kind, double p0, double p1,
     int64_t idx_base, double *__restrict__ mu_out, double *__restrict__ sigma_out, double *__restrict__ acq_out,
@@ -85,29 +98,30 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     // piece is a 32-bit element offset fixed for the whole kernel, so one DMA costs a few scalar instructions.
     const double *a_base = KsT + cand0;
     constexpr int AP = BM / 128, BP = BN / 128;  // 1 KiB pieces per row
-    unsigned voffA[2 * AP], voffB[2 * BP];        // element offsets inside a tile (row * ld + piece * 128 + lane * 2)
-    int ldsA[2 * AP], ldsB[2 * BP];               // LDS element offsets of the pieces inside a stage
+    constexpr int NPA = BK * AP / NW, NPB = BK * BP / NW;  // 1-KiB pieces per wave per tile
+    unsigned voffA[NPA], voffB[NPB];        // element offsets inside a tile (row * ld + piece * 128 + lane * 2)
+    int ldsA[NPA], ldsB[NPB];               // LDS element offsets of the pieces inside a stage
 #pragma unroll
-    for (int r = 0; r < 2 * AP; ++r) {
-        const int u = wid + 8 * r, row = u / AP, piece = u % AP;
+    for (int r = 0; r < NPA; ++r) {
+        const int u = wid + NW * r, row = u / AP, piece = u % AP;
         voffA[r] = (unsigned)(row * (unsigned)ldk + piece * 128 + lane * 2);
         ldsA[r] = row * LDA + piece * 128;
     }
 #pragma unroll
-    for (int r = 0; r < 2 * BP; ++r) {
-        const int u = wid + 8 * r, row = u / BP, piece = u % BP;
+    for (int r = 0; r < NPB; ++r) {
+        const int u = wid + NW * r, row = u / BP, piece = u % BP;
         voffB[r] = (unsigned)(row * (unsigned)Np + piece * 128 + lane * 2);
         ldsB[r] = A_TILE + row * LDB + piece * 128;
     }
-    d4_t acc[4][4];
-    double ss[4][4];
+    d4_t acc[MI][NI];
+    double ss[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-            ss[i][j] = 0.0;
-        }
+        for (int j = 0; j < NI; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ss[i][j] = 0.0;
+    }
 
     const int nJ = Np / BN;
     // staging iterator: tile (pj, pk) goes to stage pbuf; pa / pb are its global bases
@@ -116,9 +130,9 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     auto stage_next = [&]() {
         double *St = smem + pbuf * STAGE;
 #pragma unroll
-        for (int r = 0; r < 2 * AP; ++r) glds16(pa + voffA[r], St + ldsA[r]);
+        for (int r = 0; r < NPA; ++r) glds16(pa + voffA[r], St + ldsA[r]);
 #pragma unroll
-        for (int r = 0; r < 2 * BP; ++r) glds16(pb + voffB[r], St + ldsB[r]);
+        for (int r = 0; r < NPB; ++r) glds16(pb + voffB[r], St + ldsB[r]);
         pbuf = (pbuf == 2) ? 0 : pbuf + 1;
         if (++pk == (pj + 1) * (BN / BK)) {  // next column block: k restarts, columns move right
             ++pj;
@@ -144,14 +158,14 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    double a0[4], b0[4], a1[4], b1[4];
-    auto lds_frag = [&](double (&af)[4], double (&bf)[4], int buf, int kk) {
+    double a0[MI], b0[NI], a1[MI], b1[NI];
+    auto lds_frag = [&](double (&af)[MI], double (&bf)[NI], int buf, int kk) {
         const double *As = smem + buf * STAGE;
         const double *Bs = As + A_TILE;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) af[mi] = As[(kk + l4) * LDA + wr * 64 + mi * 16 + l15];
+        for (int mi = 0; mi < MI; ++mi) af[mi] = As[(kk + l4) * LDA + wr * (BM / WR) + mi * 16 + l15];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[(kk + l4) * LDB + (WQ * ni + wq) * 16 + l15];
+        for (int ni = 0; ni < NI; ++ni) bf[ni] = Bs[(kk + l4) * LDB + (WQ * ni + wq) * 16 + l15];
     };
     lds_frag(a0, b0, 0, 0);
     int dbg_it = 0;
@@ -174,12 +188,12 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         int ni_min = (kt - jb * (BN / BK) - wq + WQ - 1) / WQ;
         ni_min = ni_min < 0 ? 0 : ni_min;
         if (VARIANT == 2) ni_min = 0;
-        auto mfma8 = [&](const double (&af)[4], const double (&bf)[4], int nlo) {
+        auto mfma8 = [&](const double (&af)[MI], const double (&bf)[NI], int nlo) {
 #pragma unroll
-            for (int ni = nlo; ni < nlo + 2; ++ni) {
+            for (int ni = nlo; ni < nlo + NI / 2; ++ni) {
                 if (FULL || ni >= ni_min) {
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf[ni], acc[mi][ni]);
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf[ni], acc[mi][ni]);
                 }
             }
         };
@@ -187,12 +201,12 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         mfma8(a0, b0, 0);
         lds_frag(a1, b1, cur, 4);
         __builtin_amdgcn_sched_barrier(0);
-        mfma8(a0, b0, 2);
+        mfma8(a0, b0, NI / 2);
         __builtin_amdgcn_sched_barrier(0);
         mfma8(a1, b1, 0);
         lds_frag(a0, b0, cur, 8);
         __builtin_amdgcn_sched_barrier(0);
-        mfma8(a1, b1, 2);
+        mfma8(a1, b1, NI / 2);
         __builtin_amdgcn_sched_barrier(0);
         if (VARIANT != 1 && VARIANT != 3) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own share of tile t+1 has landed
@@ -207,12 +221,12 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         mfma8(a0, b0, 0);
         lds_frag(a1, b1, cur, 12);
         __builtin_amdgcn_sched_barrier(0);
-        mfma8(a0, b0, 2);
+        mfma8(a0, b0, NI / 2);
         __builtin_amdgcn_sched_barrier(0);
         mfma8(a1, b1, 0);
         lds_frag(a0, b0, nxt, 0);  // first step of the next tile (stale but in-bounds after the last tile)
         __builtin_amdgcn_sched_barrier(0);
-        mfma8(a1, b1, 2);
+        mfma8(a1, b1, NI / 2);
         __builtin_amdgcn_sched_barrier(0);
         if (do_stage && wq != 0) stage_next();
         cur = nxt;
@@ -224,18 +238,18 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
         // column block finished: fold |V|^2 into the row sums
         if (vbuf && VARIANT != 6) {  // (wave-uniform) keep the block of V: row = candidate, 16 consecutive columns per lane group
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        vbuf[(cand0 + wr * 64 + mi * 16 + l4 + 4 * r) * (int64_t)Np + jb * BN + (WQ * ni + wq) * 16 + l15] =
+                        vbuf[(cand0 + wr * (BM / WR) + mi * 16 + l4 + 4 * r) * (int64_t)Np + jb * BN + (WQ * ni + wq) * 16 + l15] =
                             acc[mi][ni][r];
         }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ss[mi][r] = fma(acc[mi][ni][r], acc[mi][ni][r], ss[mi][r]);
                 acc[mi][ni] = d4_t{0.0, 0.0, 0.0, 0.0};
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
     __syncthreads();
     double *red = smem;  // [WQ][BM]
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double v = ss[mi][r];
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(512) void sigma_acq_kernel(
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 8);
-            if (l15 == 0) red[wq * BM + wr * 64 + mi * 16 + l4 + 4 * r] = v;
+            if (l15 == 0) red[wq * BM + wr * (BM / WR) + mi * 16 + l4 + 4 * r] = v;
         }
     __syncthreads();
 
@@ -684,7 +698,7 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
         if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
 #define GPBO_SIGMA_LAUNCH(V)                                                                                        \
-    hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(512), 0, st, KsT[b], chunk, U, (int)Np,          \
+    hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT[b], chunk, U, (int)Np,          \
                        mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,               \
                        mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                              \
                        acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count,                     \
@@ -790,7 +804,7 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
         if (rc != GPBO_OK) return rc;
         const int64_t nblk = (Mc + BM - 1) / BM;
         // the variance kernel also leaves V (vbuf) and mu; its own single-point acquisition result is ignored
-        hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk), dim3(512), 0, st, KsT, chunk, U, (int)Np, mu_part,
+        hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
                            (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
                            (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb);
         GPBO_CHECK_LAUNCH();
