@@ -73,6 +73,30 @@ class GpboError(RuntimeError):
     pass
 
 
+def _bind_to_pytorch_hip_runtime():
+    """Two HIP runtimes in one process do not share the device: whichever initialises second sees no GPU.
+    PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's, which libgpbo.so would otherwise pull in).
+    If PyTorch is installed but not imported yet (the NumPy-only host binding), load ITS runtime first, so that a
+    later `import torch` in the same process finds the runtime it expects already in place.  Nothing is imported."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # its runtime is loaded; libgpbo.so's NEEDED libamdhip64.so.7 resolves to it
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        try:
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime
+
+
 def load():
     """Load libgpbo.so and attach prototypes.  Raises if the library or any symbol is missing."""
     global _lib
@@ -82,6 +106,7 @@ def load():
         raise GpboError(
             f"{LIB_PATH} not found: build it with bayesian_optimisation_amd/csrc/build.sh "
             "(there is no CPU fallback for the acquisition path)")
+    _bind_to_pytorch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

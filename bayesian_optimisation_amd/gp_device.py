@@ -120,6 +120,7 @@ class DeviceGP:
             self.N, self.Np, self.d = N, Np, d
             self.jitter1, self.jitter2 = float(jitter1), float(jitter2)
             self._owns_xy = False
+            self.n_appended = 0  # columns of U built by append() since the last full factorisation
             if getattr(self, "K", None) is None or self.K.shape[0] != Np or self.U.shape[0] != Np:
                 # the factor buffers (and the workspace) are kept from step to step: a BO loop refactorises
                 # at the same padded size many times, and fresh 100-MB allocations cost more than the kernels
@@ -166,7 +167,10 @@ class DeviceGP:
     def append(self, x_new, y_new, check: bool = True):
         """Add one observation to the factorised surrogate in O(N^2): column N of U, alpha recomputed.
         The length scales and jitters stay those of the last factorise() - the caller decides when they may
-        (the reference re-tunes them every iteration, point_selector.py:60-62, and then a full factorise() is due)."""
+        (the reference re-tunes them every iteration, point_selector.py:60-62, and then a full factorise() is due).
+        An appended column goes through the explicit inverse factor (l = U^T k), so it carries cond(L) eps of
+        relative error where the blocked Cholesky is backward stable: `n_appended` counts the columns built this way
+        since the last full factorisation, for callers that want to refresh after a while (PointSelector does)."""
         torch = self.torch
         if self.N < 1:
             raise _lib.GpboError("append() needs a factorised surrogate")
@@ -203,6 +207,7 @@ class DeviceGP:
             else:
                 torch.cuda.current_stream(self.device).synchronize()  # xn / yn / work must outlive the kernels
             self.N = N + 1
+            self.n_appended += 1
             del work
         return self
 
@@ -211,6 +216,7 @@ class DeviceGP:
         """Host copy of everything append()/score() need (the N x N part of the factors, not the padding)."""
         N = self.N
         return dict(version=1, N=N, d=self.d, ls=np.array(self.ls_h), jitter1=self.jitter1, jitter2=self.jitter2,
+                    n_appended=self.n_appended,
                     X=self.X[:N].cpu().numpy(), y=self.y[:N].cpu().numpy(), K=self.K[:N, :N].cpu().numpy(),
                     U=self.U[:N, :N].cpu().numpy(), alpha=self.alpha[:N].cpu().numpy())
 
@@ -224,6 +230,7 @@ class DeviceGP:
             self.N, self.Np, self.d = N, Np, d
             self.ls_h = np.ascontiguousarray(np.asarray(st["ls"], dtype=np.float64).reshape(-1))
             self.jitter1, self.jitter2 = float(st["jitter1"]), float(st["jitter2"])
+            self.n_appended = int(st["n_appended"]) if "n_appended" in st else 0
             self.X = torch.zeros((Np, d), dtype=torch.float64, device=self.device)
             self.y = torch.zeros(Np, dtype=torch.float64, device=self.device)
             self.X[:N] = self._dev(st["X"])

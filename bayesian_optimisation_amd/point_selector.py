@@ -31,6 +31,7 @@ from .gp_device import JITTER_ASSEMBLY, JITTER_KERNEL, PRIOR_VAR, DeviceGP
 COV_PRED_MAX_M = 4096          # cov_pred is M x M: 128 MiB at this size
 COV_MEAS_PRED_MAX = 1 << 24    # entries of the (M, N) cross covariance kept for inspection
 MAX_APPEND_ROWS = 64           # more new rows than this: a fresh factorisation is cheaper than row-by-row appends
+MAX_APPENDED_COLUMNS = 256     # columns built by appends since the last full factorisation before a refresh is due
 
 
 def _plot_hooks():
@@ -177,6 +178,7 @@ class PointSelector:
                 X0, y0, ls0 = self._inc
                 n0 = len(X0)
                 if (n0 < len(X) <= n0 + MAX_APPEND_ROWS and gp.N == n0 and X0.shape[1:] == X.shape[1:]
+                        and gp.n_appended + (len(X) - n0) <= MAX_APPENDED_COLUMNS
                         and ls0.shape == ls.shape and np.array_equal(ls0, ls)
                         and gp.jitter1 == JITTER_KERNEL and gp.jitter2 == JITTER_ASSEMBLY
                         and np.array_equal(X[:n0], X0) and np.array_equal(y[:n0], y0)):

@@ -158,3 +158,22 @@ def test_point_selector_incremental_and_state_file(tmp_path):
     y[3] += 1.0
     run(other, 24, np.array([0.31, 0.5]))
     assert other.last_update == "factorise"
+
+
+def test_point_selector_refreshes_after_many_appended_columns(monkeypatch):
+    """Appended columns go through the explicit inverse factor; after MAX_APPENDED_COLUMNS of them the class takes
+    the full factorisation again."""
+    from bayesian_optimisation_amd import PointSelector
+    from bayesian_optimisation_amd import point_selector as PS
+
+    monkeypatch.setattr(PS, "MAX_APPENDED_COLUMNS", 3)
+    X, y, Xs, ls = make_problem(16, 400, 2)
+    ps = PointSelector(incremental=True)
+    seen = []
+    for n in range(10, 17):
+        ps.measured_pts, ps.measured_vals = X[:n].copy(), y[:n].copy()
+        ps.feature_domain, ps.predicted_pts = [20, 20], Xs
+        ps.set_kernel_params(ls)
+        ps.update_surrogate()
+        seen.append(ps.last_update)
+    assert seen == ["factorise", "append", "append", "append", "factorise", "append", "append"]

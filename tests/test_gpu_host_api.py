@@ -141,3 +141,26 @@ def test_host_binding_runs_without_pytorch_in_the_process():
     out = subprocess.run([sys.executable, "-c", code, fixture], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().startswith("ok")
+
+
+def test_host_route_first_then_pytorch_in_the_same_process():
+    """libgpbo.so must bind to the HIP runtime PyTorch ships: with two runtimes in one process the second one to
+    initialise sees no GPU (observed: torch.cuda.is_available() False after a host-pointer call)."""
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {REPO!r})\n"
+        "from bayesian_optimisation_amd import host_binding as H\n"
+        "rng = np.random.default_rng(0)\n"
+        "X, y, Xs = rng.uniform(0, 1, (10, 2)), rng.standard_normal(10), rng.uniform(0, 1, (100, 2))\n"
+        "r = H.select_next(X, y, [0.3, 0.3], Xs)\n"
+        "assert 'torch' not in sys.modules\n"
+        "import torch\n"
+        "assert torch.cuda.is_available(), 'PyTorch lost the GPU'\n"
+        "from bayesian_optimisation_amd import DeviceGP\n"
+        "q = DeviceGP(chunk=512).factorise(X, y, [0.3, 0.3]).score(Xs, dense=True)\n"
+        "assert q.best_idx == r['best_idx'] and np.array_equal(q.mu.cpu().numpy(), r['mu'])\n"
+        "print('ok')\n"
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().endswith("ok")
