@@ -314,6 +314,46 @@ def test_config3_shape_n4096_subsampled():
         assert sub[_first_argmax(acq_o)] == r.best_idx
 
 
+def test_config4_shape_n8192_fp32_subsampled():
+    """BASELINE config 4 per-GPU shape (d=16, N=8192, fp64 factorisation + fp32 scoring): oracle on a sub-sample;
+    chunk invariance of the arg-max; the fp64 factorisation itself against the oracle's alpha."""
+    N, M, d = 8192, 1 << 14, 16
+    X, y, Xs, ls = make_problem(N, M, d)
+    gp = DeviceGP(chunk=1 << 13).factorise(X, y, ls)
+    _, _, alpha_o = O.factorise(X, y, ls)
+    a = gp.alpha[:N].cpu().numpy()
+    assert np.max(np.abs(a - alpha_o)) <= 1e-7 * np.abs(alpha_o).max()
+    r = gp.score_f32(Xs, dense=True)
+    mu, sig, acq = r.mu.cpu().numpy().astype(np.float64), r.sigma.cpu().numpy().astype(np.float64), r.acq.cpu().numpy()
+    assert r.nan_count == 0 and r.best_idx == _first_argmax(acq)
+    sub = np.unique(np.concatenate([np.random.default_rng(4).choice(M, 256, replace=False), np.argsort(acq)[-16:]]))
+    mu_o, sig_o = O.posterior_chol(X, y, Xs[sub], ls)
+    tol_mu = 5e-3 + 1e-6 * float(np.abs(alpha_o).sum())      # fp32 k* against alpha (see DESIGN.md)
+    assert np.max(np.abs(mu[sub] - mu_o)) <= tol_mu
+    assert np.max(np.abs(sig[sub] ** 2 - sig_o ** 2)) <= 5e-3
+    r2 = DeviceGP(chunk=1 << 12).factorise(X, y, ls).score_f32(Xs)
+    assert (r2.best_idx, r2.best_val) == (r.best_idx, r.best_val)
+
+
+def test_config5_shape_qei_n2048_subsampled():
+    """BASELINE config 5 shape (q=8, S=512, d=8, N=2048): oracle qEI on a sub-sample of the batches."""
+    N, M, d = 2048, 1 << 13, 8
+    X, y, Xs, ls = make_problem(N, M, d)
+    Z = O.qei_base_samples(512, 8, 7)
+    f_best = float(y.min())
+    gp = DeviceGP(chunk=1 << 12).factorise(X, y, ls)
+    r = gp.score_qei(Xs, Z, f_best, dense=True)
+    got = r.acq.cpu().numpy()
+    assert r.nan_count == 0 and r.best_idx == _first_argmax(got) and r.best_val == got.max()
+    batches = np.unique(np.concatenate([np.random.default_rng(5).choice(M // 8, 48, replace=False), np.argsort(got)[-8:]]))
+    rows = (batches[:, None] * 8 + np.arange(8)).ravel()
+    ref = O.qei_mc(X, y, Xs[rows], ls, Z, f_best)
+    assert np.max(np.abs(got[batches] - ref)) <= 1e-8 * max(1.0, np.abs(y).max())
+    top2 = np.sort(ref)[-2:]
+    if top2[1] - top2[0] > 1e-7:
+        assert batches[_first_argmax(ref)] == r.best_idx
+
+
 # ----------------------------------------------------------------------------------------------
 # edge shapes: padding boundaries of N (128), of the candidate tiles (256) and chunks (512), every feature count
 # ----------------------------------------------------------------------------------------------
