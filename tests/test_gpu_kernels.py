@@ -85,7 +85,7 @@ def test_kxx(env, N, d):
     assert np.array_equal(pad, expect)
 
 
-@pytest.mark.parametrize("n", [128, 256, 384, 640, 1024])
+@pytest.mark.parametrize("n", [128, 256, 384, 640, 1024, 4096, 4288])  # >= 4096: two block columns per trailing update
 def test_potrf_trtri_alpha(env, n):
     t, lib = env.torch, env.lib
     A = _spd(n, n)
