@@ -57,7 +57,11 @@ class DeviceGP:
         self._work_post = None
         self._work_fact = None
         self.K = self.U = self.alpha = None
-        self._result = torch.zeros(4, dtype=torch.int64, device=self.device)
+        # the 32-byte result record and the factorisation's info word share one small buffer, so that a step can read
+        # both back with a single device-to-host copy (each copy is a host synchronisation)
+        self._status = torch.zeros(5, dtype=torch.int64, device=self.device)
+        self._result = self._status[:4]
+        self.info = self._status[4:5].view(torch.int32)[:1]
         self._profile = C.c_void_p(0)
 
     # -- per-launch timing of the dominant kernel (bench.py) -----------------------------------------
@@ -127,7 +131,6 @@ class DeviceGP:
                 self.K = torch.empty((Np, Np), dtype=torch.float64, device=self.device)
                 self.U = torch.empty((Np, Np), dtype=torch.float64, device=self.device)
                 self.alpha = torch.empty(Np, dtype=torch.float64, device=self.device)
-                self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
                 self._work_fact = None
             self.U32 = None
             wbytes = int(self.lib.gpbo_factorise_workspace_bytes(Np))
@@ -243,7 +246,7 @@ class DeviceGP:
                 setattr(self, name, m)
             self.alpha = torch.zeros(Np, dtype=torch.float64, device=self.device)
             self.alpha[:N] = self._dev(st["alpha"]).reshape(-1)
-            self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.info.zero_()
             self.U32 = None
             self._work_post = None
         return self
@@ -379,6 +382,12 @@ class DeviceGP:
             _lib.check(st, "gpbo_posterior_qei_f64")
             v, i, n = self.read_result(self._result)
         return ScoreResult(v, i, n, None, None, qei)
+
+    def read_result_and_info(self) -> tuple:
+        """(best value, best index, NaN count, info of the last factorise/append) with one device-to-host copy."""
+        r = self._status.cpu()  # synchronises
+        best_val = float(r[:1].view(self.torch.float64)[0])
+        return best_val, int(r[1]), int(r[2]), int(r[4:5].view(self.torch.int32)[0])
 
     def read_result(self, result_tensor) -> tuple:
         r = result_tensor.cpu()  # synchronises

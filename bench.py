@@ -129,9 +129,9 @@ def main():
         gp.factorise(Xd, yd, ls, check=False)
         if f32:
             gp.prepare_f32()
-        res, _, _, _ = score_async()
-        v, i, n = gp.read_result(res)               # 32-byte read-back (synchronises this rank)
-        if int(gp.info.item()) != 0:
+        score_async()
+        v, i, n, info = gp.read_result_and_info()   # one 40-byte read-back (synchronises this rank)
+        if info != 0:
             raise RuntimeError("Cholesky failed")
         return D.allreduce_argmax(v, i, n, force_collective=args.force_process_group)  # the one exchange step (no-op at N=1)
 
