@@ -62,6 +62,33 @@ def allreduce_argmax(best_val: float, best_idx: int, nan_count: int, group=None,
     return reduce_records(recs)
 
 
+def allreduce_status(status, group=None, force_collective: bool = False):
+    """The exchange step straight from the device record: `status` is DeviceGP's int64[5] buffer (gpbo_result:
+    value bits, index, NaN count, reserved; then the factorisation's info word).  On nccl (= RCCL) the record is
+    gathered from device memory as it is - no host round trip before the collective - and read back once.
+    Returns (best value, lowest index, NaN total, first non-zero info over the ranks or 0)."""
+    import torch
+    import torch.distributed as dist
+
+    def parse(rows):
+        recs, info = [], 0
+        for b, i, n, _, w in rows:
+            recs.append((struct.unpack("<d", struct.pack("<q", b))[0], i, n))
+            w32 = w & 0xFFFFFFFF
+            if info == 0 and w32:
+                info = w32 - (1 << 32) if w32 >= (1 << 31) else w32
+        return reduce_records(recs) + (info,)
+
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1
+                                                                and not force_collective):
+        return parse([status.cpu().tolist()])
+    world = dist.get_world_size(group)
+    src = status if dist.get_backend(group) == "nccl" else status.cpu()
+    out = torch.empty(world * 5, dtype=torch.int64, device=src.device)
+    dist.all_gather_into_tensor(out, src.contiguous(), group=group)
+    return parse(out.cpu().view(world, 5).tolist())
+
+
 def gather_concat(local, total: int, group=None):
     """Concatenation, in rank order, of the contiguous shards produced under shard_bounds (dense mu / sigma /
     acquisition arrays, the ARD likelihood grid).  Every rank gets the full array; bytes travel unchanged.

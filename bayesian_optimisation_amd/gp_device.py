@@ -383,6 +383,12 @@ class DeviceGP:
             v, i, n = self.read_result(self._result)
         return ScoreResult(v, i, n, None, None, qei)
 
+    @property
+    def status(self):
+        """Device int64[5]: the gpbo_result record of the last scoring call + the info word of the last factorisation
+        (what distributed.allreduce_status gathers over the ranks)."""
+        return self._status
+
     def read_result_and_info(self) -> tuple:
         """(best value, best index, NaN count, info of the last factorise/append) with one device-to-host copy."""
         r = self._status.cpu()  # synchronises

@@ -130,10 +130,12 @@ def main():
         if f32:
             gp.prepare_f32()
         score_async()
-        v, i, n, info = gp.read_result_and_info()   # one 40-byte read-back (synchronises this rank)
+        # the one exchange step: the 40-byte device record (result + factorisation info) is gathered over the ranks
+        # and read back once (at N=1: just the read-back, which synchronises this rank)
+        v, i, n, info = D.allreduce_status(gp.status, force_collective=args.force_process_group)
         if info != 0:
             raise RuntimeError("Cholesky failed")
-        return D.allreduce_argmax(v, i, n, force_collective=args.force_process_group)  # the one exchange step (no-op at N=1)
+        return v, i, n
 
     def fence():
         if use_pg:

@@ -62,6 +62,14 @@ def _worker(rank, world, port, q):
             ok_gather = False
         except ValueError:
             pass
+        # the device-record form of the exchange (CPU tensors on gloo): rank 1 carries a failed factorisation
+        import struct
+
+        import torch
+
+        bits = struct.unpack("<q", struct.pack("<d", float(loc[j])))[0]
+        status = torch.tensor([bits, lo + j, 0, 0, 0 if rank == 0 else 17], dtype=torch.int64)
+        ok_gather = ok_gather and D.allreduce_status(status) == (5.0, 100, 0, 17)
         q.put((rank, out, out2, ok_gather))
     finally:
         dist.destroy_process_group()
@@ -91,3 +99,14 @@ def test_gather_concat_without_a_process_group():
     assert D.gather_concat(a, 7) is not None and np.array_equal(D.gather_concat(a, 7), a)
     with pytest.raises(ValueError):
         D.gather_concat(a, 8)
+
+
+def test_allreduce_status_without_a_process_group():
+    import struct
+
+    import torch
+
+    bits = struct.unpack("<q", struct.pack("<d", -2.5))[0]
+    assert D.allreduce_status(torch.tensor([bits, 42, 3, 0, 0], dtype=torch.int64)) == (-2.5, 42, 3, 0)
+    neg = (-7) & 0xFFFFFFFF  # an int32 info word of -7 in the low half of the slot
+    assert D.allreduce_status(torch.tensor([bits, 42, 0, 0, neg], dtype=torch.int64))[3] == -7

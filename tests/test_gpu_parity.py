@@ -522,6 +522,12 @@ def test_exchange_step_over_rccl_in_a_one_rank_group():
             assert (i, n) == (rec[1], rec[2]) and np.float64(v).tobytes() == np.float64(rec[0]).tobytes()
         v, i, n = D.allreduce_argmax(float("nan"), 4, 2, force_collective=True)
         assert n == 2 and v == float("-inf")  # a NaN record never wins; it is reported through the count
+        # the same exchange straight from DeviceGP's device record (what bench.py's step does)
+        X, y, Xs, ls = make_problem(30, 700, 3)
+        gp = DeviceGP(chunk=512).factorise(X, y, ls)
+        q = gp.score(Xs, idx_offset=11)
+        assert D.allreduce_status(gp.status, force_collective=True) == (q.best_val, q.best_idx, 0, 0)
+        assert D.allreduce_status(gp.status) == (q.best_val, q.best_idx, 0, 0)
         t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)   # bench.py's max-over-ranks timing
         dist.barrier()
