@@ -29,6 +29,8 @@ __device__ __forceinline__ d4_t mfma_f64_16x16x4(double a, double b, d4_t c) {
 // launchers implemented in the individual .hip files (host side, enqueue only)
 int gpbo_kxx_launch(const double *X, int64_t N, int32_t d, const double *ls_host, double jitter1, double jitter2,
                     double *Kp, int64_t Np, double *K2, int32_t *info0, void *stream);
+int gpbo_scale_points_launch(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host, double *Xsc,
+                             unsigned long long *zero_word, void *stream);
 int gpbo_launch_transpose_upper(const double *W, int64_t Np, double *U, hipStream_t st);
 int gpbo_launch_argmax_finish(const double *part_val, const int64_t *part_idx, int64_t nparts,
                               const unsigned long long *nan_count, gpbo_result *result, hipStream_t st);

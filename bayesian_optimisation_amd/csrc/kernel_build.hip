@@ -209,8 +209,11 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
 
 // Xsc[n][k] = X[n][k] / (ls_k sqrt 2), rows n >= N zero.   One thread per element.
 __global__ __launch_bounds__(256) void scale_points_kernel(const double *__restrict__ X, int64_t N, int64_t Np, int d,
-                                                          LsArgs ls, double *__restrict__ Xsc) {
+                                                          LsArgs ls, double *__restrict__ Xsc,
+                                                          unsigned long long *__restrict__ zero_word /* optional:
+                                                          cleared here (the posterior's NaN counter), saving a memset */) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (zero_word && e == 0) *zero_word = 0ull;
     if (e >= Np * d) return;
     const int64_t n = e / d;
     const int k = (int)(e - n * d);
@@ -272,17 +275,22 @@ extern "C" int gpbo_kxx_f64(const double *X, int64_t N, int32_t d, const double 
     return gpbo_kxx_launch(X, N, d, ls_host, jitter1, jitter2, Kp, Np, nullptr, nullptr, stream);
 }
 
-extern "C" int gpbo_scale_points_f64(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host,
-                                     double *Xsc, void *stream) {
+int gpbo_scale_points_launch(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host, double *Xsc,
+                             unsigned long long *zero_word, void *stream) {
     if (!X || !Xsc || N < 1 || Np < N) return GPBO_ERR_ARG;
     LsArgs ls;
     int rc = make_ls(ls_host, d, &ls);
     if (rc != GPBO_OK) return rc;
     const int64_t tot = Np * d;
     hipLaunchKernelGGL(scale_points_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, gpbo_stream(stream), X, N,
-                       Np, (int)d, ls, Xsc);
+                       Np, (int)d, ls, Xsc, zero_word);
     GPBO_CHECK_LAUNCH();
     return GPBO_OK;
+}
+
+extern "C" int gpbo_scale_points_f64(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host,
+                                     double *Xsc, void *stream) {
+    return gpbo_scale_points_launch(X, N, Np, d, ls_host, Xsc, nullptr, stream);
 }
 
 extern "C" int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,

@@ -629,9 +629,9 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
     double *part_val = reinterpret_cast<double *>(w + L.pval_off);
     int64_t *part_idx = reinterpret_cast<int64_t *>(w + L.pidx_off);
     unsigned long long *nan_count = reinterpret_cast<unsigned long long *>(w + L.nan_off);
-    if (hipMemsetAsync(nan_count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
     {
-        int rc0 = gpbo_scale_points_f64(X, N, Np, d, ls_host, Xsc, stream);  // observations / (ls sqrt 2), once
+        // observations / (ls sqrt 2), once per call; the same launch clears the NaN counter
+        int rc0 = gpbo_scale_points_launch(X, N, Np, d, ls_host, Xsc, nan_count, stream);
         if (rc0 != GPBO_OK) return rc0;
     }
 
