@@ -30,7 +30,8 @@ constexpr int BM = 256, BN = 128, BK = 16;  // candidates x columns of V per wor
 // Waves per workgroup and their split.  Measured on MI355X (N = 512): 8 waves as 4 x 2 (wave tile 64 x 64, two
 // waves per SIMD) run 0.547 ms per 2^17 candidates; 4 waves with 128 x 64 or 64 x 128 wave tiles (one wave per SIMD,
 // 256 accumulator registers) run 1.06 / 0.99 ms: hipcc spills 70-100 VGPRs around the tile loop and one wave
-// alone does not keep a SIMD's matrix pipe fed across the LDS reads and the barrier.
+// alone does not keep a SIMD's matrix pipe fed across the LDS reads and the barrier; 16 waves (four per SIMD, wave
+// tile 32 x 64 or 64 x 32) run 0.560 / 0.594 ms: half again as many LDS fragment reads per MFMA.
 #ifndef GPBO_NW
 #define GPBO_NW 8
 #endif
