@@ -131,12 +131,14 @@ int gpbo_gemm_launch(int transB, int64_t M, int64_t N, int64_t K, double alpha, 
     if (!A || !B || !C || M % 64 || N % 64 || K % BK || K <= 0 || (lda & 1) || (ldb & 1)) return GPBO_ERR_ARG;
     if (((uintptr_t)A | (uintptr_t)B) & 15) return GPBO_ERR_ARG;
     if (N / 32 > 65535 || M / 32 > 65535 || batch > 65535) return GPBO_ERR_ARG;
-    // small products (fewer 64 x 64 tiles than half the CUs of the device): 32 x 32 tiles, four times the workgroups
+    // up to 2048 tiles of 64 x 64 (8 per CU) the 32 x 32 variant wins: four times the workgroups, a quarter of the
+    // dependent MFMAs per k tile.  Measured, whole factorisation in ms with the switch at 128 / 512 / 2048 / 8192 tiles:
+    // N = 2048: 1.28 / 1.17 / 1.17 / 1.18;  N = 4096: 3.55 / 3.48 / 3.41 / 3.41;  N = 8192: 15.1 / - / 14.7 / 16.1
     int64_t tiles64 = (M / 64) * (N / 64) * batch;
     if (lower_only) tiles64 = (M / 64) * (M / 64 + 1) / 2 * batch;
     // (not when C aliases an operand: the in-place panel solve relies on one workgroup owning a whole 64-row tile,
     //  which it reads completely before it writes)
-    const bool small = tiles64 < 128 && C != A && C != B;
+    const bool small = tiles64 < 2048 && C != A && C != B;
     const int T = small ? 32 : 64;
     dim3 grid((unsigned)(N / T), (unsigned)(M / T), (unsigned)batch);
 #define GPBO_GEMM_LAUNCH(TB, TT)                                                                                        \
