@@ -109,7 +109,7 @@ while time.time() < t_end:
                 print("case", n_cases, tag, flush=True)
             mu_o, sig_o = O.posterior_chol(X, y, Xs, ls)
             gp = DeviceGP().factorise(X, y, ls)
-            r = gp.score_f32(Xs, dense=True)
+            r = gp.score_f32(Xs, dense=True, diag_add=1e-4 if Xs.shape == X.shape else 0.0)  # point_selector.py:173
             mu, sig, acq = r.mu.cpu().numpy(), r.sigma.cpu().numpy(), r.acq.cpu().numpy()
             # fp32 scoring: k* carries ~2^-23 relative error, so mu = k* . alpha is off by up to ~|alpha|_1 2^-22 (alpha
             # has huge alternating entries when K is ill-conditioned: many points in few dimensions); sigma^2 is a

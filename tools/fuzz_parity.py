@@ -74,6 +74,8 @@ while time.time() < t_end:
         # the stated fp64 tolerance of the path: random 1-D problems with hundreds of points reach
         # cond(K) ~ 1e7, beyond the order-tighter bound the fixed test problems meet
         tol_mu, tol_sig = 1e-9, 1e-8
+        if d <= 2 and N > 100:  # hundreds of points on a line or in a plane: cond(K) ~ N / 1e-4, the two Cholesky
+            tol_mu = 3e-9       # routes (oracle, device) then differ by up to ~cond eps each
         if route == "append":  # hundreds of columns built through the explicit inverse: cond(L) eps each
             tol_mu, tol_sig = 5e-9, 5e-8
         ok = nanc == 0 and e_mu <= tol_mu and e_sig <= tol_sig and bi == off + first_argmax(acq)
