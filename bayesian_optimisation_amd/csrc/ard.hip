@@ -3,7 +3,8 @@
 // Replaces PointSelector.tune_kernel / eval_log_marginal (/root/reference/point_selector.py:104-163):
 //     rbf = kernel_rbf(X, X)            (1e-4 jitter only, :116,193)
 //     nlml = 0.5 * (y^T inv(rbf) y + log(det(rbf)) + N log(2 pi))          (:117-119), stored as float32
-// One workgroup per grid cell.  The reference's inv + det become one Cholesky of the bordered matrix
+// One workgroup per grid cell (N <= 176: the packed lower triangle fits in LDS).  The reference's inv + det become
+// one Cholesky of the bordered matrix
 //     [ K   y ]
 //     [ y^T 0 ]
 // carried N columns deep in LDS: the last row then holds (L^-1 y)^T, the last pivot is -y^T K^-1 y,
@@ -16,15 +17,16 @@
 
 namespace {
 
-constexpr int ARD_MAX_N = 128;
+constexpr int ARD_MAX_N = 176;  // packed lower triangle of the (N+1) x (N+1) bordered matrix + X in LDS: 150 KB at d = 16
 
 __global__ __launch_bounds__(256) void nlml_grid_kernel(const double *__restrict__ X, const double *__restrict__ y,
                                                         int N, int d, const double *__restrict__ ls_cells,
                                                         double jitter, float *__restrict__ out) {
     extern __shared__ double lds[];
-    const int ld = N + 2;              // bordered matrix is (N+1) x (N+1); +1 more to break bank strides
-    double *a = lds;                   // (N+1) x ld
-    double *xs = a + (N + 1) * ld;     // N x d
+    // bordered matrix (N+1) x (N+1), lower triangle only, packed by rows: entry (r, q <= r) at r (r + 1) / 2 + q
+    auto tri = [](int r, int q) { return r * (r + 1) / 2 + q; };
+    double *a = lds;                   // (N+1) (N+2) / 2
+    double *xs = a + (N + 1) * (N + 2) / 2;  // N x d
     double *il2 = xs + N * d;          // d
     double *diag = il2 + d;            // N   (L_ii)
     const int tid = threadIdx.x;
@@ -36,8 +38,9 @@ __global__ __launch_bounds__(256) void nlml_grid_kernel(const double *__restrict
     const int n1 = N + 1;
     for (int e = tid; e < n1 * n1; e += 256) {
         const int r = e / n1, q = e - r * n1;
+        if (q > r) continue;
         double v = 0.0;
-        if (q <= r) {
+        {
             if (r < N) {
                 double acc = 0.0;
                 for (int k = 0; k < d; ++k) {
@@ -50,11 +53,11 @@ __global__ __launch_bounds__(256) void nlml_grid_kernel(const double *__restrict
                 v = y[q];
             }
         }
-        a[r * ld + q] = v;
+        a[tri(r, q)] = v;
     }
     for (int c = 0; c < N; ++c) {
         __syncthreads();
-        const double piv = a[c * ld + c];
+        const double piv = a[tri(c, c)];
         const double dd = sqrt(piv);   // NaN for a negative pivot: propagates to the cell's value
         const double inv = 1.0 / dd;
         if (tid == 0) diag[c] = dd;
@@ -63,9 +66,9 @@ __global__ __launch_bounds__(256) void nlml_grid_kernel(const double *__restrict
         for (int e = tid; e < m * m; e += 256) {
             const int r = c + 1 + e / m, q = c + 1 + (e - (e / m) * m);
             if (q <= r) {
-                const double lr = a[r * ld + c] * inv;
-                const double lq = a[q * ld + c] * inv;
-                a[r * ld + q] = fma(-lr, lq, a[r * ld + q]);
+                const double lr = a[tri(r, c)] * inv;
+                const double lq = a[tri(q, c)] * inv;
+                a[tri(r, q)] = fma(-lr, lq, a[tri(r, q)]);
             }
         }
     }
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void nlml_grid_kernel(const double *__restrict
         double logdet = 0.0;
         for (int c = 0; c < N; ++c) logdet += log(diag[c]);
         logdet *= 2.0;
-        const double quad = -a[N * ld + N];
+        const double quad = -a[tri(N, N)];
         const double logdet_ref = log(exp(logdet));  // the reference takes log of an underflowing det
         const double nlml = 0.5 * (quad + logdet_ref + (double)N * 1.8378770664093453);  // log(2 pi)
         out[blockIdx.x] = (float)nlml;
@@ -125,7 +128,7 @@ extern "C" int gpbo_nlml_grid_f64(const double *X, const double *y, int64_t N, i
     if (!X || !y || !ls_cells || !out || N < 1 || N > ARD_MAX_N || d < 1 || d > GPBO_MAX_D || G < 1 ||
         G > (1 << 30))
         return GPBO_ERR_ARG;
-    const size_t lds_bytes = sizeof(double) * ((size_t)(N + 1) * (N + 2) + (size_t)N * d + d + N);
+    const size_t lds_bytes = sizeof(double) * ((size_t)(N + 1) * (N + 2) / 2 + (size_t)N * d + d + N);
     if (lds_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(nlml_grid_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)

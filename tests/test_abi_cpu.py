@@ -45,7 +45,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.gpbo_posterior_workspace_bytes(128, 500, 10) == -1      # chunk not a multiple of 512
     assert lib.gpbo_posterior_workspace_bytes(128, 512, 1000) > 128 * 512 * 8
     assert lib.gpbo_factorise_workspace_bytes(256) == 8 * (2 * 256 * 256 + 256 * 64 + 256)
-    assert lib.gpbo_nlml_grid_max_n() == 128
+    assert lib.gpbo_nlml_grid_max_n() == 176
 
 
 def test_every_compute_entry_point_rejects_null_arguments():
@@ -98,7 +98,7 @@ def test_size_contracts_are_checked_on_the_host():
     assert lib.gpbo_potrf_f64(p, 100, p, p, None) == -1
     assert lib.gpbo_trtri_f64(p, p, 100, p, p, None) == -1
     # ARD grid: N beyond the in-LDS limit
-    assert lib.gpbo_nlml_grid_f64(p, p, 129, 2, p, 4, 1e-4, p, None) == -1
+    assert lib.gpbo_nlml_grid_f64(p, p, 177, 2, p, 4, 1e-4, p, None) == -1
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -109,7 +109,7 @@ def test_second_acquisition_and_ei_on_the_host_class():
 
 
 def test_likelihood_grid_beyond_the_lds_kernel():
-    X, y, _, ls = make_problem(150, 16, 2)
+    X, y, _, ls = make_problem(200, 16, 2)
     cells = np.stack(np.meshgrid([0.2, 0.4, 0.8], [0.3, 0.9], indexing="ij"), -1).reshape(-1, 2)
     a = H.nlml_grid(X, y, cells)
     b = DeviceGP().nlml_grid(X, y, cells)

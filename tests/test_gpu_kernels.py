@@ -202,11 +202,13 @@ def test_nlml_grid_det_underflow_like_reference(env):
             assert out[k] == r or (np.isnan(r) and np.isnan(out[k]))
 
 
-def test_nlml_grid_large_n_slow_path(env):
-    """N > 128: one full factorisation per cell; same float32 values / -inf pattern as the reference's formula."""
+@pytest.mark.parametrize("N", [129, 150, 176, 177, 230])
+def test_nlml_grid_large_n(env, N):
+    """N <= 176: the packed bordered matrix still fits in LDS; beyond: one full factorisation per cell.  Same float32
+    values / -inf pattern as the reference's formula on both routes."""
     from bayesian_optimisation_amd import DeviceGP
 
-    X, y, _, _ = make_problem(150, 8, 2)
+    X, y, _, _ = make_problem(N, 8, 2)
     a1, a2 = np.array([0.02, 0.3, 4.0]), np.array([0.05, 0.5])
     cells = np.stack(np.meshgrid(a1, a2, indexing="ij"), -1).reshape(-1, 2)
     ref = O.nlml_grid(X, y, [a1, a2]).ravel()
