@@ -67,6 +67,7 @@ SIGNATURES = {
 }
 
 _lib = None
+hip_used_before_pytorch = False  # a host-pointer entry point initialised HIP while PyTorch was not imported
 
 
 class GpboError(RuntimeError):
@@ -95,6 +96,15 @@ def _bind_to_pytorch_hip_runtime():
             C.CDLL(rt, mode=C.RTLD_GLOBAL)
         except OSError:
             pass  # fall back to the system runtime
+
+
+def note_hip_use():
+    """Called by the NumPy-only binding right before a call that initialises HIP (see gp_device._torch)."""
+    global hip_used_before_pytorch
+    import sys
+
+    if "torch" not in sys.modules:
+        hip_used_before_pytorch = True
 
 
 def load():

@@ -19,14 +19,19 @@ namespace {
 
 constexpr int ARD_MAX_N = 176;  // packed lower triangle of the (N+1) x (N+1) bordered matrix + X in LDS: 150 KB at d = 16
 
+// PACKED = false: square image with row stride N + 2 (cheaper indexing, N <= 128); PACKED = true: lower triangle packed
+// by rows (N <= 176).
+template <bool PACKED>
 __global__ __launch_bounds__(256) void nlml_grid_kernel(const double *__restrict__ X, const double *__restrict__ y,
                                                         int N, int d, const double *__restrict__ ls_cells,
                                                         double jitter, float *__restrict__ out) {
     extern __shared__ double lds[];
-    // bordered matrix (N+1) x (N+1), lower triangle only, packed by rows: entry (r, q <= r) at r (r + 1) / 2 + q
-    auto tri = [](int r, int q) { return r * (r + 1) / 2 + q; };
-    double *a = lds;                   // (N+1) (N+2) / 2
-    double *xs = a + (N + 1) * (N + 2) / 2;  // N x d
+    // bordered matrix (N+1) x (N+1), lower triangle: entry (r, q <= r) at r (r + 1) / 2 + q when packed, else at
+    // r (N + 2) + q (one more column than needed to break bank strides)
+    const int ld = N + 2;
+    auto tri = [ld](int r, int q) { return PACKED ? r * (r + 1) / 2 + q : r * ld + q; };
+    double *a = lds;
+    double *xs = a + (PACKED ? (N + 1) * (N + 2) / 2 : (N + 1) * ld);  // N x d
     double *il2 = xs + N * d;          // d
     double *diag = il2 + d;            // N   (L_ii)
     const int tid = threadIdx.x;
@@ -128,14 +133,21 @@ extern "C" int gpbo_nlml_grid_f64(const double *X, const double *y, int64_t N, i
     if (!X || !y || !ls_cells || !out || N < 1 || N > ARD_MAX_N || d < 1 || d > GPBO_MAX_D || G < 1 ||
         G > (1 << 30))
         return GPBO_ERR_ARG;
-    const size_t lds_bytes = sizeof(double) * ((size_t)(N + 1) * (N + 2) / 2 + (size_t)N * d + d + N);
+    const bool packed = N > 128;
+    const size_t mat = packed ? (size_t)(N + 1) * (N + 2) / 2 : (size_t)(N + 1) * (N + 2);
+    const size_t lds_bytes = sizeof(double) * (mat + (size_t)N * d + d + N);
+    const void *fn = packed ? reinterpret_cast<const void *>(nlml_grid_kernel<true>)
+                            : reinterpret_cast<const void *>(nlml_grid_kernel<false>);
     if (lds_bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nlml_grid_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return GPBO_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(nlml_grid_kernel, dim3((unsigned)G), dim3(256), lds_bytes, gpbo_stream(stream), X, y, (int)N,
-                       (int)d, ls_cells, jitter, out);
+    if (packed)
+        hipLaunchKernelGGL(nlml_grid_kernel<true>, dim3((unsigned)G), dim3(256), lds_bytes, gpbo_stream(stream), X, y,
+                           (int)N, (int)d, ls_cells, jitter, out);
+    else
+        hipLaunchKernelGGL(nlml_grid_kernel<false>, dim3((unsigned)G), dim3(256), lds_bytes, gpbo_stream(stream), X, y,
+                           (int)N, (int)d, ls_cells, jitter, out);
     GPBO_CHECK_LAUNCH();
     return GPBO_OK;
 }

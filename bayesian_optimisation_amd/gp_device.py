@@ -25,6 +25,13 @@ DEFAULT_CHUNK = 1 << 17
 
 
 def _torch():
+    if _lib.hip_used_before_pytorch:
+        # Seen on MI355X / ROCm 7: importing PyTorch and creating its GPU context AFTER this library has already
+        # initialised HIP in the process (host-pointer binding used first) dead-locks now and then.  The other order
+        # is the one every tensor-resident path takes and has never hung - so that is the only one allowed.
+        raise _lib.GpboError(
+            "libgpbo.so was used in this process before PyTorch was imported (PointSelectorHost / host_binding first). "
+            "A process that needs both must `import torch` before its first use of bayesian_optimisation_amd.")
     import torch
 
     if not torch.cuda.is_available():

@@ -7,6 +7,9 @@ This is the ctypes stub a maintainer of the reference would write against includ
 library, which costs a few milliseconds per step against the tensor-resident `PointSelector`; the numbers are the
 same (same kernels).  Not available here: candidate sharding over several GPUs, the incremental factorisation,
 fp32 scoring, q-EI - those need the device-pointer API behind `PointSelector`.
+A process that uses both this binding and the PyTorch-based classes must `import torch` before its first call here
+(bringing PyTorch's GPU context up after this library has initialised HIP was seen to dead-lock now and then; the
+PyTorch-based classes refuse that order with a clear error).
 """
 from __future__ import annotations
 
@@ -34,6 +37,7 @@ def nlml_grid(X, y, ls_cells, jitter: float = JITTER_KERNEL, lib=None) -> np.nda
     N, d = X.shape
     cells = _f64(np.asarray(ls_cells, dtype=np.float64).reshape(-1, d))
     out = np.empty(len(cells), dtype=np.float32)
+    _lib.note_hip_use()
     _lib.check(lib.gpbo_nlml_grid_host_f64(_ptr(X), _ptr(y), N, d, _ptr(cells), len(cells), float(jitter), _ptr(out)),
                "gpbo_nlml_grid_host_f64")
     return out
@@ -64,6 +68,7 @@ def select_next(X, y, ls, Xs, acquisition: str = "lcb", explore: float = 4.0, f_
     res = (C.c_int64 * 4)()
     info = C.c_int32(0)
     diag_add = JITTER_KERNEL if Xs.shape == X.shape else 0.0          # point_selector.py:173 shape-coincidence quirk
+    _lib.note_hip_use()
     st = lib.gpbo_select_next_host_f64(_ptr(X), _ptr(y), N, d, _ptr(ls), JITTER_KERNEL, JITTER_ASSEMBLY, _ptr(Xs), M,
                                        kind, p0, p1, diag_add, int(chunk), _ptr(mu), _ptr(sigma), _ptr(acq), _ptr(cov),
                                        C.cast(res, C.c_void_p), C.cast(C.pointer(info), C.c_void_p))

@@ -10,6 +10,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+import torch  # noqa: E402,F401  (this process mixes both routes: PyTorch first, see test_mixing_...)
+
 from bayesian_optimisation_amd import DeviceGP  # noqa: E402
 from bayesian_optimisation_amd import host_binding as H  # noqa: E402
 from bayesian_optimisation_amd.synthetic import make_problem  # noqa: E402
@@ -143,24 +145,40 @@ def test_host_binding_runs_without_pytorch_in_the_process():
     assert out.stdout.strip().startswith("ok")
 
 
-def test_host_route_first_then_pytorch_in_the_same_process():
-    """libgpbo.so must bind to the HIP runtime PyTorch ships: with two runtimes in one process the second one to
-    initialise sees no GPU (observed: torch.cuda.is_available() False after a host-pointer call)."""
-    code = (
+def test_mixing_host_binding_and_pytorch_in_one_process():
+    """libgpbo.so binds to the HIP runtime PyTorch ships (two runtimes in one process: the second one sees no GPU).
+    PyTorch first, then the host-pointer route, then the tensor-resident route: fine, same numbers.  The host-pointer
+    route first and the tensor-resident route afterwards is refused with a clear error: bringing PyTorch's GPU
+    context up after the library has initialised HIP was seen to dead-lock now and then."""
+    common = (
         "import sys, numpy as np\n"
         f"sys.path.insert(0, {REPO!r})\n"
-        "from bayesian_optimisation_amd import host_binding as H\n"
         "rng = np.random.default_rng(0)\n"
         "X, y, Xs = rng.uniform(0, 1, (10, 2)), rng.standard_normal(10), rng.uniform(0, 1, (100, 2))\n"
-        "r = H.select_next(X, y, [0.3, 0.3], Xs)\n"
-        "assert 'torch' not in sys.modules\n"
+    )
+    good = common + (
         "import torch\n"
+        "from bayesian_optimisation_amd import host_binding as H, DeviceGP\n"
+        "r = H.select_next(X, y, [0.3, 0.3], Xs)\n"
         "assert torch.cuda.is_available(), 'PyTorch lost the GPU'\n"
-        "from bayesian_optimisation_amd import DeviceGP\n"
         "q = DeviceGP(chunk=512).factorise(X, y, [0.3, 0.3]).score(Xs, dense=True)\n"
         "assert q.best_idx == r['best_idx'] and np.array_equal(q.mu.cpu().numpy(), r['mu'])\n"
         "print('ok')\n"
     )
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, "-c", good], capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().endswith("ok")
+    refused = common + (
+        "from bayesian_optimisation_amd import host_binding as H, DeviceGP\n"
+        "from bayesian_optimisation_amd._lib import GpboError\n"
+        "r = H.select_next(X, y, [0.3, 0.3], Xs)\n"
+        "assert 'torch' not in sys.modules\n"
+        "try:\n"
+        "    DeviceGP()\n"
+        "except GpboError as e:\n"
+        "    assert 'import torch' in str(e)\n"
+        "    print('refused')\n"
+    )
+    out = subprocess.run([sys.executable, "-c", refused], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().endswith("refused")

@@ -8,6 +8,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch  # noqa: F401  (before the first host-pointer call: a process that uses both routes imports PyTorch first)
 
 from bayesian_optimisation_amd import DeviceGP, PointSelector, PointSelectorHost
 from oracle import gp_oracle as O
