@@ -26,7 +26,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import distributed as D
-from .gp_device import JITTER_ASSEMBLY, JITTER_KERNEL, PRIOR_VAR, DeviceGP
+from .gp_device import JITTER_ASSEMBLY, JITTER_KERNEL, DeviceGP
 
 COV_PRED_MAX_M = 4096          # cov_pred is M x M: 128 MiB at this size
 COV_MEAS_PRED_MAX = 1 << 24    # entries of the (M, N) cross covariance kept for inspection
