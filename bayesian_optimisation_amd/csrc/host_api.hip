@@ -57,7 +57,7 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
     if (N < 1 || M < 1 || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
     if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
     if (chunk == 0) chunk = (int64_t)1 << 17;
-    if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE) return GPBO_ERR_ARG;
+    if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
     for (int k = 0; k < d; ++k)
         if (!(ls[k] > 0.0)) return GPBO_ERR_ARG;
     {  // no more chunk than the candidates need

@@ -360,7 +360,7 @@ extern "C" int gpbo_prepare_f32(const double *U, const double *alpha, int64_t Np
 }
 
 extern "C" int64_t gpbo_posterior_workspace_bytes_f32(int64_t Np32, int64_t chunk, int64_t M) {
-    if (Np32 < BN || Np32 % BN || chunk < 1024 || chunk % 1024 || M < 1) return GPBO_ERR_ARG;
+    if (Np32 < BN || Np32 % BN || chunk < 1024 || chunk % 1024 || chunk > GPBO_CHUNK_MAX || M < 1) return GPBO_ERR_ARG;
     return layout32(Np32, chunk, M).total;
 }
 
@@ -372,7 +372,7 @@ extern "C" int gpbo_posterior_acq_f32(const double *Xs, int64_t M, const double 
                                       void *stream) {
     if (!Xs || !X || !U32 || !alpha32 || !result || !work) return GPBO_ERR_ARG;
     if (M < 1 || N < 1 || Np32 != gpbo_padded_n_f32(N)) return GPBO_ERR_ARG;
-    if (chunk < 1024 || chunk % 1024) return GPBO_ERR_ARG;  // kstar workgroups cover 1024 candidates
+    if (chunk < 1024 || chunk % 1024 || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;  // kstar workgroups cover 1024 candidates
     if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
     if (((uintptr_t)work & 255) || ((uintptr_t)U32 & 15)) return GPBO_ERR_ARG;
     const Layout32 L = layout32(Np32, chunk, M);

@@ -604,7 +604,7 @@ int gpbo_launch_argmax_finish(const double *part_val, const int64_t *part_idx, i
 }
 
 extern "C" int64_t gpbo_posterior_workspace_bytes(int64_t Np, int64_t chunk, int64_t M) {
-    if (Np < GPBO_NPAD || Np % GPBO_NPAD || chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || M < 1)
+    if (Np < GPBO_NPAD || Np % GPBO_NPAD || chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX || M < 1)
         return GPBO_ERR_ARG;
     return posterior_layout(Np, chunk, M).total;
 }
@@ -617,7 +617,7 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
                                       void *stream) {
     if (!Xs || !X || !U || !alpha || !result || !work) return GPBO_ERR_ARG;
     if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || Np > (1 << 20)) return GPBO_ERR_ARG;
-    if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE) return GPBO_ERR_ARG;
+    if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
     if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
     if (((uintptr_t)work & 255) || ((uintptr_t)U & 15)) return GPBO_ERR_ARG;
     const PosteriorLayout L = posterior_layout(Np, chunk, M);
@@ -760,7 +760,7 @@ extern "C" int gpbo_acq_argmax_f64(const double *mu, const double *sigma, int64_
 }
 
 extern "C" int64_t gpbo_qei_workspace_bytes(int64_t Np, int64_t chunk, int64_t M) {
-    if (Np < GPBO_NPAD || Np % GPBO_NPAD || chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || M < 1)
+    if (Np < GPBO_NPAD || Np % GPBO_NPAD || chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX || M < 1)
         return GPBO_ERR_ARG;
     return qei_layout(Np, chunk, M).total;
 }
@@ -772,7 +772,7 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
                                       int64_t work_bytes, void *stream) {
     if (!Xs || !X || !U || !alpha || !Z || !result || !work) return GPBO_ERR_ARG;
     if (M < QQ || M % QQ || N < 1 || Np != gpbo_padded_n(N) || S < 1 || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
-    if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE) return GPBO_ERR_ARG;
+    if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
     if (((uintptr_t)work & 255) || ((uintptr_t)U & 15)) return GPBO_ERR_ARG;
     const QeiLayout L = qei_layout(Np, chunk, M);
     if (work_bytes < L.total) return GPBO_ERR_WORKSPACE;

@@ -37,6 +37,7 @@ extern "C" {
 #define GPBO_MAX_D 16          /* compile-time-unrolled feature counts 1..16 */
 #define GPBO_NPAD 128          /* observation padding granule (column-block width of the variance kernel) */
 #define GPBO_CHUNK_GRANULE 512 /* candidate-chunk granule */
+#define GPBO_CHUNK_MAX (1 << 24) /* largest chunk (16-row tile offsets inside K*^T are 32-bit element offsets) */
 
 #define GPBO_ACQ_LCB 0 /* acq = p0*sigma - mu            (point_selector.py:204, p0 = explore) */
 #define GPBO_ACQ_EI 1  /* acq = EI for minimisation, p0 = f_best, p1 = xi (not in the reference) */

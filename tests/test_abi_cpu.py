@@ -93,6 +93,7 @@ def test_size_contracts_are_checked_on_the_host():
     assert post(100, 512, 0) == -1
     assert post(128, 500, 0) == -1
     assert post(128, 512, 7) == -1
+    assert post(128, 1 << 25, 0) == -1   # chunk beyond GPBO_CHUNK_MAX
     assert post(128, 512, 0, wbytes=8) == -3
     # potrf / trtri: Np a multiple of 64
     assert lib.gpbo_potrf_f64(p, 100, p, p, None) == -1
