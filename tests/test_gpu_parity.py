@@ -534,3 +534,29 @@ def test_exchange_step_over_rccl_in_a_one_rank_group():
         assert float(t.item()) == 1.5
     finally:
         dist.destroy_process_group()
+
+
+def test_two_stream_overlap_mode_gives_identical_results():
+    """GPBO_OVERLAP=1 (K(X*,X) of chunk c+1 on a helper stream beside the variance kernel of chunk c; opt-in, read once
+    per process) must not change a bit."""
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {repo!r})\n"
+        "from bayesian_optimisation_amd import DeviceGP\n"
+        "from bayesian_optimisation_amd.synthetic import make_problem\n"
+        "X, y, Xs, ls = make_problem(200, 5000, 8)\n"
+        "r = DeviceGP(chunk=1024).factorise(X, y, ls).score(Xs, dense=True, idx_offset=3)\n"
+        "print(r.best_idx, repr(r.best_val), r.nan_count, repr(float(r.sigma.sum().item())), repr(float(r.mu.sum().item())))\n"
+    )
+    outs = []
+    for overlap in ("0", "1"):
+        env = dict(os.environ, GPBO_OVERLAP=overlap)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(p.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
