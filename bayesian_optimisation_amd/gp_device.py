@@ -70,6 +70,7 @@ class DeviceGP:
         self._result = self._status[:4]
         self.info = self._status[4:5].view(torch.int32)[:1]
         self._profile = C.c_void_p(0)
+        self.profile_active = True   # False: the next scoring calls record no events (bench.py samples every k-th step)
 
     # -- per-launch timing of the dominant kernel (bench.py) -----------------------------------------
     def enable_profile(self, capacity: int = 4096):
@@ -305,7 +306,8 @@ class DeviceGP:
                 self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d,
                 self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.U), self._ptr(self.alpha), prior_var,
                 kind, p0, p1, float(diag_add), int(idx_offset), chunk, self._ptr(mu), self._ptr(sigma),
-                self._ptr(acq), self._ptr(self._result), self._ptr(self._work_post), wbytes, self._profile,
+                self._ptr(acq), self._ptr(self._result), self._ptr(self._work_post), wbytes,
+                self._profile if self.profile_active else None,
                 self._stream())
             _lib.check(st, "gpbo_posterior_acq_f64")
         self._keep = Xsd  # keep the candidate tensor alive until the stream has consumed it
@@ -354,7 +356,8 @@ class DeviceGP:
                 self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np32, self.d,
                 self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.U32), self._ptr(self.alpha32), prior_var,
                 kind, p0, p1, float(diag_add), int(idx_offset), chunk, self._ptr(mu), self._ptr(sigma),
-                self._ptr(acq), self._ptr(self._result), self._ptr(self._work_post32), need, self._profile,
+                self._ptr(acq), self._ptr(self._result), self._ptr(self._work_post32), need,
+                self._profile if self.profile_active else None,
                 self._stream())
             _lib.check(st, "gpbo_posterior_acq_f32")
         self._keep = Xsd

@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--all-on-device", type=int, default=-1,
                     help="rehearsal only: put every rank on this GPU index instead of LOCAL_RANK")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="bracket the kernels with HIP events in every k-th timed step only (an event record costs a few "
+                         "microseconds of idle GPU; 1 = every step)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: do not bracket the kernels with HIP events (no roofline in the output)")
     ap.add_argument("--force-process-group", action="store_true",
@@ -125,7 +128,8 @@ def main():
             return gp.score_async_f32(Xsd, acquisition="lcb", explore=4.0, idx_offset=lo)
         return gp.score_async(Xsd, acquisition="lcb", explore=4.0, idx_offset=lo)
 
-    def step():
+    def step(sample_events=True):
+        gp.profile_active = sample_events
         gp.factorise(Xd, yd, ls, check=False)
         if f32:
             gp.prepare_f32()
@@ -148,10 +152,11 @@ def main():
         gp.reset_profile()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        best = step()
+    for i in range(args.steps):
+        best = step(i % max(args.event_stride, 1) == 0)
     fence()
     dt = time.perf_counter() - t0
+    gp.profile_active = True
     if use_pg:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -177,7 +182,8 @@ def main():
     roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
                     frac=round(achieved / peak, 4), traffic=traffic,
                     kernel="sigma_acq_f32_kernel" if f32 else "sigma_acq_kernel", launches=int(k_launches), avg_launch_ms=round(k_avg_ms, 4),
-                    flop_per_candidate=flop_per_cand, candidates_per_launch=cand_per_launch)
+                    flop_per_candidate=flop_per_cand, candidates_per_launch=cand_per_launch,
+                    event_stride=int(max(args.event_stride, 1)))  # launches of every k-th timed step are bracketed
 
     # second kernel of the path: K(X*,X) build (HBM-write bound when materialised): algorithmic bytes per candidate
     # = N*w written + d*w read (w = 8 for fp64), DESIGN.md section 4
