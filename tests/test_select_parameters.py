@@ -139,13 +139,24 @@ def test_driver_writes_macro_when_template_present(tmp_path):
 
 
 @pytest.mark.gpu
-def test_driver_on_gpu_matches_oracle_selector(tmp_path):
-    from bayesian_optimisation_amd import PointSelector
+@pytest.mark.parametrize("which", ["PointSelector", "PointSelectorHost", "PointSelector+state"])
+def test_driver_on_gpu_matches_oracle_selector(tmp_path, which):
+    """The DAG step with the GPU classes (tensor-resident, host-pointer, and with a surrogate state file carried from
+    job to job) chooses what the oracle-backed selector chooses and writes the same files."""
+    import bayesian_optimisation_amd as B
 
+    if which == "PointSelector+state":
+        state = str(tmp_path / "surrogate_state.npz")
+
+        def factory():
+            return B.PointSelector(state_path=state)
+    else:
+        factory = getattr(B, which)
     (tmp_path / "cpu").mkdir()
     (tmp_path / "gpu").mkdir()
     c_cpu, p_cpu = _run_sequence(_fresh(tmp_path / "cpu"), OracleSelector)
-    c_gpu, p_gpu = _run_sequence(_fresh(tmp_path / "gpu"), PointSelector)
+    c_gpu, p_gpu = _run_sequence(_fresh(tmp_path / "gpu"), factory)
     assert c_cpu == c_gpu and np.array_equal(p_cpu, p_gpu)
-    assert _run_1d(_fresh(tmp_path / "cpu"), OracleSelector, [7, 8], "A3", 0.1) == \
-        _run_1d(_fresh(tmp_path / "gpu"), PointSelector, [7, 8], "A3", 0.1)
+    if which != "PointSelector+state":  # (one state file serves one parameter block)
+        assert _run_1d(_fresh(tmp_path / "cpu"), OracleSelector, [7, 8], "A3", 0.1) == \
+            _run_1d(_fresh(tmp_path / "gpu"), factory, [7, 8], "A3", 0.1)
