@@ -103,8 +103,11 @@ def _convergence(info, within):
 
 
 def select_parameters(base_dir: str = ".", selector_factory: Optional[Callable] = None,
-                      rng: Optional[np.random.Generator] = None, echo: bool = False) -> dict:
-    """Run one SELECT_PARAMETERS step in `base_dir`.  Returns a summary dict (what was chosen)."""
+                      rng: Optional[np.random.Generator] = None, echo: bool = False,
+                      keep_surrogate: bool = False) -> dict:
+    """Run one SELECT_PARAMETERS step in `base_dir`.  Returns a summary dict (what was chosen).
+    keep_surrogate: carry the factorisation from job to job in `<measured_points file>.surrogate.npz` (the factory is
+    then called with `state_path=...`; new rows are appended in O(N^2) while the chosen length scales stay the same)."""
     if selector_factory is None:
         from .point_selector import PointSelector as selector_factory  # the GPU class (raises without a GPU)
     log = _Log(os.path.join(base_dir, "algo_log.txt"), echo)
@@ -141,7 +144,7 @@ def select_parameters(base_dir: str = ".", selector_factory: Optional[Callable] 
             measured_points = np.array([[block_best[feature_name], block_best["obj"]]])   # :135-139
         else:
             measured_points = np.load(npy)                                            # :142
-        opt = selector_factory()
+        opt = selector_factory(state_path=npy[:-4] + ".surrogate.npz") if keep_surrogate else selector_factory()
         opt.name, opt.iteration = feature_name, iteration
         opt.measured_pts = measured_points[:, 0].reshape((len(measured_points), 1))
         opt.measured_vals = measured_points[:, 1]
@@ -200,7 +203,7 @@ def select_parameters(base_dir: str = ".", selector_factory: Optional[Callable] 
             else:
                 measured_points = np.load(npy)                                        # :265
             axes = [dom["T1"], dom["T2"]] if curr_params[0] == 0 else [dom["T3"], dom["T4"]]
-            opt = selector_factory()
+            opt = selector_factory(state_path=npy[:-4] + ".surrogate.npz") if keep_surrogate else selector_factory()
             opt.name, opt.iteration = PARAMETER_NAMES[cp], iteration
             opt.measured_pts = measured_points[:, 0:2].reshape((len(measured_points), 2))
             opt.measured_vals = measured_points[:, 2]
@@ -232,7 +235,8 @@ def select_parameters(base_dir: str = ".", selector_factory: Optional[Callable] 
 
 
 def main():
-    select_parameters(os.environ.get("GPBO_BASE_DIR", os.getcwd()), echo=True)
+    select_parameters(os.environ.get("GPBO_BASE_DIR", os.getcwd()), echo=True,
+                      keep_surrogate=os.environ.get("GPBO_KEEP_SURROGATE", "0") == "1")
 
 
 if __name__ == "__main__":

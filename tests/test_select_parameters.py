@@ -51,10 +51,10 @@ def _fake_time_residuals(base, npy_name, objective):
         json.dump(info, f, indent=4)
 
 
-def _run_sequence(base, factory):
+def _run_sequence(base, factory, **driver_kw):
     schema0 = json.load(open(os.path.join(base, "opto_log.JSON")))
     # iteration 0 of the very first block: random grid point, no GP
-    s0 = SP.select_parameters(base, selector_factory=factory, rng=np.random.default_rng(7))
+    s0 = SP.select_parameters(base, selector_factory=factory, rng=np.random.default_rng(7), **driver_kw)
     npy = "T1_T2_ALGO_0_BLOCK_0.npy"
     pts = np.load(os.path.join(base, "measured_points", npy))
     assert pts.shape == (1, 3) and pts.dtype == np.float64 and pts[0, 2] == 1000
@@ -68,7 +68,7 @@ def _run_sequence(base, factory):
     for it in range(3):
         _fake_time_residuals(base, npy, objective[it])
         before = json.load(open(os.path.join(base, "opto_log.JSON")))
-        s = SP.select_parameters(base, selector_factory=factory)
+        s = SP.select_parameters(base, selector_factory=factory, **driver_kw)
         pts = np.load(os.path.join(base, "measured_points", npy))
         assert pts.shape == (it + 2, 3) and pts[-1, 2] == 10000          # placeholder objective
         assert pts[-1, 0] in SP.domains()["T1"] and pts[-1, 1] in SP.domains()["T2"]
@@ -139,24 +139,29 @@ def test_driver_writes_macro_when_template_present(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["PointSelector", "PointSelectorHost", "PointSelector+state"])
+@pytest.mark.parametrize("which", ["PointSelector", "PointSelectorHost", "PointSelector+state", "keep_surrogate"])
 def test_driver_on_gpu_matches_oracle_selector(tmp_path, which):
     """The DAG step with the GPU classes (tensor-resident, host-pointer, and with a surrogate state file carried from
     job to job) chooses what the oracle-backed selector chooses and writes the same files."""
     import bayesian_optimisation_amd as B
 
+    driver_kw = {}
     if which == "PointSelector+state":
         state = str(tmp_path / "surrogate_state.npz")
 
         def factory():
             return B.PointSelector(state_path=state)
+    elif which == "keep_surrogate":   # the driver names the state file after the measured-points file of the block
+        factory, driver_kw = B.PointSelector, dict(keep_surrogate=True)
     else:
         factory = getattr(B, which)
     (tmp_path / "cpu").mkdir()
     (tmp_path / "gpu").mkdir()
     c_cpu, p_cpu = _run_sequence(_fresh(tmp_path / "cpu"), OracleSelector)
-    c_gpu, p_gpu = _run_sequence(_fresh(tmp_path / "gpu"), factory)
+    c_gpu, p_gpu = _run_sequence(_fresh(tmp_path / "gpu"), factory, **driver_kw)
     assert c_cpu == c_gpu and np.array_equal(p_cpu, p_gpu)
-    if which != "PointSelector+state":  # (one state file serves one parameter block)
+    if which == "keep_surrogate":
+        assert os.path.exists(os.path.join(str(tmp_path / "gpu"), "measured_points", "T1_T2_ALGO_0_BLOCK_0.surrogate.npz"))
+    if which in ("PointSelector", "PointSelectorHost"):  # (one state file serves one parameter block)
         assert _run_1d(_fresh(tmp_path / "cpu"), OracleSelector, [7, 8], "A3", 0.1) == \
             _run_1d(_fresh(tmp_path / "gpu"), factory, [7, 8], "A3", 0.1)
