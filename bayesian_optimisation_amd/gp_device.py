@@ -369,9 +369,10 @@ class DeviceGP:
         return ScoreResult(v, i, n, mu, sigma, acq)
 
     # -- q = 8 Monte-Carlo Expected Improvement (BASELINE config 5) ---------------------------------------
-    def score_qei(self, Xs, Z, f_best: float, xi: float = 0.0, dense: bool = False, batch_offset: int = 0,
-                  prior_var: float = PRIOR_VAR) -> ScoreResult:
-        """qEI over consecutive batches of 8 rows of Xs; Z = [S x 8] base samples.  best_idx is a BATCH index."""
+    def score_qei_async(self, Xs, Z, f_best: float, xi: float = 0.0, dense: bool = False, batch_offset: int = 0,
+                        prior_var: float = PRIOR_VAR):
+        """Enqueue qEI over consecutive batches of 8 rows of Xs; Z = [S x 8] base samples; no host sync.
+        Returns (result_tensor, qei or None); the result's best_idx is a BATCH index."""
         torch = self.torch
         Xsd, Zd = self._dev(Xs), self._dev(Z)
         M, S = int(Xsd.shape[0]), int(Zd.shape[0])
@@ -382,15 +383,23 @@ class DeviceGP:
             need = int(self.lib.gpbo_qei_workspace_bytes(self.Np, chunk, M))
             if need < 0:
                 raise _lib.GpboError("gpbo_qei_workspace_bytes: invalid sizes")
-            work = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
+            if getattr(self, "_work_qei", None) is None or self._work_qei.numel() * 8 < need:
+                self._work_qei = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
             qei = torch.empty(M // 8, dtype=torch.float64, device=self.device) if dense else None
             st = self.lib.gpbo_posterior_qei_f64(
                 self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d, self.ls_h.ctypes.data_as(C.c_void_p),
                 self._ptr(self.U), self._ptr(self.alpha), prior_var, float(f_best), float(xi), self._ptr(Zd), S,
-                int(batch_offset), chunk, self._ptr(qei), self._ptr(self._result), self._ptr(work), need,
+                int(batch_offset), chunk, self._ptr(qei), self._ptr(self._result), self._ptr(self._work_qei), need,
                 self._stream())
             _lib.check(st, "gpbo_posterior_qei_f64")
-            v, i, n = self.read_result(self._result)
+        self._keep = (Xsd, Zd)
+        return self._result, qei
+
+    def score_qei(self, Xs, Z, f_best: float, xi: float = 0.0, dense: bool = False, batch_offset: int = 0,
+                  prior_var: float = PRIOR_VAR) -> ScoreResult:
+        """qEI over consecutive batches of 8 rows of Xs; Z = [S x 8] base samples.  best_idx is a BATCH index."""
+        res, qei = self.score_qei_async(Xs, Z, f_best, xi, dense, batch_offset, prior_var)
+        v, i, n = self.read_result(res)
         return ScoreResult(v, i, n, None, None, qei)
 
     @property

@@ -4,18 +4,27 @@
 One "step" = one BO inner-loop pass over one batch of synthetic input, everything resident in HBM
 when the timed region starts:
     factorise K(X,X)+jitter (kxx, Cholesky, U = L^-T, alpha)            [once per step]
-    K(X*,X) + mu + sigma + acquisition (LCB, explore=4) + arg-max        [every candidate of the rank]
+    K(X*,X) + mu + sigma + acquisition + arg-max                         [every candidate of the rank]
     one all-gather of (best value, lowest index, NaN count) across ranks [N > 1 only]
-Workload at N=1: BASELINE.json configs[1]  (d=8, N=512, M=2^20 Sobol candidates, fp64).
-For N>1 the candidate set grows with N (2^20 per GPU, contiguous shards): weak scaling; the reported
-value is the whole-job rate M_total / max-over-ranks step time.
+Workload (default): the configuration BASELINE.json's metric is quoted on - d=8, N=4096 Sobol observations,
+fp64, 2^21 Sobol candidates per GPU (= configs[2]'s per-GPU shard: 8 ranks score 2^24), LCB(explore=4), the
+reference's acquisition (point_selector.py:197-207).  `--acq ei` / `--acq qei` time the acquisitions the north star
+names; configs[1] (N=512, M=2^20), configs[3] (--dtype f32 --d 16 --n-obs 8192 --m-per-gpu 524288) and configs[4]
+(--acq qei --n-obs 2048 --m-per-gpu 1048576) stay reachable by flags; the default run reports configs[1] and EI
+under "also".
+For N>1 the candidate set grows with N (contiguous shards): weak scaling; the reported value is the whole-job
+rate M_total / max-over-ranks step time.
 
-Usage: python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+Usage: python bench.py --gpus N --steps K --warmup W
+    N>1 without WORLD_SIZE in the environment: this process starts the N ranks itself (child processes under
+    torch.distributed.run on 127.0.0.1) and exits with their status; under torchrun (WORLD_SIZE set) it is one rank.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,11 +34,67 @@ sys.path.insert(0, REPO)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak = fp64 vector peak (half the 157.3 TF fp32 rate
 #                               listed in MI355X_MICROARCH.md; AMD data sheet value)
+HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(X, y, Xs_sample, ls):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-obs", type=int, default=4096)
+    ap.add_argument("--m-per-gpu", type=int, default=1 << 21)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--acq", choices=["lcb", "ei", "qei"], default="lcb",
+                    help="lcb: the reference's acquisition; ei: closed-form Expected Improvement; qei: q=8 Monte-Carlo "
+                         "qEI with 512 fixed base samples (BASELINE configs[4])")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="target wall time of the cpu_baseline leg (the sample size is chosen from a short probe)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="fix the cpu_baseline sample instead (candidates)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] / EI measurements after the timed run")
+    ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only to rehearse N>1 on one GPU")
+    ap.add_argument("--all-on-device", type=int, default=-1,
+                    help="rehearsal only: put every rank on this GPU index instead of LOCAL_RANK")
+    ap.add_argument("--event-stride", type=int, default=1,
+                    help="bracket the kernels with HIP events in every k-th timed step only (an event record costs a few "
+                         "microseconds of idle GPU, which matters for sub-millisecond launches; 1 = every step)")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="diagnostic: do not bracket the kernels with HIP events (no roofline in the output)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="rehearsal only: initialise the process group and run the exchange step even at N=1")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher check (no GPU): every rank joins the process group, rank 0 prints n_gpus / ranks_seen")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="f32: fp64 factorisation, fp32 screening of all candidates + fp64 re-scoring of the survivors "
+                         "(BASELINE configs[3] shape)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no rendezvous in the environment: start the N ranks as CHILD processes (this
+    process has not touched the GPU - nothing is exec'ed over an initialised runtime) and relay their status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best):
     """The oracle's Cholesky route (NumPy/LAPACK, BLAS threads = host cores) on a bounded sample of the
-    same workload; factorisation excluded (it is amortised over the 2^20 candidates of a real step)."""
+    same workload; factorisation excluded (it is amortised over the 2^21 candidates of a real step).  The sample is
+    sized from a 1024-candidate probe so that the leg takes about `target_s` seconds."""
     import numpy as np
 
     from oracle import gp_oracle as O
@@ -44,56 +109,61 @@ def cpu_baseline(X, y, Xs_sample, ls):
         threads = min(threads, len(os.sched_getaffinity(0)))  # BLAS threads that can actually run
     except Exception:  # noqa: BLE001
         pass
+    N, d = X.shape
     _, L, alpha = O.factorise(X, y, ls)
+
+    def run(P):
+        mu, sig = O.posterior_chol(X, y, P, ls, L=L, alpha=alpha)
+        a = O.lcb(mu, sig, 4) if acq == "lcb" else O.expected_improvement(mu, sig, f_best, 0.0)
+        return int(np.flatnonzero(a == a.max())[0])
+
+    if fixed_sample:
+        ns = min(fixed_sample, len(Xs))
+    else:
+        t0 = time.perf_counter()
+        run(Xs[:1024])
+        probe = time.perf_counter() - t0
+        ns = int(min(len(Xs), max(2048, 1024 * target_s / max(probe, 1e-6))))
+        ns = 1 << (ns.bit_length() - 1)  # power of two at or below the target
     t0 = time.perf_counter()
-    mu, sig = O.posterior_chol(X, y, Xs_sample, ls, L=L, alpha=alpha)
-    acq = O.lcb(mu, sig, 4)
-    idx = int(np.flatnonzero(acq == acq.max())[0])
+    idx = run(Xs[:ns])
     dt = time.perf_counter() - t0
-    return dict(value=len(Xs_sample) / dt, unit="candidate acquisitions/s", cores=int(threads), kind="port",
-                sample=f"first {len(Xs_sample)} of the 2^20 candidates, N=512, d=8, posterior+LCB+argmax, "
-                       f"{dt:.1f} s wall, factorisation excluded"), idx
+    return dict(value=ns / dt, unit="candidate acquisitions/s", cores=int(threads), kind="port",
+                sample=f"first {ns} of the rank's candidates, N={N}, d={d}, posterior + {acq.upper()} + arg-max, "
+                       f"{dt:.1f} s wall, factorisation excluded (oracle/gp_oracle.py posterior_chol)"), idx, ns
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n-obs", type=int, default=512)
-    ap.add_argument("--m-per-gpu", type=int, default=1 << 20)
-    ap.add_argument("--d", type=int, default=8)
-    ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 19,
-                    help="candidates timed on the host for cpu_baseline (about 10-20 s of CPU work)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only to rehearse N>1 on one GPU")
-    ap.add_argument("--all-on-device", type=int, default=-1,
-                    help="rehearsal only: put every rank on this GPU index instead of LOCAL_RANK")
-    ap.add_argument("--event-stride", type=int, default=4,
-                    help="bracket the kernels with HIP events in every k-th timed step only (an event record costs a few "
-                         "microseconds of idle GPU; 1 = every step)")
-    ap.add_argument("--no-kernel-events", action="store_true",
-                    help="diagnostic: do not bracket the kernels with HIP events (no roofline in the output)")
-    ap.add_argument("--force-process-group", action="store_true",
-                    help="rehearsal only: initialise the process group and run the exchange step even at N=1")
-    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
-                    help="f32: fp64 factorisation, fp32 K*/mean/variance (BASELINE configs[3] shape)")
-    args = ap.parse_args()
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(self_launch(args))
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as "
+                 f"{args.gpus} GPUs")
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    use_pg = world > 1 or args.force_process_group
+    if args.rendezvous_only:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks_seen": int(t.item()), "rendezvous_only": True}), flush=True)
+        dist.destroy_process_group()
+        return
+
     dev_index = local_rank if args.all_on_device < 0 else args.all_on_device
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    use_pg = world > 1 or args.force_process_group
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -103,40 +173,51 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    ranks_seen = dist.get_world_size() if use_pg else 1
 
     from bayesian_optimisation_amd import DeviceGP
     from bayesian_optimisation_amd import distributed as D
     from bayesian_optimisation_amd.synthetic import ard_length_scales, rff_objective, sobol_points
 
     N, d = args.n_obs, args.d
+    f32 = args.dtype == "f32"
+    qei = args.acq == "qei"
+    if qei and (f32 or args.m_per_gpu % 8):
+        sys.exit("bench.py: --acq qei needs fp64 and a multiple of 8 candidates per GPU")
     M_total = args.m_per_gpu * world
     lo, hi = D.shard_bounds(M_total, world, rank)
     ls = ard_length_scales(d)
     X = sobol_points(0, N, d)
     y = rff_objective(X, ls)
+    f_best = float(np.min(y))
     Xs_local = sobol_points(N + lo, hi - lo, d)  # this rank's contiguous shard of the Sobol candidate stream
     kw = dict(chunk=args.chunk) if args.chunk else {}
     gp = DeviceGP(dev, **kw)
     Xd, yd, Xsd = gp._dev(X), gp._dev(y), gp._dev(Xs_local)  # inputs resident in HBM before timing
-    if not args.no_kernel_events:
+    Zd = None
+    if qei:
+        Zd = gp._dev(np.random.default_rng(7).standard_normal((512, 8)))  # fixed base samples
+    events = not args.no_kernel_events and not qei
+    if events:
         gp.enable_profile(8192)
+    acq_kw = dict(acquisition="lcb", explore=4.0) if args.acq == "lcb" else dict(acquisition="ei", f_best=f_best, xi=0.0)
 
-    f32 = args.dtype == "f32"
-
-    def score_async():
+    def score_async(g=gp, P=Xsd, off=lo):
+        if qei:
+            return g.score_qei_async(P, Zd, f_best=f_best, xi=0.0, batch_offset=off // 8)
         if f32:
-            return gp.score_async_f32(Xsd, acquisition="lcb", explore=4.0, idx_offset=lo)
-        return gp.score_async(Xsd, acquisition="lcb", explore=4.0, idx_offset=lo)
+            return g.score_async_f32(P, idx_offset=off, **acq_kw)
+        return g.score_async(P, idx_offset=off, **acq_kw)
 
-    def step(sample_events=True):
-        gp.profile_active = sample_events
-        gp.factorise(Xd, yd, ls, check=False)
+    def step(sample_events=True, g=gp, A=Xd, b=yd, P=Xsd, off=lo):
+        g.profile_active = sample_events
+        g.factorise(A, b, ls, check=False)
         if f32:
-            gp.prepare_f32()
-        score_async()
+            g.prepare_f32()
+        score_async(g, P, off)
         # the one exchange step: the 40-byte device record (result + factorisation info) is gathered over the ranks
         # and read back once (at N=1: just the read-back, which synchronises this rank)
-        v, i, n, info = D.allreduce_status(gp.status, force_collective=args.force_process_group)
+        v, i, n, info = D.allreduce_status(g.status, force_collective=args.force_process_group)
         if info != 0:
             raise RuntimeError("Cholesky failed")
         return v, i, n
@@ -148,7 +229,7 @@ def main():
 
     for _ in range(args.warmup):
         best = step()
-    if not args.no_kernel_events:
+    if events:
         gp.reset_profile()
     fence()
     t0 = time.perf_counter()
@@ -164,72 +245,117 @@ def main():
     ms_step = dt / args.steps * 1e3
     value = M_total / (dt / args.steps)
 
-    # dominant kernel (sigma/acquisition/arg-max): hipEvent pairs recorded on its stream inside the timed region
-    k_ms, k_launches, k_cands = gp.read_profile() if not args.no_kernel_events else (1.0, 1, 1)
-    k_avg_ms = k_ms / max(k_launches, 1)
-    cand_per_launch = k_cands / max(k_launches, 1)
-    flop_per_cand = float(N) * N + 2.0 * N           # triangular product N^2 + |v|^2 2N  
-    achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
-    traffic = None
-    pmc = os.path.join(REPO, "profiles", "pmc_sigma_acq.json")
-    default_shape = (N, d, args.m_per_gpu, args.dtype, args.chunk) == (512, 8, 1 << 20, "f64", 0)
-    if os.path.exists(pmc) and default_shape:  # the committed PMC pass was taken on the default workload
+    roofline = kstar_roofline = None
+    if events:
+        # dominant kernel (sigma/acquisition/arg-max): hipEvent pairs recorded on its stream inside the timed region
+        k_ms, k_launches, k_cands = gp.read_profile()
+        k_avg_ms = k_ms / max(k_launches, 1)
+        cand_per_launch = k_cands / max(k_launches, 1)
+        flop_per_cand = float(N) * N + 2.0 * N           # triangular product N^2 + |v|^2 2N  
+        achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
+        # HBM bytes of one launch from the committed rocprofv3 --pmc passes of this same command line (profiles/):
+        # counters cannot be read from inside the run, so the figure is replayed for the shape it was collected on
+        traffic = traffic_src = None
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            shapes = json.load(open(os.path.join(REPO, "profiles", "pmc_sigma_acq.json")))
+            key = f"N={N},d={d},dtype={args.dtype},candidates_per_launch={int(cand_per_launch)}"
+            if key in shapes:
+                traffic = shapes[key]["hbm_bytes_per_launch"]
+                traffic_src = f"committed PMC pass {shapes[key]['source']} (FETCH_SIZE x2 + WRITE_SIZE), not this run"
         except Exception:  # noqa: BLE001
-            traffic = None
-    peak = FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS
-    roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
-                    frac=round(achieved / peak, 4), traffic=traffic,
-                    kernel="sigma_acq_f32_kernel" if f32 else "sigma_acq_kernel", launches=int(k_launches), avg_launch_ms=round(k_avg_ms, 4),
-                    flop_per_candidate=flop_per_cand, candidates_per_launch=cand_per_launch,
-                    event_stride=int(max(args.event_stride, 1)))  # launches of every k-th timed step are bracketed
-
-    # second kernel of the path: K(X*,X) build (HBM-write bound when materialised): algorithmic bytes per candidate
-    # = N*w written + d*w read (w = 8 for fp64), DESIGN.md section 4
-    kstar_roofline = None
-    if not f32 and not args.no_kernel_events:
+            pass
+        peak = FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS
+        roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
+                        frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src,
+                        kernel="sigma_acq_f32_kernel" if f32 else "sigma_acq_kernel", launches=int(k_launches),
+                        avg_launch_ms=round(k_avg_ms, 4), flop_per_candidate=flop_per_cand,
+                        candidates_per_launch=cand_per_launch,
+                        event_stride=int(max(args.event_stride, 1)))  # launches of every k-th timed step are bracketed
+        # second kernel of the path: K(X*,X) build (HBM-write bound when materialised): algorithmic bytes per
+        # candidate = N*w written + d*8 read (w = 8 for fp64, 4 for the fp32 screen), DESIGN.md section 4
         ks_ms, ks_launches, ks_cands = gp.read_profile_kstar()
         if ks_launches:
             ks_avg = ks_ms / ks_launches
-            bytes_per_cand = 8.0 * (N + d)
+            bytes_per_cand = (4.0 if f32 else 8.0) * N + 8.0 * d
             gbs = bytes_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e9
-            kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=8000.0, unit="GB/s",
-                                  frac=round(gbs / 8000.0, 4), kernel="kstar_mu_kernel", launches=int(ks_launches),
-                                  avg_launch_ms=round(ks_avg, 4), bytes_per_candidate=bytes_per_cand)
+            kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                  frac=round(gbs / HBM_PEAK_GBS, 4),
+                                  kernel="kstar_mu_f32_kernel" if f32 else "kstar_mu_kernel",
+                                  launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
+                                  bytes_per_candidate=bytes_per_cand)
 
     # time of the scoring part alone (factorisation excluded), for the record
     fence()
+    reps = max(2, args.steps // 4)
     t1 = time.perf_counter()
-    for _ in range(max(3, args.steps // 4)):
-        res, _, _, _ = score_async()
-        gp.read_result(res)
+    for _ in range(reps):
+        score_async()
+        gp.read_result(gp.status[:4])
     torch.cuda.synchronize(dev)
-    ms_score = (time.perf_counter() - t1) / max(3, args.steps // 4) * 1e3
+    ms_score = (time.perf_counter() - t1) / reps * 1e3
 
-    cfg_name = {(512, 8, "f64"): "configs[1]", (4096, 8, "f64"): "configs[2] (per-GPU shard)",
-                (8192, 16, "f32"): "configs[3] (per-GPU shard)"}.get((N, d, args.dtype), "custom")
-    out = None
+    def also():
+        """Two more numbers from the same build on the same box (N=1 only): BASELINE configs[1] and EI on the
+        default workload - a few steps each, outside the timed region above."""
+        res = {}
+        reps2 = 3
+        if args.acq == "lcb" and not f32:
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for _ in range(reps2):
+                gp.factorise(Xd, yd, ls, check=False)
+                gp.score_async(Xsd, acquisition="ei", f_best=f_best, xi=0.0, idx_offset=lo)
+                v, i, n, info = D.allreduce_status(gp.status)
+            ms = (time.perf_counter() - t) / reps2 * 1e3
+            res["ei_same_workload"] = dict(value=(hi - lo) / (ms * 1e-3), unit="candidates/s", ms_per_step=ms,
+                                           argmax_index=i, steps=reps2)
+        if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb"):
+            n2, m2 = 512, 1 << 20
+            X2 = sobol_points(0, n2, d)
+            y2 = rff_objective(X2, ls)
+            g2 = DeviceGP(dev)
+            A2, b2, P2 = g2._dev(X2), g2._dev(y2), g2._dev(sobol_points(n2, m2, d))
+            for _ in range(2):
+                step(False, g2, A2, b2, P2, 0)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for _ in range(20):
+                v, i, n = step(False, g2, A2, b2, P2, 0)
+            ms = (time.perf_counter() - t) / 20 * 1e3
+            res["configs[1]"] = dict(workload="d=8, N=512, M=2^20, fp64, LCB(explore=4)", value=m2 / (ms * 1e-3),
+                                     unit="candidates/s", ms_per_step=ms, argmax_index=i, steps=20)
+        return res
+
+    cfg_name = {(512, 8, "f64", "lcb"): "configs[1]", (4096, 8, "f64", "lcb"): "configs[2] (per-GPU shard)",
+                (4096, 8, "f64", "ei"): "configs[2] (per-GPU shard), EI",
+                (8192, 16, "f32", "lcb"): "configs[3] (per-GPU shard)",
+                (2048, 8, "f64", "qei"): "configs[4] (per-GPU shard)"}.get((N, d, args.dtype, args.acq), "custom")
+    acq_txt = {"lcb": "LCB(explore=4) arg-max", "ei": "Expected Improvement (f_best=min y, xi=0) arg-max",
+               "qei": "q=8 Monte-Carlo qEI (512 fixed base samples) arg-max over batches"}[args.acq]
     if rank == 0:
+        lg = int(np.log2(args.m_per_gpu))
+        mtxt = f"2^{lg}" if args.m_per_gpu == 1 << lg else str(args.m_per_gpu)
         out = {
             "metric": "candidate acquisitions/sec", "value": value, "unit": "candidates/s", "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"{cfg_name}: d={d}, N={N} Sobol observations, M=2^{int(np.log2(args.m_per_gpu))} "
-                                    f"Sobol candidates per GPU, ARD-SE GP, LCB(explore=4) arg-max, "
-                                    f"{'fp64 factorisation + fp32 scoring' if f32 else 'fp64'}; "
+            "config": {"workload": (f"{cfg_name}: d={d}, N={N} Sobol observations, M={mtxt} "
+                                    f"Sobol candidates per GPU, ARD-SE GP, {acq_txt}, "
+                                    f"{'fp64 factorisation + fp32 screen + fp64 re-score of the survivors' if f32 else 'fp64'}; "
                                     f"step = factorise + score all candidates + reduce"),
                        "candidates_total": M_total, "parallelism": f"candidate-sharded x{world}"},
             "ms_per_step_scoring_only": ms_score,
             "value_excl_factorisation": (hi - lo) * world / (ms_score * 1e-3),
             "argmax_index": best[1], "roofline": roofline, "kstar_roofline": kstar_roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and not f32:
-            ns = min(args.cpu_sample, hi - lo)
-            cb, idx_cpu = cpu_baseline(X, y, Xs_local[:ns], ls)
-            r = gp.score(Xsd[:ns], acquisition="lcb", explore=4.0)
+        if world == 1 and not args.no_cpu_baseline and not qei:
+            cb, idx_cpu, ns = cpu_baseline(X, y, Xs_local, ls, args.acq, args.cpu_seconds, args.cpu_sample, f_best)
+            r = (gp.score_f32 if f32 else gp.score)(Xsd[:ns], **acq_kw)
             cb["argmax_match_on_sample"] = bool(r.best_idx == idx_cpu)
             out["cpu_baseline"] = cb
+        if world == 1 and not args.no_also:
+            out["also"] = also()
         print(json.dumps(out), flush=True)
     if use_pg:
         dist.barrier()

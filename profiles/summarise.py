@@ -3,7 +3,9 @@
     profiles/<out>_kernel_stats.csv   copy of rocprofv3's kernel stats
     profiles/<out>_pmc_summary.csv    per-launch means of every counter, per kernel
     profiles/pmc_sigma_acq.json       HBM bytes per launch of the dominant kernel (read by bench.py)
-usage: python profiles/summarise.py gpurun_out/prof_TAG r01 [bench_line.json]"""
+usage: python profiles/summarise.py gpurun_out/prof_TAG r02 [bench_line.json] [N d dtype candidates_per_launch]
+pmc_sigma_acq.json is keyed by workload shape ("N=4096,d=8,dtype=f64,candidates_per_launch=131072"); bench.py
+replays the entry that matches the shape it runs (counters cannot be read from inside an un-profiled run)."""
 import collections
 import csv
 import glob
@@ -13,6 +15,11 @@ import shutil
 import sys
 
 src, out = sys.argv[1], sys.argv[2]
+N, d, dtype, cands = 4096, 8, "f64", 131072
+if len(sys.argv) > 4:
+    N, d, dtype, cands = int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7])
+w = 4 if dtype == "f32" else 8
+kern = "sigma_acq_f32_kernel" if dtype == "f32" else "sigma_acq_kernel"
 here = os.path.dirname(os.path.abspath(__file__))
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(here, f"{out}_kernel_stats.csv"))
 
@@ -22,31 +29,37 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
         k = k.split("(")[0].split("<")[0]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-keep = ("sigma_acq_kernel", "kstar_mu_kernel", "potrf_diag_kernel", "gemm_f64_kernel", "kxx_kernel", "utv_kernel",
+keep = ("sigma_acq_kernel", "kstar_mu_kernel", "sigma_acq_f32_kernel", "kstar_mu_f32_kernel", "rescore_gather_kernel", "potrf_diag_kernel", "gemm_f64_kernel", "kxx_kernel", "utv_kernel",
         "uv_kernel")
 with open(os.path.join(here, f"{out}_pmc_summary.csv"), "w") as fo:
     fo.write("# rocprofv3 --pmc passes (one pass per counter group, profiles/collect.sh), bench.py --steps 5 --warmup 2,\n")
-    fo.write("# MI355X; per-launch means; a sigma/kstar launch = one chunk of 2^17 candidates, N=512, d=8\n")
+    fo.write(f"# MI355X; per-launch means; a sigma/kstar launch = one chunk of {cands} candidates, N={N}, d={d}, {dtype}\n")
     fo.write("kernel,counter,launches,mean_per_launch\n")
     for k in keep:
         for c, v in sorted(agg.get(k, {}).items()):
             fo.write(f"{k},{c},{len(v)},{sum(v) / len(v):.6g}\n")
 
-s = agg["sigma_acq_kernel"]
+s = agg[kern]
 fetch = sum(s["FETCH_SIZE"]) / len(s["FETCH_SIZE"])
 write = sum(s["WRITE_SIZE"]) / len(s["WRITE_SIZE"])
-N, cands = 512, 131072
-js = {
-    "kernel": "sigma_acq_kernel",
+path = os.path.join(here, "pmc_sigma_acq.json")
+try:
+    shapes = json.load(open(path))
+    if "kernel" in shapes:  # round-1 layout (one un-keyed entry, N=512)
+        shapes = {"N=512,d=8,dtype=f64,candidates_per_launch=131072": shapes}
+except Exception:  # noqa: BLE001
+    shapes = {}
+shapes[f"N={N},d={d},dtype={dtype},candidates_per_launch={cands}"] = {
+    "kernel": kern,
     "source": f"profiles/{out}_pmc_summary.csv",
     "FETCH_SIZE_KiB": fetch,
     "WRITE_SIZE_KiB": write,
     "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE x1",
     "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
     "candidates_per_launch": cands,
-    "algorithmic_bytes_per_launch": cands * 8 * (N + 5),  # K*^T slab once + mu partial slices read + outputs
+    "algorithmic_bytes_per_launch": cands * w * (N + 5),  # K*^T slab once + mu partial slices read + outputs
 }
-json.dump(js, open(os.path.join(here, "pmc_sigma_acq.json"), "w"), indent=1)
+json.dump(shapes, open(path, "w"), indent=1)
 if len(sys.argv) > 3:
     line = [l for l in open(sys.argv[3]) if l.startswith("{")][-1]
     open(os.path.join(here, f"{out}_bench_line.json"), "w").write(line)

@@ -110,3 +110,24 @@ def test_allreduce_status_without_a_process_group():
     assert D.allreduce_status(torch.tensor([bits, 42, 3, 0, 0], dtype=torch.int64)) == (-2.5, 42, 3, 0)
     neg = (-7) & 0xFFFFFFFF  # an int32 info word of -7 in the low half of the slot
     assert D.allreduce_status(torch.tensor([bits, 42, 0, 0, neg], dtype=torch.int64))[3] == -7
+
+
+def test_bench_starts_its_own_ranks_when_asked_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` with no rendezvous in the environment (how the driver calls it) must run TWO ranks:
+    the launcher check joins a gloo group and reports the ranks it saw; a WORLD_SIZE that contradicts --gpus is an
+    error, never a silently smaller run."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr

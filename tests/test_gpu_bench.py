@@ -1,0 +1,39 @@
+"""bench.py as the driver runs it: `--gpus N` alone must produce an N-rank run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], capture_output=True, text=True, env=env,
+                       timeout=540)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_two_self_launched_ranks_pick_the_point_one_rank_picks_over_the_same_candidates():
+    common = ["--n-obs", "384", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also"]
+    two = _bench("--gpus", "2", "--backend", "gloo", "--all-on-device", "0", "--m-per-gpu", "65536", *common)
+    one = _bench("--gpus", "1", "--m-per-gpu", "131072", *common)
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["candidates_total"] == one["config"]["candidates_total"] == 131072
+    assert two["argmax_index"] == one["argmax_index"]
+    assert two["roofline"]["frac"] > 0 and one["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
+    line = _bench("--steps", "2", "--warmup", "1", "--cpu-seconds", "4")
+    assert "N=4096" in line["config"]["workload"] and "d=8" in line["config"]["workload"]
+    assert line["config"]["candidates_total"] == 1 << 21 and line["dtype"] == "f64"
+    assert line["cpu_baseline"]["argmax_match_on_sample"] is True
+    assert "N=4096" in line["cpu_baseline"]["sample"]
+    assert 0.5 < line["roofline"]["frac"] <= 1.0
+    assert line["also"]["configs[1]"]["value"] > 0 and line["also"]["ei_same_workload"]["value"] > 0
