@@ -83,6 +83,15 @@ __global__ __launch_bounds__(256) void append_column_kernel(const double *__rest
     }
 }
 
+// alpha is committed only when the pivot was accepted: a failed append leaves the surrogate exactly as it was
+// (U untouched, alpha untouched), so a caller that catches the error and keeps scoring gets the old posterior.
+__global__ __launch_bounds__(256) void append_commit_alpha_kernel(const double *__restrict__ src,
+                                                                  const int32_t *__restrict__ info, int64_t Np,
+                                                                  double *__restrict__ alpha) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < Np && *info == 0) alpha[i] = src[i];
+}
+
 }  // namespace
 
 extern "C" int64_t gpbo_append_workspace_bytes(int64_t Np) {
@@ -119,7 +128,10 @@ extern "C" int gpbo_append_f64(double *X, double *y, int64_t N, int32_t d, const
     hipLaunchKernelGGL(append_column_kernel, dim3(nblk), dim3(256), 0, st, c, kvec, scal, info, (int)N, Np, kappa, U,
                        Kp);
     GPBO_CHECK_LAUNCH();
-    // alpha of the N+1 observations.  When the pivot failed (info != 0) U is unchanged but alpha is not meaningful:
-    // the caller must look at info and refactorise
-    return gpbo_alpha_f64(U, y, N + 1, Np, l, alpha, stream);
+    // alpha of the N+1 observations goes to the workspace first (c is free again) and is committed under info == 0
+    rc = gpbo_alpha_f64(U, y, N + 1, Np, l, c, stream);
+    if (rc != GPBO_OK) return rc;
+    hipLaunchKernelGGL(append_commit_alpha_kernel, dim3(nblk), dim3(256), 0, st, c, info, Np, alpha);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
 }

@@ -107,3 +107,16 @@ def gather_concat(local, total: int, group=None):
     if out.shape[0] != total:
         raise ValueError(f"gather_concat: shards add up to {out.shape[0]} rows, expected {total}")
     return out
+
+
+def all_agree(flag: bool, group=None) -> bool:
+    """True iff `flag` is true on EVERY rank (a collective decision: e.g. append-or-refactorise must be taken the same
+    way everywhere, or the ranks' factors differ at rounding level and the lowest-index tie rule no longer holds).
+    Outside a process group: the flag itself."""
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(flag)
+    votes = [None] * dist.get_world_size(group)
+    dist.all_gather_object(votes, bool(flag), group=group)
+    return all(votes)

@@ -260,7 +260,23 @@ class DeviceGP:
         return self
 
     def save_state(self, path: str):
-        np.savez(path, **self.state_dict())
+        """Atomic: written to a temporary file in the same directory and renamed over `path`, so a job killed
+        mid-write (or a concurrent reader) never sees a torn file."""
+        import os
+        import tempfile
+
+        path = str(path)
+        if not path.endswith(".npz"):
+            path += ".npz"  # what np.savez would have appended
+        fd, tmp = tempfile.mkstemp(prefix=".gpbo_state_", suffix=".tmp", dir=os.path.dirname(os.path.abspath(path)))
+        try:
+            with os.fdopen(fd, "wb") as f:
+                np.savez(f, **self.state_dict())
+            os.replace(tmp, path)
+        except BaseException:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
+            raise
 
     def load_state(self, path: str):
         with np.load(path) as z:

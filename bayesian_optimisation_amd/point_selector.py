@@ -62,9 +62,9 @@ class PointSelector:
         self.gradient_steps = 0.001
         self.iteration = None
         self.name = None
-        self.cov_pred = None
-        self.cov_meas = None
-        self.cov_meas_pred = None
+        # cov_pred / cov_meas / cov_meas_pred (:38-40) are properties below: built on first access
+        self._lazy = {}
+        self._cov = {"cov_pred": None, "cov_meas": None, "cov_meas_pred": None}
         # build-specific
         self.nlogml = None
         self._device = device
@@ -84,6 +84,24 @@ class PointSelector:
         self.last_update = None        # "factorise" | "append": what the last update_surrogate() did
 
     # ------------------------------------------------------------------------------------------
+    def _cov_get(self, name):
+        make = self._lazy.pop(name, None)
+        if make is not None:
+            self._cov[name] = make()
+        return self._cov[name]
+
+    def _cov_set(self, name, value):
+        self._lazy.pop(name, None)
+        self._cov[name] = value
+
+    cov_pred = property(lambda self: self._cov_get("cov_pred"), lambda self, v: self._cov_set("cov_pred", v),
+                        doc="k(X*,X*) + 1e-6 I (point_selector.py:78); None above COV_PRED_MAX_M candidates")
+    cov_meas = property(lambda self: self._cov_get("cov_meas"), lambda self, v: self._cov_set("cov_meas", v),
+                        doc="k(X,X) + 1e-6 I (point_selector.py:79)")
+    cov_meas_pred = property(lambda self: self._cov_get("cov_meas_pred"),
+                             lambda self, v: self._cov_set("cov_meas_pred", v),
+                             doc="k(X,X*).T (point_selector.py:81); None above COV_MEAS_PRED_MAX entries")
+
     def _log(self, *a):
         if self._verbose:
             print(*a)
@@ -118,7 +136,6 @@ class PointSelector:
         ls = self._select_kernel_params(X)
 
         self._factorise_or_append(gp, X, y, ls)                           # :79, :89 (raises LinAlgError)
-        self.cov_meas = gp.cov_meas_host()
 
         M, N = len(Xs), len(X)
         diag_add = JITTER_KERNEL if Xs.shape == X.shape else 0.0          # :173 shape-coincidence quirk
@@ -140,8 +157,15 @@ class PointSelector:
         self._cached = {("lcb", 4.0, 0.0): (acq.reshape(fd), best)}
         self._lo_hi = (lo, hi)
 
-        self.cov_meas_pred = gp.cov_meas_pred_host(Xs, diag_add) if M * N <= COV_MEAS_PRED_MAX else None
-        self.cov_pred = gp.kxx_host(Xs, ls, JITTER_KERNEL, JITTER_ASSEMBLY) if M <= COV_PRED_MAX_M else None
+        # The three covariance attributes of point_selector.py:38-40 are read by nobody on the reference's call path
+        # (select_parameters.py reads mean_func / cov_func / acq_func_eval only): they are copied out of the device
+        # on first access instead of on every call (the 2,500 x 2,500 cov_pred copy was 6.4 of 7.9 ms of a C1 step).
+        self._cov = {"cov_pred": None, "cov_meas": None, "cov_meas_pred": None}
+        self._lazy = {"cov_meas": gp.cov_meas_host}
+        if M * N <= COV_MEAS_PRED_MAX:
+            self._lazy["cov_meas_pred"] = lambda: gp.cov_meas_pred_host(Xs, diag_add)
+        if M <= COV_PRED_MAX_M:
+            self._lazy["cov_pred"] = lambda: gp.kxx_host(Xs, ls, JITTER_KERNEL, JITTER_ASSEMBLY)
 
         self.measured_pts = self.measured_pts.tolist()                    # :101-102
         self.measured_vals = self.measured_vals.tolist()
@@ -166,6 +190,7 @@ class PointSelector:
         import os
 
         appended = False
+        world, rank = self._world()
         if self._incremental:
             if self._inc is None and self._state_path is not None and os.path.exists(self._state_path):
                 try:
@@ -174,26 +199,32 @@ class PointSelector:
                 except Exception as exc:  # noqa: BLE001 - an unreadable state file only costs the shortcut
                     self._log(f"state file {self._state_path!r} ignored: {exc}")
                     self._inc = None
+            can_append = False
             if self._inc is not None:
                 X0, y0, ls0 = self._inc
                 n0 = len(X0)
-                if (n0 < len(X) <= n0 + MAX_APPEND_ROWS and gp.N == n0 and X0.shape[1:] == X.shape[1:]
-                        and gp.n_appended + (len(X) - n0) <= MAX_APPENDED_COLUMNS
-                        and ls0.shape == ls.shape and np.array_equal(ls0, ls)
-                        and gp.jitter1 == JITTER_KERNEL and gp.jitter2 == JITTER_ASSEMBLY
-                        and np.array_equal(X[:n0], X0) and np.array_equal(y[:n0], y0)):
-                    try:
-                        for i in range(n0, len(X)):
-                            gp.append(X[i], y[i])
-                        appended = True
-                    except np.linalg.LinAlgError:
-                        pass  # numerically singular through the update: the full route decides (and raises if so)
+                can_append = (n0 < len(X) <= n0 + MAX_APPEND_ROWS and gp.N == n0 and X0.shape[1:] == X.shape[1:]
+                              and gp.n_appended + (len(X) - n0) <= MAX_APPENDED_COLUMNS
+                              and ls0.shape == ls.shape and np.array_equal(ls0, ls)
+                              and gp.jitter1 == JITTER_KERNEL and gp.jitter2 == JITTER_ASSEMBLY
+                              and np.array_equal(X[:n0], X0) and np.array_equal(y[:n0], y0))
+            # the route is a collective decision: a rank that appends while another refactorises would hold factors
+            # that differ at rounding level, and the lowest-index tie rule across shards assumes identical factors
+            if D.all_agree(can_append) if self._shard else can_append:
+                try:
+                    for i in range(n0, len(X)):
+                        gp.append(X[i], y[i])
+                    appended = True
+                except np.linalg.LinAlgError:
+                    pass  # numerically singular through the update: the full route decides (and raises if so)
+                if self._shard:
+                    appended = D.all_agree(appended)
         if not appended:
             gp.factorise(X, y, ls, JITTER_KERNEL, JITTER_ASSEMBLY, check=True)
         self.last_update = "append" if appended else "factorise"
         if self._incremental:
             self._inc = (X.copy(), y.copy(), ls.copy())
-            if self._state_path is not None:
+            if self._state_path is not None and rank == 0:   # one writer; DeviceGP.save_state renames atomically
                 gp.save_state(self._state_path)
 
     @staticmethod

@@ -166,7 +166,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))  # only reached for a forced one-rank group
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":

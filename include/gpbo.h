@@ -111,8 +111,8 @@ int gpbo_factorise_f64(const double *X, const double *y, int64_t N, int32_t d, c
  *   U [Np x Np]: column N is written (U' = [U, -U l/lambda; 0, 1/lambda], l = U^T k, lambda^2 = K_NN - l.l);
  *   alpha [Np]: recomputed as U'(U'^T y');   Kp [Np x Np] or NULL: row and column N of K.
  * Needs N + 1 <= Np (Np a multiple of 64; the caller re-pads into larger buffers when the padding is used up:
- * identity on the new diagonal).  info (device int32): 0, or N+1 when the new pivot is not positive - U is then
- * unchanged, alpha is not meaningful, and the caller refactorises.  work: gpbo_append_workspace_bytes(Np). */
+ * identity on the new diagonal).  info (device int32): 0, or N+1 when the new pivot is not positive - U and alpha are
+ * then unchanged (the surrogate of the N old observations stays valid) and the caller refactorises.  work: gpbo_append_workspace_bytes(Np). */
 int64_t gpbo_append_workspace_bytes(int64_t Np);
 int gpbo_append_f64(double *X, double *y, int64_t N, int32_t d, const double *ls_host, double jitter1,
                     double jitter2, int64_t Np, const double *x_new, const double *y_new, double *Kp, double *U,

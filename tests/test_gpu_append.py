@@ -78,10 +78,16 @@ def test_append_reports_a_failed_pivot():
     """Without jitter a duplicate makes K singular: info = N+1, the error names factorise() as the way out."""
     X, y, Xs, ls = make_problem(32, 512, 2)
     gp = DeviceGP(chunk=512).factorise(X, y, ls, jitter1=1e-4, jitter2=0.0)
+    before = gp.score(Xs, dense=True)
+    mu0, sig0 = before.mu.cpu().numpy().copy(), before.sigma.cpu().numpy().copy()
     gp.jitter1 = -1e-3  # the appended diagonal falls below l.l
     with pytest.raises(np.linalg.LinAlgError):
         gp.append(X[3], y[3])
     assert gp.N == 32
+    # a caller that catches the error and keeps scoring gets the surrogate of the 32 old observations, bit for bit
+    after = gp.score(Xs, dense=True)
+    assert after.best_idx == before.best_idx and after.best_val == before.best_val
+    assert np.array_equal(after.mu.cpu().numpy(), mu0) and np.array_equal(after.sigma.cpu().numpy(), sig0)
 
 
 def test_state_round_trip_then_append(tmp_path):

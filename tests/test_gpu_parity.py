@@ -514,7 +514,12 @@ def test_exchange_step_over_rccl_in_a_one_rank_group():
 
     if dist.is_initialized():
         pytest.skip("a process group is already initialised in this process")
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+    import socket
+
+    with socket.socket() as sk:  # a free port, not a fixed one (shared hosts)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         for rec in [(3.25, 17, 0), (-0.0, 2 ** 40 + 3, 5), (float("-inf"), 0, 0), (1e-310, 9, 1)]:

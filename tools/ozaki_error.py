@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Error analysis for computing V = K* U (the variance product, N^2 flop per candidate) from int8 slices on the
+integer matrix cores (Ozaki-style splitting) instead of fp64 MFMA.  CPU emulation, exact integer arithmetic:
+every slice product is an exact integer (|sum| <= N * 2^14 < 2^53, carried in fp64 here, int32 on the GPU).
+
+  k  (entries in [0, 1])          -> sk balanced base-256 digits of round(k * 2^(8 sk - 1))
+  U  (column j scaled by 2^-e_j)   -> su balanced base-256 digits of round(U_ij 2^-e_j * 2^(8 su - 1))
+  v_j = 2^e_j * sum_{a+b < keep} 2^-8(a+b+2)+2 * (K_a U_b)_j          (digit pairs beyond `keep` diagonals dropped)
+Reports max |delta sigma| and |delta sigma^2| against an extended-precision reference and against the fp64 path,
+for the benchmark problem (Sobol X, ARD length scales geomspace(0.2, 2, d))."""
+import argparse
+import sys
+import os
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bayesian_optimisation_amd.synthetic import make_problem  # noqa: E402
+from oracle import gp_oracle as O  # noqa: E402
+
+
+def digits(Xint, s):
+    """balanced base-256 digits, most significant first: Xint = sum_a D_a 256^(s-1-a), D_a in [-128, 127]"""
+    out = []
+    r = Xint.copy()
+    for _ in range(s):
+        lo = ((r + 128) % 256) - 128
+        out.append(lo.astype(np.float64))
+        r = (r - lo) // 256
+    assert np.all(r == 0), "top digit overflow"
+    return out[::-1]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--m", type=int, default=256)
+    ap.add_argument("--ref", type=int, default=32, help="candidates checked against the extended-precision product")
+    a = ap.parse_args()
+    X, y, Xs, ls = make_problem(a.n, a.m, a.d)
+    # candidates near observations too (small sigma is where an error in sigma^2 is amplified most)
+    Xs[: a.m // 4] = X[: a.m // 4] + 1e-3 * np.random.default_rng(0).standard_normal((a.m // 4, a.d))
+    K, L, alpha = O.factorise(X, y, ls)
+    import scipy.linalg as sla
+
+    U = sla.solve_triangular(L, np.eye(a.n), lower=True).T.copy()  # L^-T
+    ks = O.kernel_rbf(Xs, X, ls)  # (m, N)
+    v64 = ks @ U
+    var64 = O.PRIOR_VAR - np.einsum("mn,mn->m", v64, v64)
+    sig64 = np.sqrt(np.abs(var64))
+    print(f"N={a.n} d={a.d}: max|U|={np.abs(U).max():.3g}  max col 1-norm={np.abs(U).sum(0).max():.3g}  "
+          f"|U|_F={np.linalg.norm(U):.3g}  sigma range [{sig64.min():.3g}, {sig64.max():.3g}]")
+    # extended precision reference of the same product (x87 80-bit) on a few candidates
+    r = min(a.ref, a.m)
+    t0 = time.time()
+    vref = (ks[:r].astype(np.longdouble) @ U.astype(np.longdouble))
+    varref = np.longdouble(O.PRIOR_VAR) - np.einsum("mn,mn->m", vref, vref)
+    sigref = np.sqrt(np.abs(varref)).astype(np.float64)
+    print(f"reference product on {r} candidates: {time.time() - t0:.1f} s;  fp64 path vs reference: "
+          f"max|dsigma|={np.abs(sig64[:r] - sigref).max():.3g}")
+    ej = np.ceil(np.log2(np.abs(U).max(axis=0)))  # column exponents
+    Us = U * 2.0 ** (-ej)[None, :]                  # |Us| <= 1
+    for sk, su, keep in [(4, 4, 4), (5, 5, 5), (6, 6, 6), (6, 6, 5), (7, 7, 7), (5, 6, 6), (6, 5, 6), (5, 5, 4)]:
+        Kint = np.rint(ks * 2.0 ** (8 * sk - 2)).astype(np.int64)
+        Uint = np.rint(Us * 2.0 ** (8 * su - 2)).astype(np.int64)
+        Kint = np.minimum(Kint, 2 ** (8 * sk - 2) - 1)
+        Uint = np.clip(Uint, -(2 ** (8 * su - 2)) + 1, 2 ** (8 * su - 2) - 1)
+        Kd, Ud = digits(Kint, sk), digits(Uint, su)
+        nprod = 0
+        groups = {}
+        for i in range(sk):
+            for j in range(su):
+                if i + j < keep:
+                    groups.setdefault(i + j, 0.0)
+                    groups[i + j] = groups[i + j] + Kd[i] @ Ud[j]  # exact integers
+                    nprod += 1
+        v = 0.0
+        for g in sorted(groups, reverse=True):  # smallest contributions first
+            # digit a of k has weight 256^(sk-1-a) / 2^(8 sk - 1); same for U
+            v = v + groups[g] * 2.0 ** (-8 * (g + 2) + 2 + 8 * 0)
+        # weight check: Kint = sum_a Kd[a] 256^(sk-1-a) -> k = Kint 2^-(8sk-2) = sum_a Kd[a] 2^(-8a-6); product 2^(-8(a+b)-12)
+        v = v * 2.0 ** (-12 - (-16 + 2))
+        v = v * 2.0 ** ej[None, :]
+        var = O.PRIOR_VAR - np.einsum("mn,mn->m", v, v)
+        sig = np.sqrt(np.abs(var))
+        print(f"sk={sk} su={su} keep={keep}: {nprod:2d} int8 products  max|dv|={np.abs(v - v64).max():.3g}  "
+              f"max|dsigma^2| vs fp64 {np.abs(var - var64).max():.3g}  max|dsigma| vs fp64 {np.abs(sig - sig64).max():.3g}  "
+              f"vs reference {np.abs(sig[:r] - sigref).max():.3g}")
+
+
+if __name__ == "__main__":
+    main()
