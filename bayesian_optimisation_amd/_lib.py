@@ -56,7 +56,10 @@ SIGNATURES = {
     "gpbo_prepare_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p]),
     "gpbo_posterior_workspace_bytes_f32": (_i64, [_i64, _i64, _i64]),
     "gpbo_posterior_acq_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _i32, _f64, _f64, _f64,
-                                         _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _p]),
+                                         _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
+    "gpbo_rescore_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "gpbo_rescore_f64": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _i32, _f64, _f64, _i64,
+                                   _f64, _i64, _i64, _i64, _p, _p, _p, _i64, _p]),
     "gpbo_acq_workspace_bytes": (_i64, []),
     "gpbo_acq_argmax_f64": (C.c_int, [_p, _p, _i64, _i32, _f64, _f64, _i64, _p, _p, _p, _i64, _p]),
     "gpbo_nlml_grid_max_n": (C.c_int, []),
@@ -68,6 +71,12 @@ SIGNATURES = {
 
 _lib = None
 hip_used_before_pytorch = False  # a host-pointer entry point initialised HIP while PyTorch was not imported
+
+
+class ScreenStats(C.Structure):
+    """gpbo_screen_stats (include/gpbo.h)."""
+    _fields_ = [("survivors", _i64), ("rescored", _i64), ("rounds", _i32), ("fallback", _i32), ("tau", _f64),
+                ("err_max", _f64)]
 
 
 class GpboError(RuntimeError):

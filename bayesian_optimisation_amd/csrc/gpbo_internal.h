@@ -26,7 +26,27 @@ __device__ __forceinline__ d4_t mfma_f64_16x16x4(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// (value, index) order of every arg-max reduction: larger value first, ties to the LOWER index (point_selector.py:207)
+__device__ __forceinline__ bool gpbo_better(double v2, int64_t i2, double v, int64_t i) {
+    return (v2 > v) || (v2 == v && i2 < i);
+}
+
+// acquisition value from the posterior mean and standard deviation (point_selector.py:204; EI: SURVEY.md 8 a10)
+__device__ __forceinline__ double gpbo_acquisition(int kind, double mu, double sigma, double p0, double p1) {
+    if (kind == GPBO_ACQ_LCB) return p0 * sigma - mu;
+    // Expected improvement for minimisation: imp = f_best - mu - xi
+    const double imp = p0 - mu - p1;
+    if (!(sigma > 0.0)) return (sigma == 0.0) ? fmax(imp, 0.0) : sigma;  // sigma NaN propagates
+    const double z = imp / sigma;
+    const double cdf = 0.5 * erfc(-z * 0.70710678118654752440);
+    const double pdf = exp(-0.5 * z * z) * 0.39894228040143267794;
+    return imp * cdf + sigma * pdf;
+}
+
 // launchers implemented in the individual .hip files (host side, enqueue only)
+int gpbo_kstar_mu_mixed(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
+                        const double *ls_host, const double *alpha, double diag_add, int64_t cand_base, float *KsT,
+                        int64_t ldk, double *mu_part, void *stream);
 int gpbo_kxx_launch(const double *X, int64_t N, int32_t d, const double *ls_host, double jitter1, double jitter2,
                     double *Kp, int64_t Np, double *K2, int32_t *info0, void *stream);
 int gpbo_scale_points_launch(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host, double *Xsc,

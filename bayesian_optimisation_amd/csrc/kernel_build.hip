@@ -109,11 +109,21 @@ __device__ __forceinline__ double exp_neg(double t, const double *tab /* LDS, 32
 // ---------------------------------------------------------------------------------------------
 constexpr int KS_SLICE = GPBO_KS_SLICE;
 
-template <int D, int VARIANT, bool HAS_DIAG>
+typedef float f2_t __attribute__((ext_vector_type(2)));
+// two adjacent candidates' entries of one K*^T row: 16 B (fp64) or, rounded once to fp32, 8 B (the fp32 screen)
+__device__ __forceinline__ void store_pair(double *p, double a, double b) { *reinterpret_cast<d2_t *>(p) = d2_t{a, b}; }
+__device__ __forceinline__ void store_pair(float *p, double a, double b) {
+    *reinterpret_cast<f2_t *>(p) = f2_t{(float)a, (float)b};
+}
+
+// TK = double: the fp64 path.  TK = float (gpbo_kstar_mu_mixed): entries and means are computed exactly as in the
+// fp64 path - the mean partials are the same doubles bit for bit - and only the stored K*^T is rounded to fp32
+// (relative error <= 2^-24 per entry) for the fp32 variance screen.
+template <int D, int VARIANT, bool HAS_DIAG, typename TK>
 __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict__ Xs, int64_t Mc,
                                                        const double *__restrict__ Xsc, int N, LsArgs ls,
                                                        const double *__restrict__ alpha, double diag_add,
-                                                       int64_t cand_base, double *__restrict__ KsT, int64_t ldk,
+                                                       int64_t cand_base, TK *__restrict__ KsT, int64_t ldk,
                                                        double *__restrict__ mu_part) {
     __shared__ double tab[32];
     if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
         nan_a = nan_a || (xa[k] != xa[k]);
         nan_b = nan_b || (xb[k] != xb[k]);
     }
-    double *out = KsT + (int64_t)n0 * ldk + c0;
+    TK *out = KsT + (int64_t)n0 * ldk + c0;
     int nend = n0 + KS_SLICE;
     if (nend > N) nend = N;  // observations beyond N are padding: exact zeros, written below
     // two observations per trip: four independent distance/exp chains per thread (the loop is bound by the
@@ -166,10 +176,9 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
         mub = fma(k01, a0, mub);
         mua = fma(k10, a1, mua);
         mub = fma(k11, a1, mub);
-        const d2_t kv0 = {k00, k01}, kv1 = {k10, k11};
         if (VARIANT != 1) {
-            *reinterpret_cast<d2_t *>(out) = kv0;
-            *reinterpret_cast<d2_t *>(out + ldk) = kv1;
+            store_pair(out, k00, k01);
+            store_pair(out + ldk, k10, k11);
         } else {
             mua += (k00 + k10) * 1e-300;
             mub += (k01 + k11) * 1e-300;
@@ -193,14 +202,12 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
         const double an = alpha[n];
         mua = fma(ka, an, mua);
         mub = fma(kb, an, mub);
-        const d2_t kv = {ka, kb};
-        *reinterpret_cast<d2_t *>(out) = kv;
+        store_pair(out, ka, kb);
         out += ldk;
         ++n;
     }
-    const d2_t zero = {0.0, 0.0};
     for (n = (nend > n0 ? nend : n0); n < n0 + KS_SLICE; ++n) {
-        *reinterpret_cast<d2_t *>(out) = zero;
+        store_pair(out, 0.0, 0.0);
         out += ldk;
     }
     d2_t m = {nan_a ? __builtin_nan("") : mua, nan_b ? __builtin_nan("") : mub};
@@ -312,7 +319,7 @@ extern "C" int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *Xsc
     constexpr int variant = 0;
 #endif
 #define KSTAR_LAUNCH(DD, V, H)                                                                                       \
-    hipLaunchKernelGGL((kstar_mu_kernel<DD, V, H>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, Xsc, (int)N, ls, \
+    hipLaunchKernelGGL((kstar_mu_kernel<DD, V, H, double>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, Xsc, (int)N, ls, \
                        alpha, diag_add, cand_base, KsT, ldk, mu_part)
 #ifdef GPBO_DIAGNOSTICS
 #define CALL(DD)                                        \
@@ -326,6 +333,31 @@ extern "C" int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *Xsc
     else KSTAR_LAUNCH(DD, 0, false)
 #endif
     (void)variant;
+    GPBO_DISPATCH_D(d, CALL)
+#undef CALL
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
+// Same build with K*^T stored in fp32 (rows of `ldk` floats, Np rows, Np a multiple of 64) and the mean partials in
+// fp64: the front end of the fp32 variance screen (posterior_f32.hip).
+int gpbo_kstar_mu_mixed(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
+                        const double *ls_host, const double *alpha, double diag_add, int64_t cand_base, float *KsT,
+                        int64_t ldk, double *mu_part, void *stream) {
+    if (!Xs || !Xsc || !alpha || !KsT || !mu_part) return GPBO_ERR_ARG;
+    if (Mc < 1 || N < 1 || Np < N || Np % KS_SLICE != 0 || ldk % GPBO_CHUNK_GRANULE != 0 || Mc > ldk) return GPBO_ERR_ARG;
+    LsArgs ls;
+    int rc = make_ls(ls_host, d, &ls);
+    if (rc != GPBO_OK) return rc;
+    const int64_t used = (Mc + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
+    dim3 grid((unsigned)(used / 512), (unsigned)(Np / KS_SLICE));
+#define CALL(DD)                                                                                                     \
+    if (diag_add != 0.0)                                                                                             \
+        hipLaunchKernelGGL((kstar_mu_kernel<DD, 0, true, float>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, Xsc,    \
+                           (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part);                               \
+    else                                                                                                             \
+        hipLaunchKernelGGL((kstar_mu_kernel<DD, 0, false, float>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, Xsc,   \
+                           (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part)
     GPBO_DISPATCH_D(d, CALL)
 #undef CALL
     GPBO_CHECK_LAUNCH();

@@ -1,10 +1,13 @@
 // fp32 scoring path (BASELINE.json config 4: d=16, N=8192, fp32 candidates).
 //
 // Same mathematics as kernel_build.hip / sigma_acq.hip (reference: point_selector.py:81, :90-98, :204-207)
-// with the M-proportional work in fp32: K(X*,X) entries, the mean dot products and the triangular
-// product on v_mfma_f32_16x16x4_f32.  The factorisation stays in fp64 (cond(K) ~ 1e6 with the
-// reference's 1.01e-4 jitter: an fp32 Cholesky at N = 8192 meets non-positive pivots) and U, alpha are
-// rounded to fp32 once per BO step by gpbo_prepare_f32.
+// with the N^2-per-candidate work - the triangular product - in fp32 on v_mfma_f32_16x16x4_f32.
+// K(X*,X) entries and the mean are computed in fp64 exactly as in the fp64 path (kernel_build.hip,
+// gpbo_kstar_mu_mixed: the mean is the fp64 path's mean bit for bit; 2N of the N^2 flops per candidate) and only the
+// stored K*^T is rounded to fp32.  The factorisation stays in fp64 (cond(K) ~ 1e6 with the reference's 1.01e-4
+// jitter: an fp32 Cholesky at N = 8192 meets non-positive pivots) and U is rounded to fp32 once per BO step by
+// gpbo_prepare_f32.  This pass is a SCREEN: its variance carries fp32 error, so the arg-max is decided by
+// rescore.hip, which re-scores every candidate that could still be the maximum through the fp64 kernels.
 //
 // Variance kernel geometry (differs from the fp64 one because elements are 4 bytes):
 //   workgroup 512 threads, 256 candidates x 256 columns of V, 16-deep k tiles, 3-stage LDS ring fed by
@@ -36,19 +39,7 @@ __device__ __forceinline__ void glds16f(const float *g, float *l) {
     __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)l, 16, 0, 0);
 }
 
-__device__ __forceinline__ bool better(double v2, int64_t i2, double v, int64_t i) {
-    return (v2 > v) || (v2 == v && i2 < i);
-}
-
-__device__ __forceinline__ float acquisition32(int kind, float mu, float sigma, float p0, float p1) {
-    if (kind == GPBO_ACQ_LCB) return p0 * sigma - mu;
-    const float imp = p0 - mu - p1;
-    if (!(sigma > 0.0f)) return (sigma == 0.0f) ? fmaxf(imp, 0.0f) : sigma;
-    const float z = imp / sigma;
-    const float cdf = 0.5f * erfcf(-z * 0.70710678118654752440f);
-    const float pdf = expf(-0.5f * z * z) * 0.39894228040143267794f;
-    return imp * cdf + sigma * pdf;
-}
+__device__ __forceinline__ bool better(double v2, int64_t i2, double v, int64_t i) { return gpbo_better(v2, i2, v, i); }
 
 // ---- U32 / alpha32: fp32 copies of the fp64 factors, re-padded to Np32 (identity / zeros on the padding)
 __global__ __launch_bounds__(256) void prepare_f32_kernel(const double *__restrict__ U, const double *__restrict__ alpha,
@@ -61,76 +52,15 @@ __global__ __launch_bounds__(256) void prepare_f32_kernel(const double *__restri
         if (r < Np && c < Np) v = (float)U[r * Np + c];
         U32[e] = v;
     }
-    if (e < Np32) alpha32[e] = (e < Np) ? (float)alpha[e] : 0.0f;
-}
-
-__global__ __launch_bounds__(256) void scale_points_f32_kernel(const double *__restrict__ X, int64_t N, int64_t Np32, int d,
-                                                              LsArgs32 ls, float *__restrict__ Xsc) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= Np32 * d) return;
-    const int64_t n = e / d;
-    const int k = (int)(e - n * d);
-    Xsc[e] = (n < N) ? (float)(X[e] * ls.isc[k]) : 0.0f;
-}
-
-// ---- K(X*,X)^T chunk in fp32 + partial means: thread = 4 adjacent candidates (16-byte stores)
-template <int D>
-__global__ __launch_bounds__(256) void kstar_mu_f32_kernel(const double *__restrict__ Xs, int64_t Mc,
-                                                           const float *__restrict__ Xsc, int N, LsArgs32 ls,
-                                                           const float *__restrict__ alpha, float diag_add,
-                                                           int64_t cand_base, float *__restrict__ KsT, int64_t ldk,
-                                                           float *__restrict__ mu_part) {
-    const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    const int n0 = blockIdx.y * KS_SLICE;
-    float x[4][D];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int k = 0; k < D; ++k) x[j][k] = (c0 + j < Mc) ? (float)(Xs[(c0 + j) * D + k] * ls.isc[k]) : 0.0f;
-    float mu[4] = {0.f, 0.f, 0.f, 0.f};
-    float *out = KsT + (int64_t)n0 * ldk + c0;
-    int nend = n0 + KS_SLICE;
-    if (nend > N) nend = N;
-    const bool has_diag = diag_add != 0.0f;
-    int n = n0;
-    for (; n < nend; ++n) {
-        const float *xo = Xsc + (int64_t)n * D;  // wave-uniform row -> scalar loads
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const float o = xo[k];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dd = x[j][k] - o;
-                s[j] = fmaf(dd, dd, s[j]);
-            }
-        }
-        f4_t kv;
-        const float an = alpha[n];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float kj = __expf(-s[j]);
-            if (has_diag && (int64_t)n == cand_base + c0 + j) kj += diag_add;
-            mu[j] = fmaf(kj, an, mu[j]);
-            kv[j] = kj;
-        }
-        *reinterpret_cast<f4_t *>(out) = kv;
-        out += ldk;
-    }
-    const f4_t zero = {0.f, 0.f, 0.f, 0.f};
-    for (n = (nend > n0 ? nend : n0); n < n0 + KS_SLICE; ++n) {
-        *reinterpret_cast<f4_t *>(out) = zero;
-        out += ldk;
-    }
-    f4_t m = {mu[0], mu[1], mu[2], mu[3]};
-    *reinterpret_cast<f4_t *>(mu_part + (int64_t)blockIdx.y * ldk + c0) = m;
+    if (alpha32 && e < Np32) alpha32[e] = (e < Np) ? (float)alpha[e] : 0.0f;
 }
 
 // ---- variance + acquisition + block arg-max, fp32 MFMA
 __global__ __launch_bounds__(512) void sigma_acq_f32_kernel(
-    const float *__restrict__ KsT, int64_t ldk, const float *__restrict__ U, int Np, const float *__restrict__ mu_part,
-    int nsl, int64_t Mc, float prior_var, int acq_kind, float p0, float p1, int64_t idx_base,
-    float *__restrict__ mu_out, float *__restrict__ sigma_out, float *__restrict__ acq_out,
+    const float *__restrict__ KsT, int64_t ldk, const float *__restrict__ U, int Np, const double *__restrict__ mu_part,
+    int nsl, int64_t Mc, double prior_var, int acq_kind, double p0, double p1, int64_t idx_base,
+    double *__restrict__ mu_out, double *__restrict__ sigma_out, double *__restrict__ acq_out,
+    double *__restrict__ var_out /* signed prior_var - |v|^2 as the fp32 product leaves it (the screen's input) */,
     double *__restrict__ part_val, int64_t *__restrict__ part_idx, unsigned long long *__restrict__ nan_count) {
     __shared__ float smem[3 * STAGE];
 
@@ -277,20 +207,21 @@ __global__ __launch_bounds__(512) void sigma_acq_f32_kernel(
         const int64_t c = cand0 + tid;
         const bool valid = c < Mc;
         const float ssq = red[tid] + red[BM + tid];
-        float mu = 0.f;
+        double mu = 0.0;  // same fixed-order sum of the same fp64 partials as the fp64 path
         for (int s = 0; s < nsl; ++s) mu += mu_part[(int64_t)s * ldk + c];
-        const float var = prior_var - ssq;
-        const float sigma = sqrtf(fabsf(var));
-        const float acq = acquisition32(acq_kind, mu, sigma, p0, p1);
+        const double var = prior_var - (double)ssq;
+        const double sigma = sqrt(fabs(var));
+        const double acq = gpbo_acquisition(acq_kind, mu, sigma, p0, p1);
         if (valid) {
             if (mu_out) mu_out[c] = mu;
             if (sigma_out) sigma_out[c] = sigma;
             if (acq_out) acq_out[c] = acq;
+            if (var_out) var_out[c] = var;
         }
         const bool is_nan = valid && (acq != acq);
         const unsigned long long nan_mask = __ballot(is_nan);
         if (lane == 0 && nan_mask) atomicAdd(nan_count, (unsigned long long)__popcll(nan_mask));
-        double bv = (valid && !is_nan) ? (double)acq : -std::numeric_limits<double>::infinity();
+        double bv = (valid && !is_nan) ? acq : -std::numeric_limits<double>::infinity();
         int64_t bi = (valid && !is_nan) ? idx_base + c : std::numeric_limits<int64_t>::max();
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -323,23 +254,13 @@ Layout32 layout32(int64_t Np32, int64_t chunk, int64_t M) {
     L.nparts_cap = nchunks * (chunk / BM);
     int64_t off = 0;
     L.kst_off = off; off += align_up((int64_t)sizeof(float) * Np32 * chunk, 256);
-    L.mup_off = off; off += align_up((int64_t)sizeof(float) * (Np32 / KS_SLICE) * chunk, 256);
-    L.xsc_off = off; off += align_up((int64_t)sizeof(float) * Np32 * GPBO_MAX_D, 256);
+    L.mup_off = off; off += align_up((int64_t)sizeof(double) * (Np32 / KS_SLICE) * chunk, 256);
+    L.xsc_off = off; off += align_up((int64_t)sizeof(double) * Np32 * GPBO_MAX_D, 256);
     L.pval_off = off; off += align_up((int64_t)sizeof(double) * L.nparts_cap, 256);
     L.pidx_off = off; off += align_up((int64_t)sizeof(int64_t) * L.nparts_cap, 256);
     L.nan_off = off; off += 256;
     L.total = off;
     return L;
-}
-
-int make_ls32(const double *ls_host, int d, LsArgs32 *out) {
-    if (!ls_host || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
-    for (int k = 0; k < GPBO_MAX_D; ++k) out->isc[k] = 0.0;
-    for (int k = 0; k < d; ++k) {
-        if (!(ls_host[k] > 0.0)) return GPBO_ERR_ARG;
-        out->isc[k] = 1.0 / (ls_host[k] * 1.4142135623730950488);
-    }
-    return GPBO_OK;
 }
 
 }  // namespace
@@ -351,7 +272,7 @@ extern "C" int64_t gpbo_padded_n_f32(int64_t N) {
 
 extern "C" int gpbo_prepare_f32(const double *U, const double *alpha, int64_t Np, float *U32, float *alpha32,
                                 int64_t Np32, void *stream) {
-    if (!U || !alpha || !U32 || !alpha32 || Np < 1 || Np32 < Np || Np32 % BN) return GPBO_ERR_ARG;
+    if (!U || !U32 || (alpha32 && !alpha) || Np < 1 || Np32 < Np || Np32 % BN) return GPBO_ERR_ARG;
     const int64_t tot = Np32 * Np32;
     hipLaunchKernelGGL(prepare_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, gpbo_stream(stream), U, alpha,
                        Np, U32, alpha32, Np32);
@@ -365,66 +286,60 @@ extern "C" int64_t gpbo_posterior_workspace_bytes_f32(int64_t Np32, int64_t chun
 }
 
 extern "C" int gpbo_posterior_acq_f32(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np32, int32_t d,
-                                      const double *ls_host, const float *U32, const float *alpha32, double prior_var,
+                                      const double *ls_host, const float *U32, const double *alpha, double prior_var,
                                       int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset,
-                                      int64_t chunk, float *mu_out, float *sigma_out, float *acq_out,
+                                      int64_t chunk, double *mu_out, double *sigma_out, double *acq_out, double *var_out,
                                       gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof,
                                       void *stream) {
-    if (!Xs || !X || !U32 || !alpha32 || !result || !work) return GPBO_ERR_ARG;
+    if (!Xs || !X || !U32 || !alpha || !result || !work) return GPBO_ERR_ARG;
     if (M < 1 || N < 1 || Np32 != gpbo_padded_n_f32(N)) return GPBO_ERR_ARG;
-    if (chunk < 1024 || chunk % 1024 || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;  // kstar workgroups cover 1024 candidates
+    if (chunk < 1024 || chunk % 1024 || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
     if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
     if (((uintptr_t)work & 255) || ((uintptr_t)U32 & 15)) return GPBO_ERR_ARG;
     const Layout32 L = layout32(Np32, chunk, M);
     if (work_bytes < L.total) return GPBO_ERR_WORKSPACE;
-    LsArgs32 ls;
-    int rc = make_ls32(ls_host, d, &ls);
-    if (rc != GPBO_OK) return rc;
     hipStream_t st = gpbo_stream(stream);
     char *w = reinterpret_cast<char *>(work);
     float *KsT = reinterpret_cast<float *>(w + L.kst_off);
-    float *mu_part = reinterpret_cast<float *>(w + L.mup_off);
-    float *Xsc = reinterpret_cast<float *>(w + L.xsc_off);
+    double *mu_part = reinterpret_cast<double *>(w + L.mup_off);
+    double *Xsc = reinterpret_cast<double *>(w + L.xsc_off);
     double *part_val = reinterpret_cast<double *>(w + L.pval_off);
     int64_t *part_idx = reinterpret_cast<int64_t *>(w + L.pidx_off);
     unsigned long long *nan_count = reinterpret_cast<unsigned long long *>(w + L.nan_off);
-    if (hipMemsetAsync(nan_count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
-    {
-        const int64_t tot = Np32 * d;
-        hipLaunchKernelGGL(scale_points_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, N, Np32, (int)d,
-                           ls, Xsc);
-    }
+    // observations / (ls sqrt 2) in fp64, once per call; the same launch clears the NaN counter
+    int rc = gpbo_scale_points_launch(X, N, Np32, d, ls_host, Xsc, nan_count, stream);
+    if (rc != GPBO_OK) return rc;
     int64_t nparts = 0;
+    bool prev_recorded = false;
     for (int64_t s = 0; s < M; s += chunk) {
         const int64_t Mc = (M - s < chunk) ? (M - s) : chunk;
-        const int64_t used = (Mc + 1023) / 1024 * 1024;
-        dim3 kgrid((unsigned)(used / 1024), (unsigned)(Np32 / KS_SLICE));
-#define CALL(DD)                                                                                                        \
-    hipLaunchKernelGGL(kstar_mu_f32_kernel<DD>, kgrid, dim3(256), 0, st, Xs + s * d, Mc, Xsc, (int)N, ls, alpha32,            \
-                       (float)diag_add, idx_offset + s, KsT, chunk, mu_part)
-        switch (d) {
-            case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;   case 4: CALL(4); break;
-            case 5: CALL(5); break;   case 6: CALL(6); break;   case 7: CALL(7); break;   case 8: CALL(8); break;
-            case 9: CALL(9); break;   case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break;
-            case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break;
-            default: return GPBO_ERR_ARG;
+        // K(X*,X) launches are timed like the fp64 path's: the launches of this call form one chain on the stream
+        const bool krec = prof && prof->count < prof->capacity;
+        if (krec) {
+            const bool chained = s > 0 && prof->count > 0 && prev_recorded;
+            prof->kmode[prof->count] = chained ? 2 : 1;
+            if (!chained && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->kbegin[prof->count]), st) != hipSuccess)
+                return GPBO_ERR_LAUNCH;
         }
-#undef CALL
+        rc = gpbo_kstar_mu_mixed(Xs + s * d, Mc, Xsc, N, Np32, d, ls_host, alpha, diag_add, idx_offset + s, KsT, chunk,
+                                 mu_part, stream);
+        if (rc != GPBO_OK) return rc;
         const int64_t nblk = (Mc + BM - 1) / BM;
-        const bool rec = prof && prof->count < prof->capacity;
+        const bool rec = krec;
         if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
         hipLaunchKernelGGL(sigma_acq_f32_kernel, dim3((unsigned)nblk), dim3(512), 0, st, KsT, chunk, U32, (int)Np32, mu_part,
-                           (int)(Np32 / KS_SLICE), Mc, (float)prior_var, (int)acq_kind, (float)p0, (float)p1, idx_offset + s,
+                           (int)(Np32 / KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                            mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
-                           acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count);
+                           acq_out ? acq_out + s : nullptr, var_out ? var_out + s : nullptr, part_val + nparts,
+                           part_idx + nparts, nan_count);
         if (rec) {
             if (hipEventRecord(reinterpret_cast<hipEvent_t>(prof->end[prof->count]), st) != hipSuccess)
                 return GPBO_ERR_LAUNCH;
             prof->cands[prof->count] = Mc;
-            prof->kmode[prof->count] = 0;  // the fp32 K(X*,X) launches are not timed separately
             ++prof->count;
         }
+        prev_recorded = rec;
         GPBO_CHECK_LAUNCH();
         nparts += nblk;
     }

@@ -1,0 +1,272 @@
+// Exact arg-max behind an fp32 screen (BASELINE.json config 4; the tie / first-index rule of point_selector.py:204-207).
+//
+// The fp32 pass (posterior_f32.hip) leaves, for every candidate c, the mean mu_c - the fp64 path's value bit for
+// bit - and var32_c = prior_var - |v_c|^2 with the N^2 product done in fp32.  If the fp64 variance lies within
+// tau of it,  |var64_c - var32_c| <= tau,  then with  s_lo = sqrt(max(|var32| - tau, 0)),  s_hi = sqrt(|var32| + tau)
+// (both acquisitions increase with sigma: d LCB / d sigma = explore > 0, d EI / d sigma = pdf(z) > 0)
+//     acq(mu_c, s_lo)  <=  acq64_c  <=  acq(mu_c, s_hi)
+// and a candidate whose upper bound is below  L = max_c acq(mu_c, s_lo)  cannot be the fp64 maximum.  Everything else
+// (plus every stride-th candidate, as a sample of the non-survivors) is gathered and re-scored through the fp64
+// kernels; the reported maximum and its LOWEST index are taken over those fp64 values alone.
+// tau is not proven a priori - a worst-case fp32 bound over N = 8192 terms is orders of magnitude above the errors
+// that occur - it is checked on every call: the largest |var64 - var32| seen on the re-scored set must stay below
+// tau / 4, otherwise tau is raised to 8x that error and the selection repeated.  When the survivors do not fit `cap`
+// (e.g. thousands of exact ties far from the data) the caller is told to run the plain fp64 pass (stats->fallback).
+#include "gpbo_internal.h"
+
+#include <limits>
+
+namespace {
+
+constexpr int SB = 256;  // threads per workgroup of the streaming kernels
+
+__device__ __forceinline__ void bounds(int kind, double mu, double var, double tau, double p0, double p1, double &lo,
+                                       double &hi) {
+    const double a = fabs(var);
+    const double s_lo = sqrt(fmax(a - tau, 0.0)), s_hi = sqrt(a + tau);
+    lo = gpbo_acquisition(kind, mu, s_lo, p0, p1);
+    hi = gpbo_acquisition(kind, mu, s_hi, p0, p1);
+}
+
+// per-workgroup maximum of the lower bounds (NaNs skipped: they survive the selection unconditionally)
+__global__ __launch_bounds__(SB) void screen_lo_kernel(const double *__restrict__ mu, const double *__restrict__ var,
+                                                       int64_t M, double tau, int kind, double p0, double p1,
+                                                       double *__restrict__ part) {
+    __shared__ double s_val[SB / 64];
+    double best = -std::numeric_limits<double>::infinity();
+    for (int64_t c = (int64_t)blockIdx.x * SB + threadIdx.x; c < M; c += (int64_t)gridDim.x * SB) {
+        double lo, hi;
+        bounds(kind, mu[c], var[c], tau, p0, p1, lo, hi);
+        if (lo > best) best = lo;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) best = fmax(best, __shfl_xor(best, off));
+    if ((threadIdx.x & 63) == 0) s_val[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < SB / 64; ++w) best = fmax(best, s_val[w]);
+        part[blockIdx.x] = best;
+    }
+}
+
+__global__ __launch_bounds__(SB) void screen_max_kernel(const double *__restrict__ part, int n, double *__restrict__ L,
+                                                        unsigned long long *__restrict__ count) {
+    __shared__ double s_val[SB / 64];
+    double best = -std::numeric_limits<double>::infinity();
+    for (int i = threadIdx.x; i < n; i += SB) best = fmax(best, part[i]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) best = fmax(best, __shfl_xor(best, off));
+    if ((threadIdx.x & 63) == 0) s_val[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < SB / 64; ++w) best = fmax(best, s_val[w]);
+        *L = best;
+        *count = 0ull;
+    }
+}
+
+// survivors: upper bound >= L, or NaN anywhere (the fp64 pass must see and count it), or one of the strided sample.
+// The list order depends on the atomics; the fp64 results do not (every candidate's row is computed on its own).
+__global__ __launch_bounds__(SB) void screen_select_kernel(const double *__restrict__ mu, const double *__restrict__ var,
+                                                           int64_t M, double tau, int kind, double p0, double p1,
+                                                           const double *__restrict__ L, int64_t stride,
+                                                           int64_t *__restrict__ list, int64_t cap,
+                                                           unsigned long long *__restrict__ count) {
+    const double thr = *L;
+    const int lane = threadIdx.x & 63;
+    const int64_t step = (int64_t)gridDim.x * SB;
+    const int64_t cmax = (M + step - 1) / step * step;  // whole waves stay in the loop together (ballot)
+    for (int64_t c = (int64_t)blockIdx.x * SB + threadIdx.x; c < cmax; c += step) {
+        bool keep = false;
+        if (c < M) {
+            double lo, hi;
+            bounds(kind, mu[c], var[c], tau, p0, p1, lo, hi);
+            keep = !(hi < thr) || (c % stride) == 0;  // !(hi < thr): also true for NaN
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(m));
+            base = __shfl(base, 0);
+            if (keep) {
+                const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if ((int64_t)pos < cap) list[pos] = c;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(SB) void gather_rows_kernel(const double *__restrict__ Xs, int d, const int64_t *__restrict__ list,
+                                                         int64_t K, double *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * SB + threadIdx.x;
+    if (e >= K * d) return;
+    const int64_t i = e / d;
+    out[e] = Xs[list[i] * d + (e - i * d)];
+}
+
+struct RescoreOut {
+    gpbo_result res;
+    double err_max;  // max over the re-scored set of | sigma64^2 - |var32| |
+    double pad;
+};
+
+// one workgroup: fp64 arg-max over the re-scored candidates (ties to the lowest ORIGINAL index), NaN count, and the
+// largest deviation of the screen's variance from the fp64 one
+__global__ __launch_bounds__(SB) void rescore_finish_kernel(const double *__restrict__ acq, const double *__restrict__ sigma,
+                                                            const int64_t *__restrict__ list, int64_t K,
+                                                            const double *__restrict__ var32, int64_t idx_offset,
+                                                            RescoreOut *__restrict__ out) {
+    __shared__ double s_val[SB / 64], s_err[SB / 64];
+    __shared__ int64_t s_idx[SB / 64];
+    __shared__ unsigned long long s_nan[SB / 64];
+    double bv = -std::numeric_limits<double>::infinity(), err = 0.0;
+    int64_t bi = std::numeric_limits<int64_t>::max();
+    unsigned long long nans = 0;
+    for (int64_t i = threadIdx.x; i < K; i += SB) {
+        const double a = acq[i], sg = sigma[i];
+        const int64_t c = list[i];
+        if (a != a) ++nans;
+        else if (gpbo_better(a, idx_offset + c, bv, bi)) { bv = a; bi = idx_offset + c; }
+        const double e = fabs(sg * sg - fabs(var32[c]));
+        if (e > err) err = e;  // NaN never raises err; NaNs are reported through the count
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int64_t oi = __shfl_xor(bi, off);
+        err = fmax(err, __shfl_xor(err, off));
+        nans += __shfl_xor(nans, off);
+        if (gpbo_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_val[w] = bv; s_idx[w] = bi; s_err[w] = err; s_nan[w] = nans; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < SB / 64; ++q) {
+            if (gpbo_better(s_val[q], s_idx[q], bv, bi)) { bv = s_val[q]; bi = s_idx[q]; }
+            err = fmax(err, s_err[q]);
+            nans += s_nan[q];
+        }
+        out->res.best_val = bv;
+        out->res.best_idx = bi;
+        out->res.nan_count = (int64_t)nans;
+        out->res.reserved = 0;
+        out->err_max = err;
+        out->pad = 0.0;
+    }
+}
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct RescoreLayout {
+    int64_t part_off, L_off, count_off, list_off, rows_off, mu_off, sig_off, acq_off, out_off, post_off, post_bytes, total;
+};
+
+constexpr int SCREEN_BLOCKS = 1024;
+
+RescoreLayout rescore_layout(int64_t Np, int64_t cap, int64_t chunk64) {
+    RescoreLayout L;
+    int64_t off = 0;
+    L.part_off = off; off += align_up((int64_t)sizeof(double) * SCREEN_BLOCKS, 256);
+    L.L_off = off; off += 256;
+    L.count_off = off; off += 256;
+    L.out_off = off; off += 256;
+    L.list_off = off; off += align_up((int64_t)sizeof(int64_t) * cap, 256);
+    L.rows_off = off; off += align_up((int64_t)sizeof(double) * cap * GPBO_MAX_D, 256);
+    L.mu_off = off; off += align_up((int64_t)sizeof(double) * cap, 256);
+    L.sig_off = off; off += align_up((int64_t)sizeof(double) * cap, 256);
+    L.acq_off = off; off += align_up((int64_t)sizeof(double) * cap, 256);
+    L.post_off = off;
+    L.post_bytes = gpbo_posterior_workspace_bytes(Np, chunk64, cap);
+    off += align_up(L.post_bytes, 256);
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+
+extern "C" int64_t gpbo_rescore_workspace_bytes(int64_t Np, int64_t cap, int64_t chunk64) {
+    if (cap < 1 || gpbo_posterior_workspace_bytes(Np, chunk64, cap) < 0) return GPBO_ERR_ARG;
+    return rescore_layout(Np, cap, chunk64).total;
+}
+
+extern "C" int gpbo_rescore_f64(const double *Xs, int64_t M, const double *mu, const double *var32, const double *X,
+                                int64_t N, int64_t Np, int32_t d, const double *ls_host, const double *U,
+                                const double *alpha, double prior_var, int32_t acq_kind, double p0, double p1,
+                                int64_t idx_offset, double tau0, int64_t sample_stride, int64_t cap, int64_t chunk64,
+                                gpbo_result *result, gpbo_screen_stats *stats_host, void *work, int64_t work_bytes,
+                                void *stream) {
+    if (!Xs || !mu || !var32 || !X || !U || !alpha || !result || !stats_host || !work) return GPBO_ERR_ARG;
+    if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || d < 1 || d > GPBO_MAX_D || cap < 1 || !(tau0 > 0.0) || sample_stride < 1)
+        return GPBO_ERR_ARG;
+    if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
+    if (gpbo_posterior_workspace_bytes(Np, chunk64, cap) < 0 || ((uintptr_t)work & 255)) return GPBO_ERR_ARG;
+    const RescoreLayout L = rescore_layout(Np, cap, chunk64);
+    if (work_bytes < L.total) return GPBO_ERR_WORKSPACE;
+    hipStream_t st = gpbo_stream(stream);
+    char *w = reinterpret_cast<char *>(work);
+    double *part = reinterpret_cast<double *>(w + L.part_off);
+    double *Ldev = reinterpret_cast<double *>(w + L.L_off);
+    unsigned long long *count = reinterpret_cast<unsigned long long *>(w + L.count_off);
+    RescoreOut *out = reinterpret_cast<RescoreOut *>(w + L.out_off);
+    int64_t *list = reinterpret_cast<int64_t *>(w + L.list_off);
+    double *rows = reinterpret_cast<double *>(w + L.rows_off);
+    double *mu64 = reinterpret_cast<double *>(w + L.mu_off);
+    double *sig64 = reinterpret_cast<double *>(w + L.sig_off);
+    double *acq64 = reinterpret_cast<double *>(w + L.acq_off);
+    void *post = w + L.post_off;
+
+    int64_t nblk = (M + SB - 1) / SB;
+    if (nblk > SCREEN_BLOCKS) nblk = SCREEN_BLOCKS;
+    double tau = tau0;
+    gpbo_screen_stats stt = {0, 0, 0, 0, tau0, 0.0};
+    for (int round = 0; round < 4; ++round) {
+        stt.rounds = round + 1;
+        stt.tau = tau;
+        hipLaunchKernelGGL(screen_lo_kernel, dim3((unsigned)nblk), dim3(SB), 0, st, mu, var32, M, tau, (int)acq_kind, p0, p1,
+                           part);
+        hipLaunchKernelGGL(screen_max_kernel, dim3(1), dim3(SB), 0, st, part, (int)nblk, Ldev, count);
+        hipLaunchKernelGGL(screen_select_kernel, dim3((unsigned)nblk), dim3(SB), 0, st, mu, var32, M, tau, (int)acq_kind, p0,
+                           p1, Ldev, sample_stride, list, cap, count);
+        GPBO_CHECK_LAUNCH();
+        unsigned long long K = 0;
+        if (hipMemcpyAsync(&K, count, sizeof(K), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
+        stt.survivors = (int64_t)K;
+        if ((int64_t)K > cap) {  // too many candidates could still be the maximum: the plain fp64 pass decides
+            stt.fallback = 1;
+            *stats_host = stt;
+            return GPBO_OK;
+        }
+        const int64_t tot = (int64_t)K * d;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((tot + SB - 1) / SB)), dim3(SB), 0, st, Xs, (int)d, list,
+                           (int64_t)K, rows);
+        GPBO_CHECK_LAUNCH();
+        int64_t chunk = chunk64;
+        const int64_t kpad = ((int64_t)K + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
+        if (chunk > kpad) chunk = kpad;
+        int rc = gpbo_posterior_acq_f64(rows, (int64_t)K, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1, 0.0, 0,
+                                        chunk, mu64, sig64, acq64, &out->res, post, L.post_bytes, nullptr, stream);
+        if (rc != GPBO_OK) return rc;
+        hipLaunchKernelGGL(rescore_finish_kernel, dim3(1), dim3(SB), 0, st, acq64, sig64, list, (int64_t)K, var32, idx_offset,
+                           out);
+        GPBO_CHECK_LAUNCH();
+        RescoreOut h;
+        if (hipMemcpyAsync(&h, out, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
+        stt.rescored += (int64_t)K;
+        stt.err_max = h.err_max;
+        if (4.0 * h.err_max <= tau) {  // the screen's assumption held with a factor 4 to spare on this call's sample
+            if (hipMemcpyAsync(result, &out->res, sizeof(gpbo_result), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return GPBO_ERR_LAUNCH;
+            *stats_host = stt;
+            return GPBO_OK;
+        }
+        tau = fmax(8.0 * h.err_max, 4.0 * tau);
+    }
+    stt.fallback = 1;
+    *stats_host = stt;
+    return GPBO_OK;
+}

@@ -61,19 +61,9 @@ __device__ __forceinline__ void glds16(const double *g, double *l) {
     __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)l, 16, 0, 0);
 }
 
-__device__ __forceinline__ bool better(double v2, int64_t i2, double v, int64_t i) {
-    return (v2 > v) || (v2 == v && i2 < i);
-}
-
+__device__ __forceinline__ bool better(double v2, int64_t i2, double v, int64_t i) { return gpbo_better(v2, i2, v, i); }
 __device__ __forceinline__ double acquisition(int kind, double mu, double sigma, double p0, double p1) {
-    if (kind == GPBO_ACQ_LCB) return p0 * sigma - mu;
-    // Expected improvement for minimisation: imp = f_best - mu - xi
-    const double imp = p0 - mu - p1;
-    if (!(sigma > 0.0)) return (sigma == 0.0) ? fmax(imp, 0.0) : sigma;  // sigma NaN propagates
-    const double z = imp / sigma;
-    const double cdf = 0.5 * erfc(-z * 0.70710678118654752440);
-    const double pdf = exp(-0.5 * z * z) * 0.39894228040143267794;
-    return imp * cdf + sigma * pdf;
+    return gpbo_acquisition(kind, mu, sigma, p0, p1);
 }
 
 template <int VARIANT>  // 0 = product; 1, 2 = timing-only diagnostics (GPBO_SIGMA_VARIANT), wrong results

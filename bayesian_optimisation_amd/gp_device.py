@@ -70,6 +70,7 @@ class DeviceGP:
         self._result = self._status[:4]
         self.info = self._status[4:5].view(torch.int32)[:1]
         self._profile = C.c_void_p(0)
+        self.screen_cap = None       # fp32 screen: most survivors re-scored in fp64 before the plain fp64 pass takes over
         self.profile_active = True   # False: the next scoring calls record no events (bench.py samples every k-th step)
 
     # -- per-launch timing of the dominant kernel (bench.py) -----------------------------------------
@@ -140,7 +141,7 @@ class DeviceGP:
                 self.U = torch.empty((Np, Np), dtype=torch.float64, device=self.device)
                 self.alpha = torch.empty(Np, dtype=torch.float64, device=self.device)
                 self._work_fact = None
-            self.U32 = None
+            self._u32_valid = False
             wbytes = int(self.lib.gpbo_factorise_workspace_bytes(Np))
             if self._work_fact is None or self._work_fact.numel() * 8 < wbytes:
                 self._work_fact = torch.empty(wbytes // 8, dtype=torch.float64, device=self.device)
@@ -208,7 +209,7 @@ class DeviceGP:
                                           self._ptr(self.alpha), self._ptr(self.info), self._ptr(work), wbytes,
                                           self._stream())
             _lib.check(st, "gpbo_append_f64")
-            self.U32 = None
+            self._u32_valid = False
             if check:
                 info = int(self.info.item())  # synchronises
                 if info != 0:
@@ -255,7 +256,7 @@ class DeviceGP:
             self.alpha = torch.zeros(Np, dtype=torch.float64, device=self.device)
             self.alpha[:N] = self._dev(st["alpha"]).reshape(-1)
             self.info.zero_()
-            self.U32 = None
+            self._u32_valid = False
             self._work_post = None
         return self
 
@@ -329,54 +330,100 @@ class DeviceGP:
         self._keep = Xsd  # keep the candidate tensor alive until the stream has consumed it
         return self._result, mu, sigma, acq
 
-    # -- fp32 scoring (BASELINE config 4): fp64 factors rounded once, M-proportional work in fp32 -------------
+    # -- fp32-screened scoring (BASELINE config 4): fp32 variance product for all, fp64 re-score of the survivors ----
+    SCREEN_TAU0 = 1e-4          # first guess of |var64 - var32|; checked and raised per call (gpbo_rescore_f64)
+    SCREEN_SAMPLE = 1024        # about this many evenly strided non-survivors are re-scored as well, to check tau
+    SCREEN_CHUNK64 = 1 << 14    # candidates per fp64 launch of the re-scoring
+
     def prepare_f32(self):
-        """Round U and alpha to fp32 (re-padded to a multiple of 256) for score_async_f32."""
+        """Round U to fp32 (re-padded to a multiple of 256) for the fp32 variance screen."""
         torch = self.torch
         Np32 = int(self.lib.gpbo_padded_n_f32(self.N))
         with torch.cuda.device(self.device):
-            self.U32 = torch.empty((Np32, Np32), dtype=torch.float32, device=self.device)
-            self.alpha32 = torch.empty(Np32, dtype=torch.float32, device=self.device)
-            st = self.lib.gpbo_prepare_f32(self._ptr(self.U), self._ptr(self.alpha), self.Np, self._ptr(self.U32),
-                                           self._ptr(self.alpha32), Np32, self._stream())
+            if getattr(self, "U32", None) is None or self.U32.shape[0] != Np32:
+                self.U32 = torch.empty((Np32, Np32), dtype=torch.float32, device=self.device)
+            st = self.lib.gpbo_prepare_f32(self._ptr(self.U), None, self.Np, self._ptr(self.U32), None, Np32,
+                                           self._stream())
             _lib.check(st, "gpbo_prepare_f32")
+        if getattr(self, "Np32", 0) != Np32:
+            self._work_post32 = None
         self.Np32 = Np32
-        self._work_post32 = None
+        self._u32_valid = True
         return self
 
     def score_async_f32(self, Xs, acquisition: str = "lcb", explore: float = 4.0, f_best: Optional[float] = None,
                         xi: float = 0.0, dense: bool = False, idx_offset: int = 0, diag_add: float = 0.0,
                         prior_var: float = PRIOR_VAR):
-        """fp32 counterpart of score_async (dense outputs are float32 tensors)."""
+        """fp32 screen of all rows of Xs, then the fp64 decision (gpbo_rescore_f64): the result record holds the fp64
+        path's maximum and its lowest index.  Dense outputs (mu exactly the fp64 path's; sigma / acq with fp32-accurate
+        variance) are float64 tensors.  Unlike score_async this call synchronises (the survivor count is read back).
+        `last_screen` keeps the statistics of the call."""
         torch = self.torch
-        if getattr(self, "U32", None) is None:
+        if not getattr(self, "_u32_valid", False) or getattr(self, "U32", None) is None:
             self.prepare_f32()
         Xsd = self._dev(Xs)
+        if Xsd.dim() != 2 or int(Xsd.shape[1]) != self.d:
+            raise ValueError("Xs must be (M, d) with the same d as X")
         M = int(Xsd.shape[0])
         if acquisition == "lcb":
             kind, p0, p1 = _lib.ACQ_LCB, float(explore), 0.0
-        else:
+        elif acquisition == "ei":
+            if f_best is None:
+                raise ValueError("EI needs f_best (the incumbent minimum)")
             kind, p0, p1 = _lib.ACQ_EI, float(f_best), float(xi)
+        else:
+            raise ValueError(f"unknown acquisition {acquisition!r}")
+        if diag_add != 0.0:
+            # N == M shape quirk (point_selector.py:173): gathered rows lose the index the quirk is keyed on
+            self.last_screen = dict(fallback=True, reason="diag_add")
+            return self.score_async(Xsd, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var)
         with torch.cuda.device(self.device):
             chunk = min(self.chunk, (M + 1023) // 1024 * 1024)
             chunk = (chunk + 1023) // 1024 * 1024
             need = int(self.lib.gpbo_posterior_workspace_bytes_f32(self.Np32, chunk, M))
             if need < 0:
                 raise _lib.GpboError("gpbo_posterior_workspace_bytes_f32: invalid sizes")
-            if self._work_post32 is None or self._work_post32.numel() * 8 < need:
+            if getattr(self, "_work_post32", None) is None or self._work_post32.numel() * 8 < need:
                 self._work_post32 = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
+            if getattr(self, "_screen_mu", None) is None or self._screen_mu.numel() < M:
+                self._screen_mu = torch.empty(M, dtype=torch.float64, device=self.device)
+                self._screen_var = torch.empty(M, dtype=torch.float64, device=self.device)
             mu = sigma = acq = None
             if dense:
-                mu, sigma, acq = (torch.empty(M, dtype=torch.float32, device=self.device) for _ in range(3))
+                mu, sigma, acq = (torch.empty(M, dtype=torch.float64, device=self.device) for _ in range(3))
+            mu_w = mu if dense else self._screen_mu
             st = self.lib.gpbo_posterior_acq_f32(
                 self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np32, self.d,
-                self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.U32), self._ptr(self.alpha32), prior_var,
-                kind, p0, p1, float(diag_add), int(idx_offset), chunk, self._ptr(mu), self._ptr(sigma),
-                self._ptr(acq), self._ptr(self._result), self._ptr(self._work_post32), need,
+                self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.U32), self._ptr(self.alpha), prior_var,
+                kind, p0, p1, 0.0, int(idx_offset), chunk, self._ptr(mu_w), self._ptr(sigma),
+                self._ptr(acq), self._ptr(self._screen_var), self._ptr(self._result), self._ptr(self._work_post32), need,
                 self._profile if self.profile_active else None,
                 self._stream())
             _lib.check(st, "gpbo_posterior_acq_f32")
+            cap = self.screen_cap if self.screen_cap else max(4096, min(M, max(M // 16, 1 << 16)))
+            chunk64 = self.SCREEN_CHUNK64
+            rbytes = int(self.lib.gpbo_rescore_workspace_bytes(self.Np, cap, chunk64))
+            if rbytes < 0:
+                raise _lib.GpboError("gpbo_rescore_workspace_bytes: invalid sizes")
+            if getattr(self, "_work_rescore", None) is None or self._work_rescore.numel() * 8 < rbytes:
+                self._work_rescore = torch.empty((rbytes + 7) // 8, dtype=torch.float64, device=self.device)
+            stats = _lib.ScreenStats()
+            stride = max(1, M // self.SCREEN_SAMPLE)
+            st = self.lib.gpbo_rescore_f64(
+                self._ptr(Xsd), M, self._ptr(mu_w), self._ptr(self._screen_var), self._ptr(self.X), self.N, self.Np,
+                self.d, self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.U), self._ptr(self.alpha), prior_var, kind,
+                p0, p1, int(idx_offset), float(self.SCREEN_TAU0), stride, cap, chunk64, self._ptr(self._result),
+                C.byref(stats), self._ptr(self._work_rescore), rbytes, self._stream())
+            _lib.check(st, "gpbo_rescore_f64")
+            self.last_screen = dict(survivors=int(stats.survivors), rescored=int(stats.rescored), rounds=int(stats.rounds),
+                                    fallback=bool(stats.fallback), tau=float(stats.tau), err_max=float(stats.err_max),
+                                    candidates=M)
         self._keep = Xsd
+        if stats.fallback:
+            # too many candidates could still be the maximum (or tau did not settle): the plain fp64 pass decides
+            res, mu64, sig64, acq64 = self.score_async(Xsd, acquisition, explore, f_best, xi, dense, idx_offset, 0.0,
+                                                       prior_var)
+            return res, mu64, sig64, acq64
         return self._result, mu, sigma, acq
 
     def score_f32(self, Xs, **kw) -> ScoreResult:

@@ -354,6 +354,8 @@ def main():
             r = (gp.score_f32 if f32 else gp.score)(Xsd[:ns], **acq_kw)
             cb["argmax_match_on_sample"] = bool(r.best_idx == idx_cpu)
             out["cpu_baseline"] = cb
+        if f32:
+            out["screen"] = gp.last_screen   # survivors of the fp32 screen, tolerance and its check, fallback flag
         if world == 1 and not args.no_also:
             out["also"] = also()
         print(json.dumps(out), flush=True)

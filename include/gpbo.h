@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPBO_VERSION 110 /* 0.1.1: + gpbo_append_f64, host-pointer entry points */
+#define GPBO_VERSION 120 /* 0.2.0: fp32 screen + fp64 re-score (gpbo_rescore_f64), gpbo_posterior_acq_f32 changed */
 
 #define GPBO_OK 0
 #define GPBO_ERR_ARG (-1)      /* null pointer, bad size/alignment, unsupported d */
@@ -159,19 +159,46 @@ int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double *X, int64_t
                            double xi, const double *Z, int32_t S, int64_t batch_offset, int64_t chunk, double *qei_out,
                            gpbo_result *result, void *work, int64_t work_bytes, void *stream);
 
-/* fp32 scoring path (BASELINE config 4): the factorisation stays fp64; U and alpha are rounded to fp32 once
- * per step (gpbo_prepare_f32, re-padded to Np32 = gpbo_padded_n_f32(N), a multiple of 256) and the
- * M-proportional work - K(X*,X), mean, variance on the fp32 matrix cores, acquisition, arg-max - runs in fp32.
- * Candidates and observations are still given in fp64; dense outputs are fp32. chunk: a multiple of 1024. */
+/* fp32-screened scoring (BASELINE config 4).  The factorisation stays fp64; U is rounded to fp32 once per step
+ * (gpbo_prepare_f32, re-padded to Np32 = gpbo_padded_n_f32(N), a multiple of 256; alpha32 may be NULL).
+ * gpbo_posterior_acq_f32 = the screen over all M candidates: K(X*,X) entries and the mean in fp64 exactly as in the
+ * fp64 path (mu_out is the fp64 path's mean bit for bit), K*^T stored in fp32, the N^2-per-candidate triangular
+ * product on the fp32 matrix cores.  Dense outputs are doubles holding fp32-accurate values; var_out is the signed
+ * prior_var - |v|^2 the screen decides on.  alpha: the fp64 alpha of the factorisation.  chunk: a multiple of 1024.
+ * result: the screen's own arg-max (NOT final - see gpbo_rescore_f64). */
 int64_t gpbo_padded_n_f32(int64_t N);
 int gpbo_prepare_f32(const double *U, const double *alpha, int64_t Np, float *U32, float *alpha32, int64_t Np32,
                      void *stream);
 int64_t gpbo_posterior_workspace_bytes_f32(int64_t Np32, int64_t chunk, int64_t M);
 int gpbo_posterior_acq_f32(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np32, int32_t d,
-                           const double *ls_host, const float *U32, const float *alpha32, double prior_var,
+                           const double *ls_host, const float *U32, const double *alpha, double prior_var,
                            int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset, int64_t chunk,
-                           float *mu_out, float *sigma_out, float *acq_out, gpbo_result *result, void *work,
-                           int64_t work_bytes, gpbo_profile *prof /* or NULL */, void *stream);
+                           double *mu_out, double *sigma_out, double *acq_out, double *var_out, gpbo_result *result,
+                           void *work, int64_t work_bytes, gpbo_profile *prof /* or NULL */, void *stream);
+
+/* The decision behind the screen: the selected point must be the fp64 path's (point_selector.py:204-207: first index
+ * of the maximum).  Given the screen's dense mu [M] and var32 [M]: every candidate whose acquisition could still reach
+ * the best lower bound when its variance is off by up to tau - plus every sample_stride-th candidate - is gathered and
+ * re-scored through the fp64 kernels (gpbo_posterior_acq_f64 on the gathered rows); result = fp64 maximum over those,
+ * lowest original index on ties, idx_offset added.  tau starts at tau0 and is CHECKED on every call: the largest
+ * |var64 - var32| on the re-scored set must stay below tau / 4, else tau is raised and the selection repeated.
+ * stats_host->fallback = 1 (result untouched) when more than `cap` candidates survive or tau does not settle in four
+ * rounds: the caller then runs gpbo_posterior_acq_f64 over all candidates.  This call synchronises `stream` (it
+ * reads the survivor count back); not supported with the N == M diagonal quirk (diag_add != 0: use the fp64 path). */
+typedef struct gpbo_screen_stats {
+    int64_t survivors; /* candidates selected in the last round (may exceed cap when fallback is set) */
+    int64_t rescored;  /* candidates pushed through the fp64 kernels, all rounds */
+    int32_t rounds;
+    int32_t fallback;
+    double tau;        /* variance tolerance of the last round */
+    double err_max;    /* largest |sigma64^2 - |var32|| seen on the last round's re-scored set */
+} gpbo_screen_stats;
+int64_t gpbo_rescore_workspace_bytes(int64_t Np, int64_t cap, int64_t chunk64);
+int gpbo_rescore_f64(const double *Xs, int64_t M, const double *mu, const double *var32, const double *X, int64_t N,
+                     int64_t Np, int32_t d, const double *ls_host, const double *U, const double *alpha,
+                     double prior_var, int32_t acq_kind, double p0, double p1, int64_t idx_offset, double tau0,
+                     int64_t sample_stride, int64_t cap, int64_t chunk64, gpbo_result *result,
+                     gpbo_screen_stats *stats_host, void *work, int64_t work_bytes, void *stream);
 
 /* K7+K8 on a posterior already on the device: acq = LCB/EI of (mu, sigma), first-index arg-max
  * (point_selector.py:204-207).  Used for a second acquisition on the same surrogate.

@@ -32,7 +32,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv
 keep = ("sigma_acq_kernel", "kstar_mu_kernel", "sigma_acq_f32_kernel", "kstar_mu_f32_kernel", "rescore_gather_kernel", "potrf_diag_kernel", "gemm_f64_kernel", "kxx_kernel", "utv_kernel",
         "uv_kernel")
 with open(os.path.join(here, f"{out}_pmc_summary.csv"), "w") as fo:
-    fo.write("# rocprofv3 --pmc passes (one pass per counter group, profiles/collect.sh), bench.py --steps 5 --warmup 2,\n")
+    fo.write("# rocprofv3 --pmc passes (one pass per counter group, profiles/collect.sh), bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also,\n")
     fo.write(f"# MI355X; per-launch means; a sigma/kstar launch = one chunk of {cands} candidates, N={N}, d={d}, {dtype}\n")
     fo.write("kernel,counter,launches,mean_per_launch\n")
     for k in keep:
