@@ -54,3 +54,10 @@ int gpbo_scale_points_launch(const double *X, int64_t N, int64_t Np, int32_t d, 
 int gpbo_launch_transpose_upper(const double *W, int64_t Np, double *U, hipStream_t st);
 int gpbo_launch_argmax_finish(const double *part_val, const int64_t *part_idx, int64_t nparts,
                               const unsigned long long *nan_count, gpbo_result *result, hipStream_t st);
+int64_t gpbo_posterior_workspace_bytes_split(int64_t Np, int64_t chunk, int64_t M, int split_max);
+int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                                 const double *ls_host, const double *U, const double *alpha, double prior_var,
+                                 int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset,
+                                 int64_t chunk, double *mu_out, double *sigma_out, double *acq_out, gpbo_result *result,
+                                 void *work, int64_t work_bytes, gpbo_profile *prof, int split_max, void *stream);
+#define GPBO_RESCORE_SPLIT_MAX 64

@@ -177,7 +177,7 @@ RescoreLayout rescore_layout(int64_t Np, int64_t cap, int64_t chunk64) {
     L.sig_off = off; off += align_up((int64_t)sizeof(double) * cap, 256);
     L.acq_off = off; off += align_up((int64_t)sizeof(double) * cap, 256);
     L.post_off = off;
-    L.post_bytes = gpbo_posterior_workspace_bytes(Np, chunk64, cap);
+    L.post_bytes = gpbo_posterior_workspace_bytes_split(Np, chunk64, cap, GPBO_RESCORE_SPLIT_MAX);
     off += align_up(L.post_bytes, 256);
     L.total = off;
     return L;
@@ -246,8 +246,9 @@ extern "C" int gpbo_rescore_f64(const double *Xs, int64_t M, const double *mu, c
         int64_t chunk = chunk64;
         const int64_t kpad = ((int64_t)K + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
         if (chunk > kpad) chunk = kpad;
-        int rc = gpbo_posterior_acq_f64(rows, (int64_t)K, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1, 0.0, 0,
-                                        chunk, mu64, sig64, acq64, &out->res, post, L.post_bytes, nullptr, stream);
+        int rc = gpbo_posterior_acq_f64_split(rows, (int64_t)K, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1,
+                                              0.0, 0, chunk, mu64, sig64, acq64, &out->res, post, L.post_bytes, nullptr,
+                                              GPBO_RESCORE_SPLIT_MAX, stream);
         if (rc != GPBO_OK) return rc;
         hipLaunchKernelGGL(rescore_finish_kernel, dim3(1), dim3(SB), 0, st, acq64, sig64, list, (int64_t)K, var32, idx_offset,
                            out);

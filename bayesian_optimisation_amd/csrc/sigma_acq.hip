@@ -72,8 +72,14 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
     const double *__restrict__ mu_part, int nsl, int64_t Mc, double prior_var, int acq_kind, double p0, double p1,
     int64_t idx_base, double *__restrict__ mu_out, double *__restrict__ sigma_out, double *__restrict__ acq_out,
     double *__restrict__ part_val, int64_t *__restrict__ part_idx, unsigned long long *__restrict__ nan_count,
-    double *__restrict__ vbuf /* optional [chunk x Np]: V = K* U itself, for the joint (qEI) posterior */) {
+    double *__restrict__ vbuf /* optional [chunk x Np]: V = K* U itself, for the joint (qEI) posterior */,
+    double *__restrict__ ss_part /* column-split launches (gridDim.y = S > 1): [S x ldk] partial |v|^2, no epilogue */) {
     __shared__ double smem[3 * STAGE];
+    // Column split (few candidates, e.g. the re-scoring behind a screen): workgroup (x, s) of S takes the column
+    // blocks s, 2S-1-s, 2S+s, 4S-1-s, ... (boustrophedon rounds: block jb costs jb+1 k tiles, so pairing a cheap
+    // with an expensive one balances the S workgroups) and leaves its partial row sums for split_finish_kernel.
+    const int S = (int)gridDim.y, sp = (int)blockIdx.y;
+    auto jb_of = [&](int r) { return r * S + ((r & 1) ? (S - 1 - sp) : sp); };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -116,8 +122,8 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
 
     const int nJ = Np / BN;
     // staging iterator: tile (pj, pk) goes to stage pbuf; pa / pb are its global bases
-    const double *pa = a_base, *pb = U;
-    int pj = 0, pk = 0, pbuf = 0;
+    int pr = 0, pj = jb_of(0), pk = 0, pbuf = 0;
+    const double *pa = a_base, *pb = U + (int64_t)pj * BN;
     auto stage_next = [&]() {
         double *St = smem + pbuf * STAGE;
 #pragma unroll
@@ -125,8 +131,8 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
 #pragma unroll
         for (int r = 0; r < NPB; ++r) glds16(pb + voffB[r], St + ldsB[r]);
         pbuf = (pbuf == 2) ? 0 : pbuf + 1;
-        if (++pk == (pj + 1) * (BN / BK)) {  // next column block: k restarts, columns move right
-            ++pj;
+        if (++pk == (pj + 1) * (BN / BK)) {  // next column block of this workgroup: k restarts
+            pj = jb_of(++pr);
             pk = 0;
             pa = a_base;
             pb = U + (int64_t)pj * BN;
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
         constexpr bool FULL = decltype(full_tag)::value;
         if (VARIANT == 6 && vbuf && tid == 0) {  // diagnostic: cycle stamp per tile (timing build only)
             vbuf[(int64_t)blockIdx.x * 1024 + dbg_it] = (double)__builtin_amdgcn_s_memtime();
-            if (dbg_it == 0 || (jb == nJ - 1 && kt == nJ * (BN / BK) - 1))  // 100 MHz wall clock at both ends
+            if (dbg_it == 0 || (jb == nJ - 1 && kt == nJ * (BN / BK) - 1))  // 100 MHz wall clock at both ends (S = 1)
                 vbuf[(int64_t)blockIdx.x * 1024 + (dbg_it == 0 ? 1000 : 1001)] = (double)__builtin_amdgcn_s_memrealtime();
             ++dbg_it;
         }
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
         if (do_stage && wq != 0) stage_next();
         cur = nxt;
     };
-    for (int jb = 0; jb < nJ; ++jb) {
+    for (int rr = 0, jb = jb_of(0); jb < nJ; jb = jb_of(++rr)) {
         const int heavy = jb * (BN / BK);
         for (int kt = 0; kt < heavy; ++kt) tile_body(std::true_type{}, jb, kt);
         for (int kt = heavy; kt < heavy + BN / BK; ++kt) tile_body(std::false_type{}, jb, kt);
@@ -267,6 +273,15 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
     //  LDS-DMA in front of every k tile's first ds_read)
     double *s_val = smem + WQ * BM;
     int64_t *s_idx = reinterpret_cast<int64_t *>(smem + WQ * BM + 4);
+    if (ss_part) {  // (kernel-argument uniform) column-split launch: partial sums only
+        if (tid < BM) {
+            double ssq = red[tid];
+#pragma unroll
+            for (int q = 1; q < WQ; ++q) ssq += red[q * BM + tid];
+            ss_part[(int64_t)sp * ldk + cand0 + tid] = ssq;
+        }
+        return;
+    }
     if (tid < BM) {
         const int64_t c = cand0 + tid;  // chunk-local candidate
         const bool valid = c < Mc;
@@ -337,6 +352,52 @@ __global__ __launch_bounds__(256) void argmax_finish_kernel(const double *__rest
     }
 }
 
+// Epilogue of a column-split variance launch: |v|^2 = sum of the S partials in index order, then exactly the
+// epilogue of sigma_acq_kernel (mean from the per-slice partials, sigma, acquisition, dense stores, block arg-max).
+__global__ __launch_bounds__(256) void split_finish_kernel(const double *__restrict__ ss_part, int S, int64_t ldk,
+                                                           const double *__restrict__ mu_part, int nsl, int64_t Mc,
+                                                           double prior_var, int acq_kind, double p0, double p1,
+                                                           int64_t idx_base, double *__restrict__ mu_out,
+                                                           double *__restrict__ sigma_out, double *__restrict__ acq_out,
+                                                           double *__restrict__ part_val, int64_t *__restrict__ part_idx,
+                                                           unsigned long long *__restrict__ nan_count) {
+    __shared__ double s_val[4];
+    __shared__ int64_t s_idx[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t c = (int64_t)blockIdx.x * 256 + tid;
+    const bool valid = c < Mc;
+    double ssq = 0.0, mu = 0.0;
+    for (int q = 0; q < S; ++q) ssq += ss_part[(int64_t)q * ldk + c];
+    for (int q = 0; q < nsl; ++q) mu += mu_part[(int64_t)q * ldk + c];
+    const double var = prior_var - ssq;
+    const double sigma = sqrt(fabs(var));
+    const double acq = acquisition(acq_kind, mu, sigma, p0, p1);
+    if (valid) {
+        if (mu_out) mu_out[c] = mu;
+        if (sigma_out) sigma_out[c] = sigma;
+        if (acq_out) acq_out[c] = acq;
+    }
+    const bool is_nan = valid && (acq != acq);
+    const unsigned long long nan_mask = __ballot(is_nan);
+    if (lane == 0 && nan_mask) atomicAdd(nan_count, (unsigned long long)__popcll(nan_mask));
+    double bv = (valid && !is_nan) ? acq : -std::numeric_limits<double>::infinity();
+    int64_t bi = (valid && !is_nan) ? idx_base + c : std::numeric_limits<int64_t>::max();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int64_t oi = __shfl_xor(bi, off);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better(s_val[w], s_idx[w], bv, bi)) { bv = s_val[w]; bi = s_idx[w]; }
+        part_val[blockIdx.x] = bv;
+        part_idx[blockIdx.x] = bi;
+    }
+}
+
 // Acquisition + arg-max over dense mu / sigma that are already on the device (used when the caller asks
 // for a second acquisition on the same posterior, e.g. lower_confidence_bound(explore != 4)).
 __global__ __launch_bounds__(256) void acq_argmax_kernel(const double *__restrict__ mu, const double *__restrict__ sigma,
@@ -404,10 +465,19 @@ Helper *helper_for_current_device() {
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct PosteriorLayout {
-    int64_t kst_off[2], mup_off[2], xsc_off, pval_off, pidx_off, nan_off, total, nparts_cap;
+    int64_t kst_off[2], mup_off[2], xsc_off, pval_off, pidx_off, nan_off, ssp_off, total, nparts_cap;
 };
 
-PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M) {
+// number of column-split workgroups per candidate tile for a launch of nblk tiles (1 = the plain kernel)
+int split_factor(int64_t nblk, int64_t nJ, int split_max) {
+    if (split_max <= 1 || nblk >= 128) return 1;
+    int64_t S = (384 + nblk - 1) / nblk;
+    if (S > nJ) S = nJ;
+    if (S > split_max) S = split_max;
+    return S < 1 ? 1 : (int)S;
+}
+
+PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M, int split_max = 1) {
     PosteriorLayout L;
     const int64_t nchunks = (M + chunk - 1) / chunk;
     L.nparts_cap = nchunks * (chunk / BM);
@@ -424,6 +494,8 @@ PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M) {
     L.pval_off = off; off += align_up((int64_t)sizeof(double) * L.nparts_cap, 256);
     L.pidx_off = off; off += align_up((int64_t)sizeof(int64_t) * L.nparts_cap, 256);
     L.nan_off = off; off += 256;
+    L.ssp_off = off;
+    if (split_max > 1) off += align_up((int64_t)sizeof(double) * split_max * chunk, 256);
     L.total = off;
     return L;
 }
@@ -605,15 +677,36 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
                                       int64_t chunk, double *mu_out, double *sigma_out, double *acq_out,
                                       gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof,
                                       void *stream) {
+    return gpbo_posterior_acq_f64_split(Xs, M, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1, diag_add,
+                                        idx_offset, chunk, mu_out, sigma_out, acq_out, result, work, work_bytes, prof, 1,
+                                        stream);
+}
+
+int64_t gpbo_posterior_workspace_bytes_split(int64_t Np, int64_t chunk, int64_t M, int split_max) {
+    if (Np < GPBO_NPAD || Np % GPBO_NPAD || chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX || M < 1)
+        return GPBO_ERR_ARG;
+    return posterior_layout(Np, chunk, M, split_max).total;
+}
+
+// split_max > 1: launches of fewer than 128 candidate tiles are split over the column blocks of V (the re-scoring
+// of a few survivors: one workgroup per 256 candidates would take N^2/2 MFMA-bound k tiles on ONE compute unit).
+// The partial sums are combined in a fixed order, so results are deterministic; they differ from the unsplit
+// kernel's by the rounding of a different summation order (~1e-16 relative).
+int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                                 const double *ls_host, const double *U, const double *alpha, double prior_var,
+                                 int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset,
+                                 int64_t chunk, double *mu_out, double *sigma_out, double *acq_out, gpbo_result *result,
+                                 void *work, int64_t work_bytes, gpbo_profile *prof, int split_max, void *stream) {
     if (!Xs || !X || !U || !alpha || !result || !work) return GPBO_ERR_ARG;
     if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || Np > (1 << 20)) return GPBO_ERR_ARG;
     if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
     if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
     if (((uintptr_t)work & 255) || ((uintptr_t)U & 15)) return GPBO_ERR_ARG;
-    const PosteriorLayout L = posterior_layout(Np, chunk, M);
+    const PosteriorLayout L = posterior_layout(Np, chunk, M, split_max);
     if (work_bytes < L.total) return GPBO_ERR_WORKSPACE;
     hipStream_t st = gpbo_stream(stream);
     char *w = reinterpret_cast<char *>(work);
+    double *ss_part = reinterpret_cast<double *>(w + L.ssp_off);
     double *KsT[2] = {reinterpret_cast<double *>(w + L.kst_off[0]), reinterpret_cast<double *>(w + L.kst_off[1])};
     double *mu_part[2] = {reinterpret_cast<double *>(w + L.mup_off[0]), reinterpret_cast<double *>(w + L.mup_off[1])};
     double *Xsc = reinterpret_cast<double *>(w + L.xsc_off);
@@ -688,12 +781,23 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
         const bool rec = prof && prof->count < prof->capacity;
         if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
+        const int S = split_factor(nblk, Np / BN, split_max);
+        if (S > 1) {
+            hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk, (unsigned)S), dim3(NW * 64), 0, st, KsT[b], chunk, U,
+                               (int)Np, mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1,
+                               idx_offset + s, (double *)nullptr, (double *)nullptr, (double *)nullptr, part_val + nparts,
+                               part_idx + nparts, nan_count, (double *)nullptr, ss_part);
+            hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, S, chunk, mu_part[b],
+                               (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
+                               mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
+                               acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count);
+        } else {
 #define GPBO_SIGMA_LAUNCH(V)                                                                                        \
     hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT[b], chunk, U, (int)Np,          \
                        mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,               \
                        mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                              \
                        acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count,                     \
-                       (V == 6 && c == nchunks - 1 && nchunks > 1) ? KsT[(c + 1) & 1] : (double *)nullptr)
+                       (V == 6 && c == nchunks - 1 && nchunks > 1) ? KsT[(c + 1) & 1] : (double *)nullptr, (double *)nullptr)
 #ifdef GPBO_DIAGNOSTICS
         if (variant == 1) GPBO_SIGMA_LAUNCH(1);
         else if (variant == 2) GPBO_SIGMA_LAUNCH(2);
@@ -706,6 +810,7 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
         GPBO_SIGMA_LAUNCH(0);
 #endif
 #undef GPBO_SIGMA_LAUNCH
+        }
         if (rec) {
             if (hipEventRecord(reinterpret_cast<hipEvent_t>(prof->end[prof->count]), st) != hipSuccess)
                 return GPBO_ERR_LAUNCH;
@@ -797,7 +902,7 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
         // the variance kernel also leaves V (vbuf) and mu; its own single-point acquisition result is ignored
         hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
                            (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
-                           (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb);
+                           (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb, (double *)nullptr);
         GPBO_CHECK_LAUNCH();
         const int64_t nbatch = Mc / QQ;
         const int64_t qblk = (nbatch + 3) / 4;
