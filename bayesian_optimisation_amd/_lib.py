@@ -17,6 +17,7 @@ ACQ_EI = 1
 NPAD = 128
 CHUNK_GRANULE = 512
 MAX_D = 16
+I8_MAX_N = 16384
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -57,6 +58,11 @@ SIGNATURES = {
     "gpbo_posterior_workspace_bytes_f32": (_i64, [_i64, _i64, _i64]),
     "gpbo_posterior_acq_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _i32, _f64, _f64, _f64,
                                          _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
+    "gpbo_prepare_i8_bytes": (_i64, [_i64]),
+    "gpbo_prepare_i8": (C.c_int, [_p, _i64, _p, _i64, _p]),
+    "gpbo_posterior_workspace_bytes_i8": (_i64, [_i64, _i64, _i64]),
+    "gpbo_posterior_acq_i8": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _i32, _f64, _f64, _i64, _i64,
+                                        _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
     "gpbo_rescore_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gpbo_rescore_f64": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _i32, _f64, _f64, _i64,
                                    _f64, _i64, _i64, _i64, _p, _p, _p, _i64, _p]),

@@ -1,0 +1,532 @@
+// Variance product on the INTEGER matrix cores: V = K* U from int8 slices (Ozaki-style splitting), exact integer
+// accumulation, fp64 recombination.  Same mathematics as sigma_acq.hip (reference: point_selector.py:91,98):
+//     sigma_c^2 = prior_var - |U^T k_c|^2,
+// but the N^2 multiply-adds per candidate run on v_mfma_i32_32x32x32_i8 (64x the fp64 MFMA rate per clock) instead of
+// v_mfma_f64_16x16x4_f64.
+//
+// Splitting.  k in [0, 1] and the column-scaled U_ij 2^-e_j in [-1, 1] are rounded ONCE to 47-bit fixed point,
+//     T = rint(x 2^46),  |T| <= 2^46,
+// and T is written in balanced base-256 digits  T = sum_a D_a 256^(5-a),  D_a in [-128, 127]  (six int8 slices; the
+// digits come out of T + 0x8080808080 byte by byte, xor 0x80).  Then
+//     v_j = 2^e_j sum_{a,b} 2^(-12 - 8(a+b)) (K_a U_b)_j
+// where every K_a U_b is an EXACT integer (|sum| <= N 2^14 < 2^31 for N <= 16384: int32 accumulators).  The digit
+// pairs are accumulated per diagonal g = a + b (six int32 accumulator sets) and pairs with a + b > 5 are dropped:
+// 21 of the 36 slice products.  Error (tools/ozaki_error.py, the benchmark problem): the dropped diagonals and the two
+// 2^-47 roundings leave |dv_j| <= 1.6e-10 and |dsigma| <= 1.3e-10 at N = 4096 (fp64 MFMA path: 1.3e-13); everything
+// after the two roundings is exact integer arithmetic, so the result does not depend on tile shapes or summation order.
+// The arg-max is still decided in fp64 (rescore.hip) - this pass is a screen with a 1e-10-accurate variance.
+//
+// Geometry.  Operands live in HBM as ready-made MFMA fragments: 1-KiB blocks [32 rows x 32 k] in lane order (lane l =
+// row l & 31, k half l >> 5, 16 consecutive k per lane), indexed [k block][row tile][slice].  A stage (32 k) of a
+// 128 x 128 block tile is two contiguous 24-KiB pieces (4 row tiles x 6 slices of K*, 4 column tiles x 6 slices of U):
+// 48 LDS-DMA instructions, fragments land in LDS exactly as ds_read_b128 will fetch them (no bank conflicts, no
+// repacking).  Workgroup = 512 threads = 8 waves as 2 (candidates) x 4 (columns): wave tile 64 x 32 = two 32 x 32 MFMA
+// tiles x 6 diagonals = 192 accumulator registers; 42 MFMAs per wave and stage; three-stage LDS ring (144 KiB), one
+// barrier in the middle of each stage (same protocol as sigma_acq.hip).
+#include "gpbo_internal.h"
+
+#include <limits>
+
+namespace {
+
+typedef int i4_t __attribute__((ext_vector_type(4)));
+typedef int i16_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+constexpr int NS = 6;                      // int8 slices per operand
+constexpr int BM = 128, BN = 128, BK = 32;  // candidates x columns of V per workgroup, k depth of a stage
+constexpr int FRAG = 1024;                 // bytes of one 32 x 32 int8 fragment
+constexpr int HALF_STAGE = (BM / 32) * NS * FRAG;  // 24 KiB: the K* part (= the U part) of a stage
+constexpr int STAGE = 2 * HALF_STAGE;      // 48 KiB
+constexpr int KS_SLICE = GPBO_KS_SLICE;    // observations per mu_part slice (64)
+constexpr double MAGIC = 6755399441055744.0;  // 1.5 2^52: x + MAGIC has rint(x) in its low mantissa bits
+constexpr double TWO46 = 70368744177664.0;
+
+struct LsArgsI8 {
+    double isc[GPBO_MAX_D];  // 1 / (ls_k sqrt 2)
+};
+
+__device__ __forceinline__ void glds16b(const char *g, char *l) {
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)l, 16, 0, 0);
+}
+
+// ---- exp(-t), t >= 0 (same algorithm as kernel_build.hip: 2^(n/32) table x degree-6 polynomial, <= 1 ulp) ----------
+__device__ const double kExp2TabI8[32] = {
+    1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237,
+    1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775,
+    1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332,
+    1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832,
+    1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228,
+    1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965,
+    1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072,
+    1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002};
+
+__device__ __forceinline__ double exp_neg_i8(double t, const double *tab) {
+    const double u = -t;
+    const double z = fma(u, 46.16624130844683, MAGIC);
+    const int ni = __double2loint(z);
+    const double fn = z - MAGIC;
+    double r = fma(fn, -0.02166084939249829, u);
+    r = fma(fn, -7.247021293269686e-19, r);
+    const double T = tab[ni & 31];
+    double q = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    q = fma(r, q, 1.0 / 24.0);
+    q = fma(r, q, 1.0 / 6.0);
+    q = fma(r, q, 0.5);
+    q = fma(r, q, 1.0);
+    const double v = fma(T * r, q, T);
+    const double s = __hiloint2double(__double2hiint(v) + ((ni >> 5) << 20), __double2loint(v));
+    return (t <= 708.0) ? s : 0.0;
+}
+
+// ---- balanced base-256 digits of four fixed-point values at once --------------------------------------------------
+// In: z[q] = x_q 2^46 + MAGIC (q = 0..3).  Out: P[a] (a = 0 most significant) = the a-th digits of the four values,
+// one int8 per byte (value q in byte q).  T' = T + 0x8080808080; digit byte = byte of T' (xor 0x80 below the top).
+__device__ __forceinline__ void digits4(const double (&z)[4], unsigned (&P)[NS]) {
+    unsigned lo[4], hi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned l = (unsigned)__double2loint(z[q]);
+        const unsigned h = (unsigned)__double2hiint(z[q]) - 0x43380000u;  // high word of T (two's complement)
+        lo[q] = l + 0x80808080u;
+        hi[q] = h + 0x80u + (lo[q] < l ? 1u : 0u);
+    }
+    // v_perm_b32: result byte k = byte sel_k of {S0:S1}, selector 0-3 = bytes of S1 (second argument), 4-7 = bytes of S0
+    const unsigned t01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400u);  // {l0.b0, l1.b0, l0.b1, l1.b1}
+    const unsigned t23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400u);
+    const unsigned u01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602u);  // {l0.b2, l1.b2, l0.b3, l1.b3}
+    const unsigned u23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602u);
+    const unsigned h01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u);  // {h0.b0, h1.b0, h0.b1, h1.b1}
+    const unsigned h23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400u);
+    P[5] = __builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u;  // bytes 0 of the four values
+    P[4] = __builtin_amdgcn_perm(t23, t01, 0x07060302u) ^ 0x80808080u;
+    P[3] = __builtin_amdgcn_perm(u23, u01, 0x05040100u) ^ 0x80808080u;
+    P[2] = __builtin_amdgcn_perm(u23, u01, 0x07060302u) ^ 0x80808080u;
+    P[1] = __builtin_amdgcn_perm(h23, h01, 0x05040100u) ^ 0x80808080u;
+    P[0] = __builtin_amdgcn_perm(h23, h01, 0x07060302u);                // top digit: plain two's complement byte
+}
+
+// ---- U -> column scales and int8 fragments (once per factorisation) ---------------------------------------------------
+// scale[j] = 2^e_j >= max_i |U_ij|  (exact power of two), inv[j] = 2^(46 - e_j).   grid Np/256, block 256.
+__global__ __launch_bounds__(256) void u_colscale_kernel(const double *__restrict__ U, int Np, double *__restrict__ scale,
+                                                         double *__restrict__ inv) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Np) return;
+    double m = 0.0;
+    for (int i = 0; i <= j; ++i) m = fmax(m, fabs(U[(int64_t)i * Np + j]));  // upper triangular: rows <= j
+    int e = 0;
+    if (m > 0.0) (void)frexp(m, &e);  // m = f 2^e, f in [0.5, 1)
+    scale[j] = ldexp(1.0, e);
+    inv[j] = ldexp(1.0, 46 - e);
+}
+
+// thread = (k block of 16, column): 16 entries -> six 16-byte lane operands.  grid (Np/256, Np/16), block 256.
+__global__ __launch_bounds__(256) void u_slices_kernel(const double *__restrict__ U, int Np, const double *__restrict__ inv,
+                                                       char *__restrict__ U8) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= Np) return;  // Np is a multiple of 128, not of 256
+    const int k0 = blockIdx.y * 16;
+    const double sc = inv[col];
+    unsigned out[NS][4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        double z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + q4 * 4 + q;
+            const double u = (k <= col) ? U[(int64_t)k * Np + col] : 0.0;  // zeros below the diagonal, whatever is stored
+            z[q] = fma(u, sc, MAGIC);
+        }
+        unsigned P[NS];
+        digits4(z, P);
+#pragma unroll
+        for (int a = 0; a < NS; ++a) out[a][q4] = P[a];
+    }
+    const int kb = k0 >> 5, kg = (k0 >> 4) & 1, ct = col >> 5, CT = Np >> 5;
+    char *base = U8 + (((int64_t)kb * CT + ct) * NS) * FRAG + kg * 512 + (col & 31) * 16;
+#pragma unroll
+    for (int a = 0; a < NS; ++a)
+        *reinterpret_cast<i4_t *>(base + a * FRAG) = i4_t{(int)out[a][0], (int)out[a][1], (int)out[a][2], (int)out[a][3]};
+}
+
+// ---- K(X*,X) chunk -> int8 fragments + fp64 mean partials ---------------------------------------------------------------
+// grid (ldk_used/256, Np/64), block 256: thread = one candidate, blockIdx.y = 64 observations (four 16-entry lane
+// operands).  Entries and mean partials are the fp64 path's (same distance / exp arithmetic, same fma order over n).
+template <int D>
+__global__ __launch_bounds__(256) void kstar_slices_kernel(const double *__restrict__ Xs, int64_t Mc,
+                                                           const double *__restrict__ Xsc, int N, LsArgsI8 ls,
+                                                           const double *__restrict__ alpha, char *__restrict__ A8,
+                                                           int64_t RT, double *__restrict__ mu_part, int64_t ldk) {
+    __shared__ double tab[32];
+    if (threadIdx.x < 32) tab[threadIdx.x] = kExp2TabI8[threadIdx.x];
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double x[D];
+    bool nan_c = false;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        x[k] = ((c < Mc) ? Xs[c * D + k] : 0.0) * ls.isc[k];
+        nan_c = nan_c || (x[k] != x[k]);
+    }
+    __syncthreads();
+    double mu = 0.0;
+    const int nb = blockIdx.y * KS_SLICE;
+#pragma unroll 1
+    for (int g16 = 0; g16 < KS_SLICE / 16; ++g16) {
+        const int n0 = nb + g16 * 16;
+        unsigned out[NS][4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            double z[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + q4 * 4 + q;
+                double kv = 0.0;
+                if (n < N) {  // wave-uniform
+                    const double *xo = Xsc + (int64_t)n * D;
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const double dd = x[k] - xo[k];
+                        s = fma(dd, dd, s);
+                    }
+                    kv = exp_neg_i8(s, tab);
+                    mu = fma(kv, alpha[n], mu);
+                }
+                z[q] = fma(kv, TWO46, MAGIC);
+            }
+            unsigned P[NS];
+            digits4(z, P);
+#pragma unroll
+            for (int a = 0; a < NS; ++a) out[a][q4] = P[a];
+        }
+        const int kb = n0 >> 5, kg = (n0 >> 4) & 1;
+        char *base = A8 + (((int64_t)kb * RT + (c >> 5)) * NS) * FRAG + kg * 512 + (int)(c & 31) * 16;
+#pragma unroll
+        for (int a = 0; a < NS; ++a)
+            *reinterpret_cast<i4_t *>(base + a * FRAG) = i4_t{(int)out[a][0], (int)out[a][1], (int)out[a][2], (int)out[a][3]};
+    }
+    mu_part[(int64_t)blockIdx.y * ldk + c] = nan_c ? __builtin_nan("") : mu;
+}
+
+// ---- the variance kernel -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void sigma_i8_kernel(
+    const char *__restrict__ A8, int64_t RT, const char *__restrict__ U8, int Np, const double *__restrict__ colscale,
+    const double *__restrict__ mu_part, int nsl, int64_t ldk, int64_t Mc, double prior_var, int acq_kind, double p0,
+    double p1, int64_t idx_base, double *__restrict__ mu_out, double *__restrict__ sigma_out,
+    double *__restrict__ acq_out, double *__restrict__ var_out, double *__restrict__ part_val,
+    int64_t *__restrict__ part_idx, unsigned long long *__restrict__ nan_count) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid & 1, wq = wid >> 1;  // 2 row groups of 64 candidates x 4 column groups of 32 columns
+    const int CT = Np >> 5;
+    const int nJ = Np / BN;
+    const int lane16 = lane * 16;
+
+    // staging iterator over the flattened stage sequence (jb, kb): kb = 0 .. 4 (jb + 1) - 1 for jb = 0 .. nJ - 1
+#ifdef GPBO_I8_DIAG_SAME_A  // timing-only diagnostic (wrong results): every workgroup streams the same K* rows (L2 hits)
+    const char *a0p = A8;
+#else
+    const char *a0p = A8 + ((int64_t)blockIdx.x * (BM / 32) * NS) * FRAG;  // k block 0 of this workgroup's row tiles
+#endif
+    const int64_t a_step = RT * NS * FRAG, b_step = (int64_t)CT * NS * FRAG;
+    const char *pa = a0p, *pb = U8;
+    int pj = 0, pk = 0, pbuf = 0;
+    auto stage_next = [&]() {
+        char *St = smem + pbuf * STAGE;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) glds16b(pa + (wid + 8 * r) * FRAG + lane16, St + (wid + 8 * r) * FRAG);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) glds16b(pb + (wid + 8 * r) * FRAG + lane16, St + HALF_STAGE + (wid + 8 * r) * FRAG);
+        pbuf = (pbuf == 2) ? 0 : pbuf + 1;
+        if (++pk == (pj + 1) * (BN / BK)) {
+            ++pj;
+            pk = 0;
+            pa = a0p;
+            pb = U8 + ((int64_t)pj * (BN / 32) * NS) * FRAG;
+        } else {
+            pa += a_step;
+            pb += b_step;
+        }
+    };
+
+    i16_t acc[NS][2];
+#pragma unroll
+    for (int g = 0; g < NS; ++g)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][t][r] = 0;
+    double ssrow = 0.0;  // |v|^2 of ONE row of this wave's tile (which row: see the butterfly below)
+
+    // LDS ring protocol (three stages, one barrier per stage, at its END): before the barrier that closes stage t
+    // each wave waits for its own pieces of stage t+1 (issued two stages earlier; the six pieces of stage t+2 may still
+    // be in flight: counted vmcnt); after it every wave has finished reading stage t, whose buffer takes stage t+3.
+    // A DMA therefore has two full stages (about 5,400 MFMA cycles) to land.
+    int inflight = 0;  // stages issued and not yet waited for
+    stage_next();
+    ++inflight;
+    if (pj < nJ) { stage_next(); ++inflight; }
+    if (pj < nJ) { stage_next(); ++inflight; }
+    if (inflight == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (inflight == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    --inflight;
+    __builtin_amdgcn_s_barrier();
+
+    int cur = 0;
+    auto stage_body = [&](bool active) {
+        const char *St = smem + cur * STAGE;
+        const char *As = St + (2 * wr) * NS * FRAG + lane16;
+        const char *Bs = St + HALF_STAGE + wq * NS * FRAG + lane16;
+        i4_t b[NS], a0, a1;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) b[j] = *reinterpret_cast<const i4_t *>(Bs + j * FRAG);
+        a0 = *reinterpret_cast<const i4_t *>(As);
+        a1 = *reinterpret_cast<const i4_t *>(As + NS * FRAG);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            i4_t n0 = a0, n1 = a1;
+            if (i + 1 < NS) {  // next slice of K* while this one multiplies
+                n0 = *reinterpret_cast<const i4_t *>(As + (i + 1) * FRAG);
+                n1 = *reinterpret_cast<const i4_t *>(As + (NS + i + 1) * FRAG);
+            }
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < NS - i; ++j) {
+                    acc[i + j][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[j], acc[i + j][0], 0, 0, 0);
+                    acc[i + j][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[j], acc[i + j][1], 0, 0, 0);
+                }
+            }
+            a0 = n0;
+            a1 = n1;
+        }
+        // end of the stage: next stage landed (own pieces) -> barrier -> this stage's buffer is free for stage t+3
+        if (inflight >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (inflight > 0) --inflight;
+        __builtin_amdgcn_s_barrier();
+        if (pj < nJ) { stage_next(); ++inflight; }
+        cur = (cur == 2) ? 0 : cur + 1;
+    };
+
+    for (int jb = 0; jb < nJ; ++jb) {
+        const int ct = jb * (BN / 32) + wq;        // this wave's 32-column tile of V
+        const int nkb = (jb + 1) * (BN / BK);
+        for (int kb = 0; kb < nkb; ++kb) stage_body(kb <= ct);  // U is upper triangular: k tiles below the diagonal are zero
+        // column block finished: v = 2^e_j sum_g 2^(-12-8g) G_g, squared and summed over this wave's 32 columns
+        const double cs = colscale[ct * 32 + (lane & 31)];
+        double x[32];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double v = (double)acc[5][t][r] * 0x1p-52;
+                v = fma((double)acc[4][t][r], 0x1p-44, v);
+                v = fma((double)acc[3][t][r], 0x1p-36, v);
+                v = fma((double)acc[2][t][r], 0x1p-28, v);
+                v = fma((double)acc[1][t][r], 0x1p-20, v);
+                v = fma((double)acc[0][t][r], 0x1p-12, v);
+                v *= cs;
+                x[t * 16 + r] = v * v;
+#pragma unroll
+                for (int g = 0; g < NS; ++g) acc[g][t][r] = 0;
+            }
+        // butterfly over the 32 lanes of a half wave: 32 values per lane -> 1; lane bits b0..b4 end up holding the
+        // column sum of value index Q = 16 b0 + 8 b1 + 4 b2 + 2 b3 + b4
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int half = 16 >> s;
+            const bool up = (lane >> s) & 1;
+#pragma unroll
+            for (int q = 0; q < half; ++q) {
+                const double keep = up ? x[q + half] : x[q];
+                const double send = up ? x[q] : x[q + half];
+                x[q] = keep + __shfl_xor(send, 1 << s);
+            }
+        }
+        ssrow += x[0];
+    }
+
+    // ---- row sums to LDS: red[wq][row of the block]
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(smem);  // [4][BM]
+    {
+        const int Q = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+        const int t = Q >> 4, r = Q & 15;
+        // 32 x 32 accumulator map: register r of lane l holds row 8 (r >> 2) + 4 (l >> 5) + (r & 3), column l & 31
+        const int row = wr * 64 + t * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        red[wq * BM + row] = ssrow;
+    }
+    __syncthreads();
+    double *s_val = red + 4 * BM;
+    int64_t *s_idx = reinterpret_cast<int64_t *>(red + 4 * BM + 4);
+    if (tid < BM) {
+        const int64_t c = (int64_t)blockIdx.x * BM + tid;
+        const bool valid = c < Mc;
+        const double ssq = ((red[tid] + red[BM + tid]) + red[2 * BM + tid]) + red[3 * BM + tid];
+        double mu = 0.0;
+        for (int s = 0; s < nsl; ++s) mu += mu_part[(int64_t)s * ldk + c];
+        const double var = prior_var - ssq;
+        const double sigma = sqrt(fabs(var));
+        const double acq = gpbo_acquisition(acq_kind, mu, sigma, p0, p1);
+        if (valid) {
+            if (mu_out) mu_out[c] = mu;
+            if (sigma_out) sigma_out[c] = sigma;
+            if (acq_out) acq_out[c] = acq;
+            if (var_out) var_out[c] = var;
+        }
+        const bool is_nan = valid && (acq != acq);
+        const unsigned long long nan_mask = __ballot(is_nan);
+        if (lane == 0 && nan_mask) atomicAdd(nan_count, (unsigned long long)__popcll(nan_mask));
+        double bv = (valid && !is_nan) ? acq : -std::numeric_limits<double>::infinity();
+        int64_t bi = (valid && !is_nan) ? idx_base + c : std::numeric_limits<int64_t>::max();
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int64_t oi = __shfl_xor(bi, off);
+            if (gpbo_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = s_val[0];
+        int64_t bi = s_idx[0];
+        if (gpbo_better(s_val[1], s_idx[1], bv, bi)) { bv = s_val[1]; bi = s_idx[1]; }
+        part_val[blockIdx.x] = bv;
+        part_idx[blockIdx.x] = bi;
+    }
+}
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct LayoutI8 {
+    int64_t a8_off, mup_off, xsc_off, pval_off, pidx_off, nan_off, total, nparts_cap;
+};
+
+LayoutI8 layout_i8(int64_t Np, int64_t chunk, int64_t M) {
+    LayoutI8 L;
+    const int64_t nchunks = (M + chunk - 1) / chunk;
+    L.nparts_cap = nchunks * (chunk / BM);
+    int64_t off = 0;
+    L.a8_off = off; off += align_up(Np * chunk * NS, 256);
+    L.mup_off = off; off += align_up((int64_t)sizeof(double) * (Np / KS_SLICE) * chunk, 256);
+    L.xsc_off = off; off += align_up((int64_t)sizeof(double) * Np * GPBO_MAX_D, 256);
+    L.pval_off = off; off += align_up((int64_t)sizeof(double) * L.nparts_cap, 256);
+    L.pidx_off = off; off += align_up((int64_t)sizeof(int64_t) * L.nparts_cap, 256);
+    L.nan_off = off; off += 256;
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+
+extern "C" int64_t gpbo_prepare_i8_bytes(int64_t Np) {
+    if (Np < GPBO_NPAD || Np % GPBO_NPAD || Np > GPBO_I8_MAX_N) return GPBO_ERR_ARG;
+    return align_up(Np * Np * NS, 256) + 2 * align_up((int64_t)sizeof(double) * Np, 256);
+}
+
+extern "C" int gpbo_prepare_i8(const double *U, int64_t Np, void *u8, int64_t u8_bytes, void *stream) {
+    if (!U || !u8 || ((uintptr_t)u8 & 255)) return GPBO_ERR_ARG;
+    const int64_t need = gpbo_prepare_i8_bytes(Np);
+    if (need < 0) return GPBO_ERR_ARG;
+    if (u8_bytes < need) return GPBO_ERR_WORKSPACE;
+    hipStream_t st = gpbo_stream(stream);
+    char *U8 = reinterpret_cast<char *>(u8);
+    double *scale = reinterpret_cast<double *>(U8 + align_up(Np * Np * NS, 256));
+    double *inv = scale + align_up((int64_t)sizeof(double) * Np, 256) / 8;
+    hipLaunchKernelGGL(u_colscale_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, U, (int)Np, scale, inv);
+    hipLaunchKernelGGL(u_slices_kernel, dim3((unsigned)(Np / 256 + (Np % 256 ? 1 : 0)), (unsigned)(Np / 16)), dim3(256), 0, st,
+                       U, (int)Np, inv, U8);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
+extern "C" int64_t gpbo_posterior_workspace_bytes_i8(int64_t Np, int64_t chunk, int64_t M) {
+    if (Np < GPBO_NPAD || Np % GPBO_NPAD || Np > GPBO_I8_MAX_N || chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE ||
+        chunk > GPBO_CHUNK_MAX || M < 1)
+        return GPBO_ERR_ARG;
+    return layout_i8(Np, chunk, M).total;
+}
+
+extern "C" int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                                     const double *ls_host, const void *u8, const double *alpha, double prior_var,
+                                     int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk,
+                                     double *mu_out, double *sigma_out, double *acq_out, double *var_out,
+                                     gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof,
+                                     void *stream) {
+    if (!Xs || !X || !u8 || !alpha || !result || !work || !ls_host) return GPBO_ERR_ARG;
+    if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || Np > GPBO_I8_MAX_N || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
+    if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
+    if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
+    if (((uintptr_t)work & 255) || ((uintptr_t)u8 & 255)) return GPBO_ERR_ARG;
+    const LayoutI8 L = layout_i8(Np, chunk, M);
+    if (work_bytes < L.total) return GPBO_ERR_WORKSPACE;
+    LsArgsI8 ls;
+    for (int k = 0; k < GPBO_MAX_D; ++k) ls.isc[k] = 0.0;
+    for (int k = 0; k < d; ++k) {
+        if (!(ls_host[k] > 0.0)) return GPBO_ERR_ARG;
+        ls.isc[k] = 1.0 / (ls_host[k] * 1.4142135623730950488);
+    }
+    hipStream_t st = gpbo_stream(stream);
+    char *w = reinterpret_cast<char *>(work);
+    char *A8 = w + L.a8_off;
+    double *mu_part = reinterpret_cast<double *>(w + L.mup_off);
+    double *Xsc = reinterpret_cast<double *>(w + L.xsc_off);
+    double *part_val = reinterpret_cast<double *>(w + L.pval_off);
+    int64_t *part_idx = reinterpret_cast<int64_t *>(w + L.pidx_off);
+    unsigned long long *nan_count = reinterpret_cast<unsigned long long *>(w + L.nan_off);
+    const char *U8 = reinterpret_cast<const char *>(u8);
+    const double *colscale = reinterpret_cast<const double *>(U8 + align_up(Np * Np * NS, 256));
+    int rc = gpbo_scale_points_launch(X, N, Np, d, ls_host, Xsc, nan_count, stream);
+    if (rc != GPBO_OK) return rc;
+    const int64_t RT = chunk / 32;
+    int64_t nparts = 0;
+    bool prev_recorded = false;
+    for (int64_t s = 0; s < M; s += chunk) {
+        const int64_t Mc = (M - s < chunk) ? (M - s) : chunk;
+        const bool rec = prof && prof->count < prof->capacity;
+        if (rec) {
+            const bool chained = s > 0 && prof->count > 0 && prev_recorded;
+            prof->kmode[prof->count] = chained ? 2 : 1;
+            if (!chained && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->kbegin[prof->count]), st) != hipSuccess)
+                return GPBO_ERR_LAUNCH;
+        }
+        // fragments of whole 128-candidate blocks are read by the variance kernel: build them for every block touched
+        const int64_t used = (Mc + 255) / 256 * 256;
+        dim3 kgrid((unsigned)(used / 256), (unsigned)(Np / KS_SLICE));
+#define CALL(DD)                                                                                                     \
+    hipLaunchKernelGGL(kstar_slices_kernel<DD>, kgrid, dim3(256), 0, st, Xs + s * d, Mc, Xsc, (int)N, ls, alpha, A8, RT, \
+                       mu_part, chunk)
+        switch (d) {
+            case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;   case 4: CALL(4); break;
+            case 5: CALL(5); break;   case 6: CALL(6); break;   case 7: CALL(7); break;   case 8: CALL(8); break;
+            case 9: CALL(9); break;   case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break;
+            case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break;
+            default: return GPBO_ERR_ARG;
+        }
+#undef CALL
+        const int64_t nblk = (Mc + BM - 1) / BM;
+        if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
+        hipLaunchKernelGGL(sigma_i8_kernel, dim3((unsigned)nblk), dim3(512), 0, st, A8, RT, U8, (int)Np, colscale, mu_part,
+                           (int)(Np / KS_SLICE), chunk, Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
+                           mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
+                           acq_out ? acq_out + s : nullptr, var_out ? var_out + s : nullptr, part_val + nparts,
+                           part_idx + nparts, nan_count);
+        if (rec) {
+            if (hipEventRecord(reinterpret_cast<hipEvent_t>(prof->end[prof->count]), st) != hipSuccess)
+                return GPBO_ERR_LAUNCH;
+            prof->cands[prof->count] = Mc;
+            ++prof->count;
+        }
+        prev_recorded = rec;
+        GPBO_CHECK_LAUNCH();
+        nparts += nblk;
+    }
+    return gpbo_launch_argmax_finish(part_val, part_idx, nparts, nan_count, result, st);
+}

@@ -142,6 +142,7 @@ class DeviceGP:
                 self.alpha = torch.empty(Np, dtype=torch.float64, device=self.device)
                 self._work_fact = None
             self._u32_valid = False
+            self._u8_valid = False
             wbytes = int(self.lib.gpbo_factorise_workspace_bytes(Np))
             if self._work_fact is None or self._work_fact.numel() * 8 < wbytes:
                 self._work_fact = torch.empty(wbytes // 8, dtype=torch.float64, device=self.device)
@@ -210,6 +211,7 @@ class DeviceGP:
                                           self._stream())
             _lib.check(st, "gpbo_append_f64")
             self._u32_valid = False
+            self._u8_valid = False
             if check:
                 info = int(self.info.item())  # synchronises
                 if info != 0:
@@ -257,6 +259,7 @@ class DeviceGP:
             self.alpha[:N] = self._dev(st["alpha"]).reshape(-1)
             self.info.zero_()
             self._u32_valid = False
+            self._u8_valid = False
             self._work_post = None
         return self
 
@@ -351,16 +354,31 @@ class DeviceGP:
         self._u32_valid = True
         return self
 
-    def score_async_f32(self, Xs, acquisition: str = "lcb", explore: float = 4.0, f_best: Optional[float] = None,
-                        xi: float = 0.0, dense: bool = False, idx_offset: int = 0, diag_add: float = 0.0,
-                        prior_var: float = PRIOR_VAR):
-        """fp32 screen of all rows of Xs, then the fp64 decision (gpbo_rescore_f64): the result record holds the fp64
-        path's maximum and its lowest index.  Dense outputs (mu exactly the fp64 path's; sigma / acq with fp32-accurate
-        variance) are float64 tensors.  Unlike score_async this call synchronises (the survivor count is read back).
+    def prepare_i8(self):
+        """Column scales and int8 MFMA fragments of U for the int8-sliced variance screen (once per factorisation)."""
+        torch = self.torch
+        if self.Np > _lib.I8_MAX_N:
+            raise _lib.GpboError(f"the int8-sliced screen needs N <= {_lib.I8_MAX_N} (int32 accumulators)")
+        with torch.cuda.device(self.device):
+            need = int(self.lib.gpbo_prepare_i8_bytes(self.Np))
+            if need < 0:
+                raise _lib.GpboError("gpbo_prepare_i8_bytes: invalid size")
+            if getattr(self, "U8", None) is None or self.U8.numel() < need:
+                self.U8 = torch.empty(need, dtype=torch.uint8, device=self.device)
+            st = self.lib.gpbo_prepare_i8(self._ptr(self.U), self.Np, self._ptr(self.U8), need, self._stream())
+            _lib.check(st, "gpbo_prepare_i8")
+        self._u8_valid = True
+        return self
+
+    SCREEN_TAU0_I8 = 1e-9       # int8-sliced screen: |var64 - var_i8| is ~1e-11; checked per call like the fp32 one
+
+    def _score_screened(self, mode, Xs, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var):
+        """A reduced-cost pass over all rows of Xs (mode "f32": fp32 matrix cores; "i8": int8 slices on the integer
+        matrix cores), then the fp64 decision (gpbo_rescore_f64): the result record holds the fp64 kernels' maximum and
+        its lowest index.  Dense outputs (mu exactly the fp64 path's; sigma / acq with the screen's variance) are
+        float64 tensors.  Unlike score_async this call synchronises (the survivor count is read back).
         `last_screen` keeps the statistics of the call."""
         torch = self.torch
-        if not getattr(self, "_u32_valid", False) or getattr(self, "U32", None) is None:
-            self.prepare_f32()
         Xsd = self._dev(Xs)
         if Xsd.dim() != 2 or int(Xsd.shape[1]) != self.d:
             raise ValueError("Xs must be (M, d) with the same d as X")
@@ -377,14 +395,11 @@ class DeviceGP:
             # N == M shape quirk (point_selector.py:173): gathered rows lose the index the quirk is keyed on
             self.last_screen = dict(fallback=True, reason="diag_add")
             return self.score_async(Xsd, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var)
+        if mode == "f32" and (not getattr(self, "_u32_valid", False) or getattr(self, "U32", None) is None):
+            self.prepare_f32()
+        if mode == "i8" and (not getattr(self, "_u8_valid", False) or getattr(self, "U8", None) is None):
+            self.prepare_i8()
         with torch.cuda.device(self.device):
-            chunk = min(self.chunk, (M + 1023) // 1024 * 1024)
-            chunk = (chunk + 1023) // 1024 * 1024
-            need = int(self.lib.gpbo_posterior_workspace_bytes_f32(self.Np32, chunk, M))
-            if need < 0:
-                raise _lib.GpboError("gpbo_posterior_workspace_bytes_f32: invalid sizes")
-            if getattr(self, "_work_post32", None) is None or self._work_post32.numel() * 8 < need:
-                self._work_post32 = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
             if getattr(self, "_screen_mu", None) is None or self._screen_mu.numel() < M:
                 self._screen_mu = torch.empty(M, dtype=torch.float64, device=self.device)
                 self._screen_var = torch.empty(M, dtype=torch.float64, device=self.device)
@@ -392,14 +407,36 @@ class DeviceGP:
             if dense:
                 mu, sigma, acq = (torch.empty(M, dtype=torch.float64, device=self.device) for _ in range(3))
             mu_w = mu if dense else self._screen_mu
-            st = self.lib.gpbo_posterior_acq_f32(
-                self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np32, self.d,
-                self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.U32), self._ptr(self.alpha), prior_var,
-                kind, p0, p1, 0.0, int(idx_offset), chunk, self._ptr(mu_w), self._ptr(sigma),
-                self._ptr(acq), self._ptr(self._screen_var), self._ptr(self._result), self._ptr(self._work_post32), need,
-                self._profile if self.profile_active else None,
-                self._stream())
-            _lib.check(st, "gpbo_posterior_acq_f32")
+            prof = self._profile if self.profile_active else None
+            lsp = self.ls_h.ctypes.data_as(C.c_void_p)
+            if mode == "f32":
+                chunk = min(self.chunk, (M + 1023) // 1024 * 1024)
+                chunk = (chunk + 1023) // 1024 * 1024
+                need = int(self.lib.gpbo_posterior_workspace_bytes_f32(self.Np32, chunk, M))
+            else:
+                chunk = min(self.chunk, (M + _lib.CHUNK_GRANULE - 1) // _lib.CHUNK_GRANULE * _lib.CHUNK_GRANULE)
+                need = int(self.lib.gpbo_posterior_workspace_bytes_i8(self.Np, chunk, M))
+            if need < 0:
+                raise _lib.GpboError("screen workspace: invalid sizes")
+            if getattr(self, "_work_screen", None) is None or self._work_screen.numel() * 8 < need:
+                self._work_screen = None
+                self._work_screen = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
+            if mode == "f32":
+                st = self.lib.gpbo_posterior_acq_f32(
+                    self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np32, self.d, lsp, self._ptr(self.U32),
+                    self._ptr(self.alpha), prior_var, kind, p0, p1, 0.0, int(idx_offset), chunk, self._ptr(mu_w),
+                    self._ptr(sigma), self._ptr(acq), self._ptr(self._screen_var), self._ptr(self._result),
+                    self._ptr(self._work_screen), need, prof, self._stream())
+                _lib.check(st, "gpbo_posterior_acq_f32")
+                tau0 = float(self.SCREEN_TAU0)
+            else:
+                st = self.lib.gpbo_posterior_acq_i8(
+                    self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d, lsp, self._ptr(self.U8),
+                    self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), chunk, self._ptr(mu_w),
+                    self._ptr(sigma), self._ptr(acq), self._ptr(self._screen_var), self._ptr(self._result),
+                    self._ptr(self._work_screen), need, prof, self._stream())
+                _lib.check(st, "gpbo_posterior_acq_i8")
+                tau0 = float(self.SCREEN_TAU0_I8)
             cap = self.screen_cap if self.screen_cap else max(4096, min(M, max(M // 16, 1 << 16)))
             chunk64 = self.SCREEN_CHUNK64
             rbytes = int(self.lib.gpbo_rescore_workspace_bytes(self.Np, cap, chunk64))
@@ -411,20 +448,35 @@ class DeviceGP:
             stride = max(1, M // self.SCREEN_SAMPLE)
             st = self.lib.gpbo_rescore_f64(
                 self._ptr(Xsd), M, self._ptr(mu_w), self._ptr(self._screen_var), self._ptr(self.X), self.N, self.Np,
-                self.d, self.ls_h.ctypes.data_as(C.c_void_p), self._ptr(self.U), self._ptr(self.alpha), prior_var, kind,
-                p0, p1, int(idx_offset), float(self.SCREEN_TAU0), stride, cap, chunk64, self._ptr(self._result),
+                self.d, lsp, self._ptr(self.U), self._ptr(self.alpha), prior_var, kind,
+                p0, p1, int(idx_offset), tau0, stride, cap, chunk64, self._ptr(self._result),
                 C.byref(stats), self._ptr(self._work_rescore), rbytes, self._stream())
             _lib.check(st, "gpbo_rescore_f64")
-            self.last_screen = dict(survivors=int(stats.survivors), rescored=int(stats.rescored), rounds=int(stats.rounds),
-                                    fallback=bool(stats.fallback), tau=float(stats.tau), err_max=float(stats.err_max),
-                                    candidates=M)
+            self.last_screen = dict(mode=mode, survivors=int(stats.survivors), rescored=int(stats.rescored),
+                                    rounds=int(stats.rounds), fallback=bool(stats.fallback), tau=float(stats.tau),
+                                    err_max=float(stats.err_max), candidates=M)
         self._keep = Xsd
         if stats.fallback:
             # too many candidates could still be the maximum (or tau did not settle): the plain fp64 pass decides
-            res, mu64, sig64, acq64 = self.score_async(Xsd, acquisition, explore, f_best, xi, dense, idx_offset, 0.0,
-                                                       prior_var)
-            return res, mu64, sig64, acq64
+            return self.score_async(Xsd, acquisition, explore, f_best, xi, dense, idx_offset, 0.0, prior_var)
         return self._result, mu, sigma, acq
+
+    def score_async_f32(self, Xs, acquisition: str = "lcb", explore: float = 4.0, f_best: Optional[float] = None,
+                        xi: float = 0.0, dense: bool = False, idx_offset: int = 0, diag_add: float = 0.0,
+                        prior_var: float = PRIOR_VAR):
+        """fp32 variance screen + fp64 decision (BASELINE config 4); see _score_screened."""
+        return self._score_screened("f32", Xs, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var)
+
+    def score_async_i8(self, Xs, acquisition: str = "lcb", explore: float = 4.0, f_best: Optional[float] = None,
+                       xi: float = 0.0, dense: bool = False, idx_offset: int = 0, diag_add: float = 0.0,
+                       prior_var: float = PRIOR_VAR):
+        """int8-sliced variance screen (|dsigma| ~ 1e-10) + fp64 decision; see _score_screened."""
+        return self._score_screened("i8", Xs, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var)
+
+    def score_i8(self, Xs, **kw) -> ScoreResult:
+        res, mu, sigma, acq = self.score_async_i8(Xs, **kw)
+        v, i, n = self.read_result(res)
+        return ScoreResult(v, i, n, mu, sigma, acq)
 
     def score_f32(self, Xs, **kw) -> ScoreResult:
         res, mu, sigma, acq = self.score_async_f32(Xs, **kw)

@@ -280,7 +280,7 @@ def main():
             gbs = bytes_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e9
             kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(gbs / HBM_PEAK_GBS, 4),
-                                  kernel="kstar_mu_f32_kernel" if f32 else "kstar_mu_kernel",
+                                  kernel="kstar_mu_kernel<..., float>" if f32 else "kstar_mu_kernel",
                                   launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
                                   bytes_per_candidate=bytes_per_cand)
 

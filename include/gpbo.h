@@ -200,6 +200,21 @@ int gpbo_rescore_f64(const double *Xs, int64_t M, const double *mu, const double
                      int64_t sample_stride, int64_t cap, int64_t chunk64, gpbo_result *result,
                      gpbo_screen_stats *stats_host, void *work, int64_t work_bytes, void *stream);
 
+/* int8-sliced variance screen (Ozaki-style splitting on the integer matrix cores, csrc/ozaki.hip): same role and
+ * outputs as gpbo_posterior_acq_f32 - mean exactly the fp64 path's, variance from 21 exact int8 slice products
+ * (|dsigma| ~ 1e-10 at N = 4096), decision by gpbo_rescore_f64 - at N <= GPBO_I8_MAX_N (int32 accumulators).
+ * gpbo_prepare_i8: once per factorisation, U -> column scales + int8 MFMA fragments in `u8`
+ * (gpbo_prepare_i8_bytes(Np) bytes, 256-byte aligned).  chunk: a multiple of 512.  No N == M diagonal quirk. */
+#define GPBO_I8_MAX_N 16384
+int64_t gpbo_prepare_i8_bytes(int64_t Np);
+int gpbo_prepare_i8(const double *U, int64_t Np, void *u8, int64_t u8_bytes, void *stream);
+int64_t gpbo_posterior_workspace_bytes_i8(int64_t Np, int64_t chunk, int64_t M);
+int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                          const double *ls_host, const void *u8, const double *alpha, double prior_var,
+                          int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk, double *mu_out,
+                          double *sigma_out, double *acq_out, double *var_out, gpbo_result *result, void *work,
+                          int64_t work_bytes, gpbo_profile *prof /* or NULL */, void *stream);
+
 /* K7+K8 on a posterior already on the device: acq = LCB/EI of (mu, sigma), first-index arg-max
  * (point_selector.py:204-207).  Used for a second acquisition on the same surrogate.
  * work: gpbo_acq_workspace_bytes() bytes, 256-byte aligned. */

@@ -1,0 +1,44 @@
+# timing of the int8-sliced screen at the headline shape (N=4096, d=8), 2^19 candidates, beside the fp64 kernels
+# modes: i8 (screen + fp64 decision), f64 (plain fp64 pass), i8raw (the int8 pass alone: gpbo_posterior_acq_i8 through ctypes)
+import ctypes as C
+import sys, time
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+from bayesian_optimisation_amd import DeviceGP, _lib
+from bayesian_optimisation_amd.gp_device import PRIOR_VAR
+from bayesian_optimisation_amd.synthetic import make_problem
+N, M, d = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 1 << 19, 8
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["i8", "f64"]
+X, y, Xs, ls = make_problem(N, M, d)
+gp = DeviceGP().factorise(X, y, ls)
+Xd = gp._dev(Xs)
+
+
+def i8raw(P):
+    if not getattr(gp, "_u8_valid", False):
+        gp.prepare_i8()
+    m = int(P.shape[0])
+    need = int(gp.lib.gpbo_posterior_workspace_bytes_i8(gp.Np, gp.chunk, m))
+    if getattr(gp, "_w8", None) is None:
+        gp._w8 = torch.empty(need // 8 + 1, dtype=torch.float64, device=gp.device)
+        gp._v8 = torch.empty(m, dtype=torch.float64, device=gp.device)
+    st = gp.lib.gpbo_posterior_acq_i8(gp._ptr(P), m, gp._ptr(gp.X), gp.N, gp.Np, gp.d, gp.ls_h.ctypes.data_as(C.c_void_p),
+                                      gp._ptr(gp.U8), gp._ptr(gp.alpha), PRIOR_VAR, 0, 4.0, 0.0, 0, gp.chunk, None, None, None,
+                                      gp._ptr(gp._v8), gp._ptr(gp._result), gp._ptr(gp._w8), need, None, gp._stream())
+    _lib.check(st, "i8raw")
+    v, i, n = gp.read_result(gp._result)
+
+    class R:
+        best_idx = i
+    return R
+
+
+for name in modes:
+    fn = {"i8": gp.score_i8, "f64": gp.score, "i8raw": i8raw}[name]
+    fn(Xd)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps):
+        r = fn(Xd)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
+    print(name, "N=%d %.2f ms per 2^19" % (N, dt * 1e3), "%.4g cand/s" % (M / dt), r.best_idx, flush=True)
