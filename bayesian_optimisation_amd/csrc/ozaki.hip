@@ -262,56 +262,124 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
             for (int r = 0; r < 16; ++r) acc[g][t][r] = 0;
     double ssrow = 0.0;  // |v|^2 of ONE row of this wave's tile (which row: see the butterfly below)
 
-    // LDS ring protocol (three stages, one barrier per stage, at its END): before the barrier that closes stage t
-    // each wave waits for its own pieces of stage t+1 (issued two stages earlier; the six pieces of stage t+2 may still
-    // be in flight: counted vmcnt); after it every wave has finished reading stage t, whose buffer takes stage t+3.
-    // A DMA therefore has two full stages (about 5,400 MFMA cycles) to land.
+    // ---- software pipeline ---------------------------------------------------------------------------------------
+    // Slice pairs of a stage in row order: M(i) = { K*_i x U_j : j <= 5 - i }, i = 0..5 (12, 10, 8, 6, 4, 2 MFMAs).
+    // LDS ring, three stages, ONE barrier per stage, placed before M(4):
+    //   before it  every wave has all its LDS operands of stage t in registers (K* slices 4 and 5 are fetched early) and
+    //              has waited for its own DMA pieces of stage t+1 (issued a whole stage earlier; the pieces of stage
+    //              t+2 may still be in flight: counted vmcnt);
+    //   after it   stage t+1 is complete for everyone, so its first operands are fetched under the cover of M(4), M(5)
+    //              of stage t - the matrix pipe does not drain at a stage boundary - and the buffer of stage t is free:
+    //              it takes the DMA of stage t+3, which the two waves of a SIMD issue at different times (waves 0-3
+    //              inside M(0), waves 4-7 inside M(2) of the next stage), one piece after every second MFMA.
     int inflight = 0;  // stages issued and not yet waited for
     stage_next();
     ++inflight;
     if (pj < nJ) { stage_next(); ++inflight; }
-    if (pj < nJ) { stage_next(); ++inflight; }
-    if (inflight == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (inflight == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (inflight == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     --inflight;
     __builtin_amdgcn_s_barrier();
+    bool dma_due = pj < nJ;   // a stage is waiting to be issued into the free buffer (stage 2 into buffer 2 at first)
 
     int cur = 0;
-    auto stage_body = [&](bool active) {
-        const char *St = smem + cur * STAGE;
-        const char *As = St + (2 * wr) * NS * FRAG + lane16;
-        const char *Bs = St + HALF_STAGE + wq * NS * FRAG + lane16;
-        i4_t b[NS], a0, a1;
-#pragma unroll
-        for (int j = 0; j < NS; ++j) b[j] = *reinterpret_cast<const i4_t *>(Bs + j * FRAG);
-        a0 = *reinterpret_cast<const i4_t *>(As);
-        a1 = *reinterpret_cast<const i4_t *>(As + NS * FRAG);
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            i4_t n0 = a0, n1 = a1;
-            if (i + 1 < NS) {  // next slice of K* while this one multiplies
-                n0 = *reinterpret_cast<const i4_t *>(As + (i + 1) * FRAG);
-                n1 = *reinterpret_cast<const i4_t *>(As + (NS + i + 1) * FRAG);
-            }
-            if (active) {
-#pragma unroll
-                for (int j = 0; j < NS - i; ++j) {
-                    acc[i + j][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[j], acc[i + j][0], 0, 0, 0);
-                    acc[i + j][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[j], acc[i + j][1], 0, 0, 0);
-                }
-            }
-            a0 = n0;
-            a1 = n1;
+    i4_t b[NS], a0[2];       // U slices of the current stage, K* slice 0 of the current stage (both row tiles)
+    auto lds_a = [&](i4_t (&dst)[2], int buf, int i) {
+        const char *As = smem + buf * STAGE + (2 * wr) * NS * FRAG + lane16;
+        dst[0] = *reinterpret_cast<const i4_t *>(As + i * FRAG);
+        dst[1] = *reinterpret_cast<const i4_t *>(As + (NS + i) * FRAG);
+    };
+    auto lds_b = [&](int buf, int j) {
+        b[j] = *reinterpret_cast<const i4_t *>(smem + buf * STAGE + HALF_STAGE + (wq * NS + j) * FRAG + lane16);
+    };
+    // one DMA piece of the pending stage (wave-uniform piece index q = 0..5: 3 of K*, 3 of U)
+    const char *da = pa, *db = pb;   // sources of the stage being issued piecewise
+    int dbuf = pbuf;
+    auto dma_piece = [&](int q) {
+        char *St = smem + dbuf * STAGE;
+        if (q < 3) glds16b(da + (wid + 8 * q) * FRAG + lane16, St + (wid + 8 * q) * FRAG);
+        else glds16b(db + (wid + 8 * (q - 3)) * FRAG + lane16, St + HALF_STAGE + (wid + 8 * (q - 3)) * FRAG);
+    };
+    auto dma_begin = [&]() {  // latch the sources of the next stage and advance the iterator
+        da = pa; db = pb; dbuf = pbuf;
+        pbuf = (pbuf == 2) ? 0 : pbuf + 1;
+        if (++pk == (pj + 1) * (BN / BK)) {
+            ++pj;
+            pk = 0;
+            pa = a0p;
+            pb = U8 + ((int64_t)pj * (BN / 32) * NS) * FRAG;
+        } else {
+            pa += a_step;
+            pb += b_step;
         }
-        // end of the stage: next stage landed (own pieces) -> barrier -> this stage's buffer is free for stage t+3
-        if (inflight >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#pragma unroll
+    for (int j = 0; j < NS; ++j) lds_b(0, j);
+    lds_a(a0, 0, 0);
+
+    const bool early = wid < 4;  // which of the two waves of a SIMD issues its DMA pieces first
+#define MM(av, i, j)                                                                                         \
+    do {                                                                                                     \
+        acc[(i) + (j)][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0], b[j], acc[(i) + (j)][0], 0, 0, 0); \
+        acc[(i) + (j)][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[1], b[j], acc[(i) + (j)][1], 0, 0, 0); \
+    } while (0)
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    auto stage_body = [&](bool active) {
+        const int nxt = (cur == 2) ? 0 : cur + 1;
+        i4_t a1[2], a2[2], a3[2], a4[2], a5[2];
+        const bool issue_now = dma_due;
+        if (issue_now) dma_begin();
+        SB();
+        lds_a(a1, cur, 1);
+        SB();
+        // M(0): j descending - U slice 0 of this stage was the last operand fetched
+        if (active) { MM(a0, 0, 5); } SB(); if (issue_now && early) dma_piece(0); SB();
+        if (active) { MM(a0, 0, 4); } SB(); if (issue_now && early) dma_piece(1); SB();
+        if (active) { MM(a0, 0, 3); } SB(); if (issue_now && early) dma_piece(2); SB();
+        if (active) { MM(a0, 0, 2); } SB(); if (issue_now && early) dma_piece(3); SB();
+        if (active) { MM(a0, 0, 1); } SB(); if (issue_now && early) dma_piece(4); SB();
+        if (active) { MM(a0, 0, 0); } SB(); if (issue_now && early) dma_piece(5); SB();
+        lds_a(a2, cur, 2);
+        SB();
+        if (active) { MM(a1, 1, 0); MM(a1, 1, 1); MM(a1, 1, 2); MM(a1, 1, 3); MM(a1, 1, 4); }
+        SB();
+        lds_a(a3, cur, 3);
+        SB();
+        if (active) { MM(a2, 2, 0); } SB(); if (issue_now && !early) dma_piece(0); SB();
+        if (active) { MM(a2, 2, 1); } SB(); if (issue_now && !early) dma_piece(1); SB();
+        if (active) { MM(a2, 2, 2); } SB(); if (issue_now && !early) dma_piece(2); SB();
+        if (active) { MM(a2, 2, 3); } SB(); if (issue_now && !early) dma_piece(3); SB();
+        lds_a(a4, cur, 4);
+        lds_a(a5, cur, 5);
+        SB();
+        if (active) { MM(a3, 3, 0); } SB(); if (issue_now && !early) dma_piece(4); SB();
+        if (active) { MM(a3, 3, 1); } SB(); if (issue_now && !early) dma_piece(5); SB();
+        if (active) { MM(a3, 3, 2); }
+        SB();
+        if (issue_now) ++inflight;
+        // all LDS operands of this stage are in registers; own pieces of the next stage have landed
+        if (inflight >= 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (inflight > 0) --inflight;
         __builtin_amdgcn_s_barrier();
-        if (pj < nJ) { stage_next(); ++inflight; }
-        cur = (cur == 2) ? 0 : cur + 1;
+        dma_due = pj < nJ;   // the buffer of this stage is free from here on
+        SB();
+        // next stage's operands under the cover of M(4), M(5); registers of dead U slices are reused as they die
+        lds_b(nxt, 5); lds_b(nxt, 4); lds_b(nxt, 3); lds_b(nxt, 2);
+        SB();
+        if (active) { MM(a4, 4, 0); MM(a4, 4, 1); }
+        SB();
+        lds_b(nxt, 1);
+        lds_a(a0, nxt, 0);
+        SB();
+        if (active) { MM(a5, 5, 0); }
+        SB();
+        lds_b(nxt, 0);
+        SB();
+        cur = nxt;
     };
+#undef MM
+#undef SB
 
     for (int jb = 0; jb < nJ; ++jb) {
         const int ct = jb * (BN / 32) + wq;        // this wave's 32-column tile of V

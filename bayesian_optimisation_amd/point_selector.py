@@ -14,7 +14,8 @@ Differences from the reference, all deliberate:
     is materialised only when M <= COV_PRED_MAX_M; `cov_meas_pred` (:81) only when M*N is small.
   * Failures raise instead of returning garbage: numpy.linalg.LinAlgError when K is not positive
     definite, IndexError when the acquisition contains NaN (the reference's own failure at :207).
-  * Extra, not in the reference: `precision="fp32"` (fp64 factorisation, fp32 scoring), `expected_improvement(xi)`,
+  * Extra, not in the reference: `precision="fp32"` / `"i8"` (fp64 factorisation and means; the N^2 variance product
+    as an fp32 or int8-sliced SCREEN; the selected point is still decided by the fp64 kernels), `expected_improvement(xi)`,
     `q_expected_improvement()`, `kernel_params` may be preset (then no
     ARD search runs), optional multi-GPU candidate sharding when torch.distributed is initialised,
     `incremental=True` / `state_path=...` (append new observations to the previous factorisation in O(N^2)
@@ -70,8 +71,9 @@ class PointSelector:
         self._device = device
         self._verbose = verbose
         self._shard = shard_candidates
-        if precision not in ("fp64", "fp32"):
-            raise ValueError("precision must be 'fp64' (reference arithmetic) or 'fp32' (fp64 factorisation, fp32 scoring)")
+        if precision not in ("fp64", "fp32", "i8"):
+            raise ValueError("precision must be 'fp64' (reference arithmetic), 'fp32' or 'i8' (fp64 factorisation and "
+                             "decision, variance product screened in fp32 / in int8 slices)")
         self._precision = precision
         self._gp = None
         self._mu_dev = self._sigma_dev = None
@@ -141,9 +143,9 @@ class PointSelector:
         diag_add = JITTER_KERNEL if Xs.shape == X.shape else 0.0          # :173 shape-coincidence quirk
         world, rank = self._world()
         lo, hi = D.shard_bounds(M, world, rank)
-        if self._precision == "fp32":   # BASELINE config 4's mode: fp32 K*/mean/variance on the fp32 matrix cores
-            res = gp.score_f32(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
-            res.mu, res.sigma, res.acq = res.mu.double(), res.sigma.double(), res.acq.double()
+        if self._precision in ("fp32", "i8"):   # screened variance product (fp32: BASELINE config 4's mode), fp64 decision
+            score = gp.score_f32 if self._precision == "fp32" else gp.score_i8
+            res = score(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
         else:
             res = gp.score(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
         self._mu_dev, self._sigma_dev = res.mu, res.sigma

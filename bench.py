@@ -32,6 +32,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
+I8_MFMA_PEAK_TOPS = 5033.0  # v_mfma_i32_32x32x32_i8: 2048 int8 op/clk/SIMD x 1024 SIMDs x 2.4 GHz (2x the bf16 rate)
+I8_SLICE_PRODUCTS = 21     # int8 slice products per fp64-equivalent multiply-add (csrc/ozaki.hip)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak = fp64 vector peak (half the 157.3 TF fp32 rate
 #                               listed in MI355X_MICROARCH.md; AMD data sheet value)
 HBM_PEAK_GBS = 8000.0
@@ -66,9 +68,10 @@ def parse_args(argv=None):
                     help="rehearsal only: initialise the process group and run the exchange step even at N=1")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher check (no GPU): every rank joins the process group, rank 0 prints n_gpus / ranks_seen")
-    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+    ap.add_argument("--dtype", choices=["f64", "f32", "i8"], default="f64",
                     help="f32: fp64 factorisation, fp32 screening of all candidates + fp64 re-scoring of the survivors "
-                         "(BASELINE configs[3] shape)")
+                         "(BASELINE configs[3] shape); i8: the same with the variance product from int8 slices on the "
+                         "integer matrix cores (|dsigma| ~ 1e-10)")
     return ap.parse_args(argv)
 
 
@@ -181,8 +184,9 @@ def main():
 
     N, d = args.n_obs, args.d
     f32 = args.dtype == "f32"
+    i8 = args.dtype == "i8"
     qei = args.acq == "qei"
-    if qei and (f32 or args.m_per_gpu % 8):
+    if qei and (f32 or i8 or args.m_per_gpu % 8):
         sys.exit("bench.py: --acq qei needs fp64 and a multiple of 8 candidates per GPU")
     M_total = args.m_per_gpu * world
     lo, hi = D.shard_bounds(M_total, world, rank)
@@ -207,6 +211,8 @@ def main():
             return g.score_qei_async(P, Zd, f_best=f_best, xi=0.0, batch_offset=off // 8)
         if f32:
             return g.score_async_f32(P, idx_offset=off, **acq_kw)
+        if i8:
+            return g.score_async_i8(P, idx_offset=off, **acq_kw)
         return g.score_async(P, idx_offset=off, **acq_kw)
 
     def step(sample_events=True, g=gp, A=Xd, b=yd, P=Xsd, off=lo):
@@ -214,6 +220,8 @@ def main():
         g.factorise(A, b, ls, check=False)
         if f32:
             g.prepare_f32()
+        if i8:
+            g.prepare_i8()
         score_async(g, P, off)
         # the one exchange step: the 40-byte device record (result + factorisation info) is gathered over the ranks
         # and read back once (at N=1: just the read-back, which synchronises this rank)
@@ -265,9 +273,15 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         peak = FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS
-        roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
+        unit = "TFLOP/s"
+        if i8:  # algorithmic work of this kernel: 21 int8 slice products per multiply-add of the triangular product
+            flop_per_cand = I8_SLICE_PRODUCTS * float(N) * N
+            achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
+            peak, unit = I8_MFMA_PEAK_TOPS, "TOP/s (int8)"
+        roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit=unit,
                         frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src,
-                        kernel="sigma_acq_f32_kernel" if f32 else "sigma_acq_kernel", launches=int(k_launches),
+                        kernel={"f32": "sigma_acq_f32_kernel", "i8": "sigma_i8_kernel"}.get(args.dtype, "sigma_acq_kernel"),
+                        launches=int(k_launches),
                         avg_launch_ms=round(k_avg_ms, 4), flop_per_candidate=flop_per_cand,
                         candidates_per_launch=cand_per_launch,
                         event_stride=int(max(args.event_stride, 1)))  # launches of every k-th timed step are bracketed
@@ -276,11 +290,12 @@ def main():
         ks_ms, ks_launches, ks_cands = gp.read_profile_kstar()
         if ks_launches:
             ks_avg = ks_ms / ks_launches
-            bytes_per_cand = (4.0 if f32 else 8.0) * N + 8.0 * d
+            bytes_per_cand = {"f32": 4.0, "i8": 6.0}.get(args.dtype, 8.0) * N + 8.0 * d
             gbs = bytes_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e9
             kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(gbs / HBM_PEAK_GBS, 4),
-                                  kernel="kstar_mu_kernel<..., float>" if f32 else "kstar_mu_kernel",
+                                  kernel={"f32": "kstar_mu_kernel<..., float>", "i8": "kstar_slices_kernel"}.get(
+                                      args.dtype, "kstar_mu_kernel"),
                                   launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
                                   bytes_per_candidate=bytes_per_cand)
 
@@ -299,7 +314,7 @@ def main():
         default workload - a few steps each, outside the timed region above."""
         res = {}
         reps2 = 3
-        if args.acq == "lcb" and not f32:
+        if args.acq == "lcb" and args.dtype == "f64":
             torch.cuda.synchronize(dev)
             t = time.perf_counter()
             for _ in range(reps2):
@@ -309,6 +324,26 @@ def main():
             ms = (time.perf_counter() - t) / reps2 * 1e3
             res["ei_same_workload"] = dict(value=(hi - lo) / (ms * 1e-3), unit="candidates/s", ms_per_step=ms,
                                            argmax_index=i, steps=reps2)
+        if args.dtype == "f64" and N <= 16384:
+            # the same workload with the variance product from int8 slices on the integer matrix cores (csrc/ozaki.hip:
+            # |dsigma| ~ 1e-10, means and the selected point still from the fp64 kernels)
+            gp.prepare_i8()
+            kw8 = dict(idx_offset=lo, **acq_kw)
+            gp.score_async_i8(Xsd, **kw8)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for _ in range(reps2):
+                gp.factorise(Xd, yd, ls, check=False)
+                gp.prepare_i8()
+                gp.score_async_i8(Xsd, **kw8)
+                v, i, n, info = D.allreduce_status(gp.status)
+            ms = (time.perf_counter() - t) / reps2 * 1e3
+            res["int8_sliced_same_workload"] = dict(
+                value=(hi - lo) / (ms * 1e-3), unit="candidates/s", ms_per_step=ms, argmax_index=i,
+                argmax_matches_fp64=bool(i == best[1]), steps=reps2, screen=gp.last_screen,
+                note="variance product = 21 exact int8 slice products on v_mfma_i32_32x32x32_i8 (|dsigma| ~ 1e-10 against "
+                     "the fp64 kernels); means and the selected point are the fp64 kernels'; --dtype i8 times it as the "
+                     "main workload")
         if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb"):
             n2, m2 = 512, 1 << 20
             X2 = sobol_points(0, n2, d)
@@ -329,6 +364,7 @@ def main():
     cfg_name = {(512, 8, "f64", "lcb"): "configs[1]", (4096, 8, "f64", "lcb"): "configs[2] (per-GPU shard)",
                 (4096, 8, "f64", "ei"): "configs[2] (per-GPU shard), EI",
                 (8192, 16, "f32", "lcb"): "configs[3] (per-GPU shard)",
+                (4096, 8, "i8", "lcb"): "configs[2] (per-GPU shard), int8-sliced variance screen",
                 (2048, 8, "f64", "qei"): "configs[4] (per-GPU shard)"}.get((N, d, args.dtype, args.acq), "custom")
     acq_txt = {"lcb": "LCB(explore=4) arg-max", "ei": "Expected Improvement (f_best=min y, xi=0) arg-max",
                "qei": "q=8 Monte-Carlo qEI (512 fixed base samples) arg-max over batches"}[args.acq]
@@ -342,7 +378,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"{cfg_name}: d={d}, N={N} Sobol observations, M={mtxt} "
                                     f"Sobol candidates per GPU, ARD-SE GP, {acq_txt}, "
-                                    f"{'fp64 factorisation + fp32 screen + fp64 re-score of the survivors' if f32 else 'fp64'}; "
+                                    f"{ {'f32': 'fp64 factorisation + fp32 screen + fp64 re-score of the survivors', 'i8': 'fp64 factorisation and means + int8-sliced variance screen + fp64 re-score of the survivors'}.get(args.dtype, 'fp64') }; "
                                     f"step = factorise + score all candidates + reduce"),
                        "candidates_total": M_total, "parallelism": f"candidate-sharded x{world}"},
             "ms_per_step_scoring_only": ms_score,
@@ -351,10 +387,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not qei:
             cb, idx_cpu, ns = cpu_baseline(X, y, Xs_local, ls, args.acq, args.cpu_seconds, args.cpu_sample, f_best)
-            r = (gp.score_f32 if f32 else gp.score)(Xsd[:ns], **acq_kw)
+            r = {"f32": gp.score_f32, "i8": gp.score_i8}.get(args.dtype, gp.score)(Xsd[:ns], **acq_kw)
             cb["argmax_match_on_sample"] = bool(r.best_idx == idx_cpu)
             out["cpu_baseline"] = cb
-        if f32:
+        if f32 or i8:
             out["screen"] = gp.last_screen   # survivors of the fp32 screen, tolerance and its check, fallback flag
         if world == 1 and not args.no_also:
             out["also"] = also()

@@ -37,3 +37,13 @@ def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
     assert "N=4096" in line["cpu_baseline"]["sample"]
     assert 0.5 < line["roofline"]["frac"] <= 1.0
     assert line["also"]["configs[1]"]["value"] > 0 and line["also"]["ei_same_workload"]["value"] > 0
+    i8 = line["also"]["int8_sliced_same_workload"]
+    assert i8["argmax_matches_fp64"] is True and not i8["screen"]["fallback"] and i8["value"] > line["value"]
+
+
+@pytest.mark.gpu
+def test_int8_sliced_mode_as_the_main_workload():
+    line = _bench("--dtype", "i8", "--n-obs", "1024", "--m-per-gpu", "262144", "--steps", "2", "--warmup", "1",
+                  "--cpu-seconds", "3")
+    assert line["dtype"] == "i8" and line["roofline"]["kernel"] == "sigma_i8_kernel" and 0.1 < line["roofline"]["frac"] <= 1.0
+    assert line["cpu_baseline"]["argmax_match_on_sample"] is True and not line["screen"]["fallback"]

@@ -77,3 +77,28 @@ def test_i8_nan_candidate_and_size_limit():
     Xs[77, 0] = np.nan
     r = DeviceGP(chunk=1024).factorise(X, y, ls).score_i8(Xs)
     assert r.nan_count == 1 and r.best_idx != 77
+
+
+@pytest.mark.parametrize("name", ["g1_m32", "g1_m50", "g2_n20_tr", "g4_dup_rows", "g7_n_eq_m"])
+def test_dropin_class_with_the_int8_screen_reproduces_the_reference(golden, name):
+    """The reference's own runs (ARD search included where the fixture has one) through PointSelector(precision="i8"):
+    same length scales, same selected point, dense outputs within the fp64 tolerances of SURVEY.md 8(a)."""
+    from bayesian_optimisation_amd import PointSelector
+
+    g = golden(name)
+    ps = PointSelector(precision="i8")
+    ps.name, ps.iteration = "T", 0
+    ps.measured_pts, ps.measured_vals = g["X"], g["y"]
+    ps.feature_domain, ps.predicted_pts = [int(v) for v in g["feature_domain"]], g["Xs"]
+    if "length_scales" in g:
+        ps.length_scales = g["length_scales"]
+    else:
+        ps.set_kernel_params(g["kernel_params"] if "kernel_params" in g else g["ls"])
+    ps.update_surrogate()
+    idx = ps.lower_confidence_bound()
+    ys = max(1.0, float(np.abs(g["y"]).max()))
+    assert np.max(np.abs(ps.mean_func - g["mean_func"])) <= 1e-9 * ys
+    assert np.max(np.abs(ps.cov_func - g["cov_func"])) <= 1e-8
+    assert np.max(np.abs(ps.acq_func_eval - g["acq_func_eval"])) <= 1e-8 * ys
+    if g["top2_gap"] > 1e-7 * ys or g["n_max_ties"] > 1:
+        assert np.array_equal(idx, g["index"])

@@ -18,6 +18,9 @@ Xd = gp._dev(Xs)
 def i8raw(P):
     if not getattr(gp, "_u8_valid", False):
         gp.prepare_i8()
+        import os
+        if os.environ.get("ZERO_U8"):   # power / clock diagnostic: same instruction stream on all-zero U digits
+            gp.U8[: gp.Np * gp.Np * 6] = 0
     m = int(P.shape[0])
     need = int(gp.lib.gpbo_posterior_workspace_bytes_i8(gp.Np, gp.chunk, m))
     if getattr(gp, "_w8", None) is None:
