@@ -4,7 +4,7 @@ Behavioural mirror of /root/reference/select_parameters.py (a script that runs t
 with hard-coded site paths) as a callable: same inputs (`opto_log.JSON`, `measured_points/*.npy`), same
 outputs (next sample appended to the `.npy` with a placeholder objective, `opto_log.JSON` rewritten with
 `json.dump(indent=4)`, RAT macro + simulate.submit when the template is present, lines appended to
-`algo_log.txt`), same branch structure:
+`algo_log.txt`, the reference's `plot_utils` panels when that module is importable), same branch structure:
 
   * 1-D tuning (amplitudes `[5, 6]` / `[7, 8]`, rise time `[4]`)           select_parameters.py:120-207
   * 2-D tuning of a decay-constant pair, incl. the very first random draw   select_parameters.py:209-337
@@ -47,6 +47,29 @@ def candidate_grid(axis0: np.ndarray, axis1: np.ndarray) -> np.ndarray:
     """Row-major grid X*[i*g + j] = (axis0[i], axis1[j])  (select_parameters.py:273-279)."""
     a, b = np.meshgrid(axis0, axis1, indexing="ij")
     return np.stack([a.ravel(), b.ravel()], axis=1)
+
+
+def _plot_utils():
+    """The reference's plotting module (plot_utils.py; the script star-imports it, select_parameters.py:2) when it is
+    importable from the job's working directory - plots are a side output and never a reason to fail the step."""
+    try:
+        import plot_utils  # type: ignore
+
+        return plot_utils
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def _plot(fn_name, *args):
+    pu = _plot_utils()
+    fn = getattr(pu, fn_name, None) if pu is not None else None
+    if fn is None:
+        return False
+    try:
+        fn(*args)
+    except Exception:  # noqa: BLE001
+        return False
+    return True
 
 
 class _Log:
@@ -158,6 +181,10 @@ def select_parameters(base_dir: str = ".", selector_factory: Optional[Callable] 
         rows = measured_points.tolist()
         rows.append([updated, 10000])                                                 # :163 placeholder objective
         np.save(npy, rows)
+        # :167-170 the iteration's panel, from host copies of the posterior
+        plot_name = f"{feature_name}_ALGO_{algo_iter}_BLOCK_{block_iter}_{iteration}"
+        _plot("surrogate_uncert_acquistion_1d", opt.mean_func, opt.cov_func, opt.acq_func_eval, opt.predicted_pts,
+              plot_name, iteration, rows)
 
         parameters = info["parameters"]
         params_update = _params_vector(parameters)
@@ -217,6 +244,11 @@ def select_parameters(base_dir: str = ".", selector_factory: Optional[Callable] 
             rows = measured_points.tolist()
             rows.append([updated[0], updated[1], 10000])                              # :299
             np.save(npy, rows)
+            # :303-307 the iteration's panel, from host copies of the posterior
+            plot_name = f"{names[0]}_{names[1]}_ALGO_{algo_iter}_BLOCK_{block_iter}_{iteration}"
+            mesh_x, mesh_y = np.meshgrid(axes[0], axes[1])
+            _plot("surrogate_uncert_acquistion", opt.mean_func, opt.cov_func, opt.acq_func_eval, mesh_x, mesh_y,
+                  plot_name, iteration, rows)
             params_update = _params_vector(parameters)
             params_update[cp] = updated
             _write_macro(base_dir, params_update, f"{names[0]}_{names[1]}")
