@@ -116,7 +116,132 @@ __global__ __launch_bounds__(256) void nlml_cell_kernel(const double *__restrict
     }
 }
 
+// ---- any N: all cells of a batch through one blocked Cholesky (factor.hip, gpbo_potrf_batched) ----------------------
+// Cell g owns a bordered matrix [Ne x Ne], Ne = 64 ceil(N/64) + 64:
+//     rows/cols < N            k(x_i, x_j) with the cell's length scales, + jitter on the diagonal
+//     rows N .. Nf-1           identity (padding of the factorised part, Nf = 64 ceil(N/64))
+//     row  Nf                  y^T (columns < N), zero elsewhere: after Nf columns of the factorisation it holds
+//                              (L^-1 y)^T and entry (Nf, Nf) holds -y^T K^-1 y - the bordered-matrix identity the
+//                              in-LDS kernel above uses, here carried by the panel solve / trailing update GEMMs
+//     rows > Nf                identity, never factorised.
+// grid (Ne/256 up, Ne/8, cells), block 256: thread = column, 8 rows per workgroup (as kxx_kernel).
+template <int D>
+__global__ __launch_bounds__(256) void nlml_build_kernel(const double *__restrict__ X, const double *__restrict__ y, int N,
+                                                         int Nf, int Ne, const double *__restrict__ ls_cells,
+                                                         double jitter, double *__restrict__ Ab,
+                                                         int32_t *__restrict__ info) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int64_t g = blockIdx.z;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) info[g] = 0;
+    if (j >= Ne) return;
+    const double *ls = ls_cells + g * D;
+    double il2[D], xj[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        il2[k] = 1.0 / (ls[k] * ls[k]);
+        xj[k] = (j < N) ? X[(int64_t)j * D + k] : 0.0;
+    }
+    double *A = Ab + g * (int64_t)Ne * Ne;
+    const int i0 = blockIdx.y * 8;
+    for (int i = i0; i < i0 + 8; ++i) {
+        double v;
+        if (i < N && j < N) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double diff = xj[k] - X[(int64_t)i * D + k];
+                acc = fma(diff * diff, il2[k], acc);
+            }
+            v = exp(-0.5 * acc);
+            if (i == j) v += jitter;
+        } else if (i == Nf) {
+            v = (j < N) ? y[j] : 0.0;
+        } else {
+            v = (i == j) ? 1.0 : 0.0;
+        }
+        A[(int64_t)i * Ne + j] = v;
+    }
+}
+
+// one workgroup per cell: log det K = 2 sum log L_ii, y^T K^-1 y = -A[Nf][Nf]; NaN when a pivot failed
+__global__ __launch_bounds__(256) void nlml_finish_kernel(const double *__restrict__ Ab, int N, int Nf, int Ne,
+                                                          const int32_t *__restrict__ info, float *__restrict__ out) {
+    __shared__ double s_ld[256];
+    const int tid = threadIdx.x;
+    const double *A = Ab + (int64_t)blockIdx.x * Ne * Ne;
+    double ld = 0.0;
+    for (int i = tid; i < N; i += 256) ld += log(A[(int64_t)i * Ne + i]);
+    s_ld[tid] = ld;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) s_ld[tid] += s_ld[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double logdet = 2.0 * s_ld[0];
+        const double quad = -A[(int64_t)Nf * Ne + Nf];
+        const double logdet_ref = log(exp(logdet));  // the reference takes log of a det that under/overflows
+        double nlml = 0.5 * (quad + logdet_ref + (double)N * 1.8378770664093453);
+        if (info[blockIdx.x] != 0) nlml = __builtin_nan("");
+        out[blockIdx.x] = (float)nlml;
+    }
+}
+
+inline int64_t nlml_batch_cells(int64_t Ne, int64_t G) {
+    // matrices of one sub-batch stay under 8 GiB (2,500 cells at N = 512 are 6.6 GB: one batch)
+    int64_t cap = (int64_t)(8ll << 30) / (Ne * Ne * 8);
+    if (cap < 1) cap = 1;
+    if (cap > 32768) cap = 32768;
+    return G < cap ? G : cap;
+}
+
 }  // namespace
+
+extern "C" int64_t gpbo_nlml_grid_batched_workspace_bytes(int64_t N, int64_t G) {
+    if (N < 1 || G < 1 || N > (1 << 15)) return GPBO_ERR_ARG;
+    const int64_t Nf = (N + GPBO_NB - 1) / GPBO_NB * GPBO_NB, Ne = Nf + GPBO_NB;
+    const int64_t B = nlml_batch_cells(Ne, G);
+    return B * (Ne * Ne * 8 + (Nf / GPBO_NB) * GPBO_NB * GPBO_NB * 8 + 256) + 256;
+}
+
+extern "C" int gpbo_nlml_grid_batched_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells,
+                                          int64_t G, double jitter, float *out, void *work, int64_t work_bytes,
+                                          void *stream) {
+    if (!X || !y || !ls_cells || !out || !work || N < 1 || d < 1 || d > GPBO_MAX_D || G < 1) return GPBO_ERR_ARG;
+    const int64_t need = gpbo_nlml_grid_batched_workspace_bytes(N, G);
+    if (need < 0) return GPBO_ERR_ARG;
+    if (work_bytes < need || ((uintptr_t)work & 255)) return GPBO_ERR_WORKSPACE;
+    const int64_t Nf = (N + GPBO_NB - 1) / GPBO_NB * GPBO_NB, Ne = Nf + GPBO_NB;
+    const int64_t B = nlml_batch_cells(Ne, G);
+    const int nbf = (int)(Nf / GPBO_NB);
+    char *w = reinterpret_cast<char *>(work);
+    double *Ab = reinterpret_cast<double *>(w);
+    double *dinv = Ab + B * Ne * Ne;
+    int32_t *info = reinterpret_cast<int32_t *>(dinv + B * nbf * GPBO_NB * GPBO_NB);
+    hipStream_t st = gpbo_stream(stream);
+    for (int64_t g0 = 0; g0 < G; g0 += B) {
+        const int64_t nb = (G - g0 < B) ? (G - g0) : B;
+        dim3 grid((unsigned)((Ne + 255) / 256), (unsigned)(Ne / 8), (unsigned)nb);
+#define CALL(DD)                                                                                                       \
+    hipLaunchKernelGGL(nlml_build_kernel<DD>, grid, dim3(256), 0, st, X, y, (int)N, (int)Nf, (int)Ne, ls_cells + g0 * d,   \
+                       jitter, Ab, info)
+        switch (d) {
+            case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;   case 4: CALL(4); break;
+            case 5: CALL(5); break;   case 6: CALL(6); break;   case 7: CALL(7); break;   case 8: CALL(8); break;
+            case 9: CALL(9); break;   case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break;
+            case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break;
+            default: return GPBO_ERR_ARG;
+        }
+#undef CALL
+        GPBO_CHECK_LAUNCH();
+        int rc = gpbo_potrf_batched(Ab, Ne, nbf, (int)nb, dinv, info, st);
+        if (rc != GPBO_OK) return rc;
+        hipLaunchKernelGGL(nlml_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, Ab, (int)N, (int)Nf, (int)Ne, info,
+                           out + g0);
+        GPBO_CHECK_LAUNCH();
+    }
+    return GPBO_OK;
+}
 
 extern "C" int gpbo_nlml_cell_f64(const double *U, const double *alpha, const double *y, int64_t N, int64_t Np,
                                   const int32_t *info, float *out, void *stream) {

@@ -61,3 +61,4 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                                  int64_t chunk, double *mu_out, double *sigma_out, double *acq_out, gpbo_result *result,
                                  void *work, int64_t work_bytes, gpbo_profile *prof, int split_max, void *stream);
 #define GPBO_RESCORE_SPLIT_MAX 64
+int gpbo_potrf_batched(double *Ab, int64_t Ne, int nbf, int batch, double *dinv, int32_t *info, hipStream_t st);

@@ -565,17 +565,20 @@ class DeviceGP:
         cells = self._dev(np.asarray(ls_cells, dtype=np.float64).reshape(-1, d))
         G = int(cells.shape[0])
         if N > int(self.lib.gpbo_nlml_grid_max_n()):
-            # beyond the in-LDS kernel's size: one full factorisation per cell (slow path; the reference's own
-            # det-based likelihood is -inf for most cells at such N, which log(exp(logdet)) reproduces)
+            # beyond the in-LDS kernel's size: every cell's bordered matrix through one batched blocked Cholesky
+            # (the reference's own det-based likelihood is -inf for most cells at such N: log(exp(logdet)) reproduces it)
             with torch.cuda.device(self.device):
                 out = torch.empty(G, dtype=torch.float32, device=self.device)
-                cells_h = np.asarray(ls_cells, dtype=np.float64).reshape(-1, d)
-                for g in range(G):
-                    self.factorise(Xd, yd, cells_h[g], jitter, 0.0, check=False)
-                    st = self.lib.gpbo_nlml_cell_f64(self._ptr(self.U), self._ptr(self.alpha), self._ptr(yd), N, self.Np,
-                                                     self._ptr(self.info), C.c_void_p(out.data_ptr() + 4 * g),
-                                                     self._stream())
-                    _lib.check(st, "gpbo_nlml_cell_f64")
+                need = int(self.lib.gpbo_nlml_grid_batched_workspace_bytes(N, G))
+                if need < 0:
+                    raise _lib.GpboError("gpbo_nlml_grid_batched_workspace_bytes: invalid sizes")
+                if getattr(self, "_work_ard", None) is None or self._work_ard.numel() * 8 < need:
+                    self._work_ard = None
+                    self._work_ard = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
+                st = self.lib.gpbo_nlml_grid_batched_f64(self._ptr(Xd), self._ptr(yd), N, d, self._ptr(cells), G,
+                                                         float(jitter), self._ptr(out), self._ptr(self._work_ard), need,
+                                                         self._stream())
+                _lib.check(st, "gpbo_nlml_grid_batched_f64")
                 return out.cpu().numpy()
         with torch.cuda.device(self.device):
             out = torch.empty(G, dtype=torch.float32, device=self.device)

@@ -79,6 +79,8 @@ class PointSelector:
         self._mu_dev = self._sigma_dev = None
         self._cached = None  # (kind, p0, p1) -> (acq ndarray, flat index)
         self._preset_kernel_params = False
+        self._ls_cells = None          # explicit [G x d] cell list for d > 2 (set_length_scale_cells)
+        self.ard_sweeps = 2            # passes of the coordinate-wise search when length_scales holds d > 2 axes
         # consecutive iterations differ by one observed row (select_parameters.py:163,299)
         self._incremental = bool(incremental) or state_path is not None
         self._state_path = state_path
@@ -116,6 +118,16 @@ class PointSelector:
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(), dist.get_rank()
         return 1, 0
+
+    def set_length_scale_cells(self, cells):
+        """d > 2 (not in the reference, whose tune_kernel builds a 1-D or 2-D grid only, point_selector.py:122-163):
+        an explicit list of length-scale vectors [G x d]; tune_kernel() evaluates the reference's likelihood
+        (:111-120) in every cell on the GPU and keeps the FIRST minimum (np.argwhere(g == amin)[0], as :141,159)."""
+        self.length_scales = None
+        self._ls_cells = np.ascontiguousarray(np.asarray(cells, dtype=np.float64))
+        if self._ls_cells.ndim != 2:
+            raise ValueError("cells must be a [G x d] array of length-scale vectors")
+        self._preset_kernel_params = False
 
     def set_kernel_params(self, kernel_params):
         """Preset length scales: update_surrogate() then skips the ARD grid search (needed for d > 2,
@@ -178,6 +190,10 @@ class PointSelector:
             pass
         elif len(X[:, 0]) > 1:                                           # :60
             self.tune_kernel()
+        elif self._ls_cells is not None:                                 # one observation: the middle cell of the list
+            self.kernel_params = np.array(self._ls_cells[len(self._ls_cells) // 2])
+        elif X.shape[1] > 2:                                             # the middle of every axis, as :63-73 does
+            self.kernel_params = np.array([np.asarray(a, dtype=np.float64)[len(a) // 2] for a in self.length_scales])
         else:                                                            # :63-73
             if len(self.length_scales) == 2:
                 a1, a2 = self.length_scales[0], self.length_scales[1]
@@ -249,6 +265,35 @@ class PointSelector:
         X = np.asarray(self.measured_pts, dtype=np.float64)
         y = np.asarray(self.measured_vals, dtype=np.float64)
         plot2, plot1 = _plot_hooks()
+        if self._gp is None:
+            self._gp = DeviceGP(self._device)
+        if self._ls_cells is not None:
+            # explicit cell list (any d): the reference's likelihood in every cell, first minimum wins
+            if self._ls_cells.shape[1] != X.shape[1]:
+                raise ValueError(f"length-scale cells have {self._ls_cells.shape[1]} columns, the observations {X.shape[1]}")
+            nlogml = self._nlml_cells(X, y, self._ls_cells)
+            self.kernel_params = np.array(self._ls_cells[np.argwhere(nlogml == np.amin(nlogml))[0][0]])
+            self.nlogml = nlogml
+            return
+        if X.shape[1] > 2:
+            # d > 2: `length_scales` holds one search axis per feature.  The full Cartesian grid has prod(G_k) cells, so
+            # the axes are searched one at a time from the middle of every axis (the reference's choice when it cannot
+            # tune, :63-73), first minimum per axis, `ard_sweeps` passes.
+            axes = [np.asarray(a, dtype=np.float64).reshape(-1) for a in self.length_scales]
+            if len(axes) != X.shape[1]:
+                raise ValueError(f"length_scales must hold one axis per feature ({X.shape[1]}), got {len(axes)}")
+            ls = np.array([a[len(a) // 2] for a in axes])
+            grids = [None] * len(axes)
+            for _ in range(int(self.ard_sweeps)):
+                for k, a in enumerate(axes):
+                    cells = np.tile(ls, (len(a), 1))
+                    cells[:, k] = a
+                    g = self._nlml_cells(X, y, cells)
+                    grids[k] = g
+                    ls[k] = a[np.argwhere(g == np.amin(g))[0][0]]
+            self.kernel_params = ls
+            self.nlogml = grids
+            return
         if len(self.length_scales) == 2:                                  # :122
             axis1 = np.asarray(self.length_scales[0], dtype=np.float64)
             axis2 = np.asarray(self.length_scales[1], dtype=np.float64)

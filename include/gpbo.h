@@ -255,6 +255,14 @@ int gpbo_nlml_grid_max_n(void);
 int gpbo_nlml_grid_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells, int64_t G,
                        double jitter, float *out, void *stream);
 
+/* The same grid for ANY N: every cell's bordered matrix [K y; y^T 0] goes through one batched blocked Cholesky
+ * (batched potrf_diag + strided-batched MFMA GEMMs; sub-batches of at most 8 GiB of matrices).  Same value per cell
+ * as gpbo_nlml_grid_f64 up to the rounding of a blocked elimination order.  work: ..._workspace_bytes(N, G), 256-byte
+ * aligned. */
+int64_t gpbo_nlml_grid_batched_workspace_bytes(int64_t N, int64_t G);
+int gpbo_nlml_grid_batched_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells,
+                               int64_t G, double jitter, float *out, void *work, int64_t work_bytes, void *stream);
+
 /* One cell of the same grid for any N, from a factorisation made with (jitter1, jitter2) = (1e-4, 0):
  * log det K = -2 sum log U_ii, y^T K^-1 y = y . alpha; NaN when info != 0 (the reference's log of a negative det). */
 int gpbo_nlml_cell_f64(const double *U, const double *alpha, const double *y, int64_t N, int64_t Np,

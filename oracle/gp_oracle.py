@@ -83,6 +83,66 @@ def nlml_grid(X: np.ndarray, y: np.ndarray, length_scales) -> np.ndarray:
     return out
 
 
+def nlml_cells(X: np.ndarray, y: np.ndarray, cells: np.ndarray) -> np.ndarray:
+    """eval_log_marginal (point_selector.py:111-120) for an explicit list of length-scale vectors [G x d], any d:
+    the same arithmetic as `nlml_grid` per cell (1e-4 jitter only, explicit inv and det, float32 result).  The
+    reference's tune_kernel only builds such cells for d = 1 and d = 2; for d > 2 this is its formula applied to the
+    cells the build searches."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    cells = np.asarray(cells, dtype=np.float64).reshape(-1, X.shape[1])
+    n = len(X)
+    out = np.zeros(len(cells), dtype=np.float32)
+    with np.errstate(all="ignore"):
+        for g, kp in enumerate(cells):
+            rbf = kernel_rbf(X, X, kp)
+            inv = np.linalg.inv(rbf)
+            det = np.linalg.det(rbf)
+            out[g] = 0.5 * (y.T @ inv @ y + np.log(det) + n * np.log(2 * np.pi))
+    return out
+
+
+def nlml_cells_stable(X: np.ndarray, y: np.ndarray, cells: np.ndarray) -> np.ndarray:
+    """The same quantity from a Cholesky factorisation (log det = 2 sum log L_ii, y^T K^-1 y = |L^-1 y|^2), with the
+    reference's det underflow applied afterwards (log(exp(logdet)): NumPy's det IS sign * exp(logdet)).  Equal to
+    `nlml_cells` wherever LAPACK's LU determinant is accurate; the comparison value for large N, where the explicit
+    inverse of the reference loses digits first."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    cells = np.asarray(cells, dtype=np.float64).reshape(-1, X.shape[1])
+    n = len(X)
+    out = np.zeros(len(cells))
+    with np.errstate(all="ignore"):
+        for g, kp in enumerate(cells):
+            try:
+                L = np.linalg.cholesky(kernel_rbf(X, X, kp))
+            except np.linalg.LinAlgError:
+                out[g] = np.nan
+                continue
+            z = sla.solve_triangular(L, y, lower=True, check_finite=False)
+            logdet = 2.0 * np.sum(np.log(np.diag(L)))
+            out[g] = 0.5 * (z @ z + np.log(np.exp(logdet)) + n * np.log(2 * np.pi))
+    return out
+
+
+def coordinate_search(X, y, axes, sweeps: int = 2):
+    """Length-scale search for d > 2 (not in the reference, whose tune_kernel handles one or two axes only): start
+    from the middle of every axis (the reference's own choice when it cannot tune, point_selector.py:63-73), then for
+    each axis in turn evaluate the likelihood with that coordinate running over its grid and keep the FIRST minimum
+    (np.argwhere(g == amin)[0], as :141,159), `sweeps` passes over the axes.  Returns (kernel_params, last grids)."""
+    axes = [np.asarray(a, dtype=np.float64) for a in axes]
+    ls = np.array([a[len(a) // 2] for a in axes])
+    grids = [None] * len(axes)
+    for _ in range(sweeps):
+        for k, a in enumerate(axes):
+            cells = np.tile(ls, (len(a), 1))
+            cells[:, k] = a
+            g = nlml_cells(X, y, cells)
+            grids[k] = g
+            ls[k] = a[int(first_min_index(g)[0])]
+    return ls, grids
+
+
 def first_min_index(grid: np.ndarray) -> np.ndarray:
     """np.argwhere(g == np.amin(g))[0]  (point_selector.py:141,159): first row-major minimum;
     a NaN anywhere makes amin NaN, the comparison empty, and the [0] an IndexError."""

@@ -219,3 +219,68 @@ def test_nlml_grid_large_n(env, N):
             assert abs(o - r) <= 1e-5 * abs(r) + 1e-3
         else:
             assert (np.isnan(r) and np.isnan(o)) or o == r
+
+
+def _nlml_direct(gp, X, y, cells, batched):
+    """The two grid entry points called directly (DeviceGP.nlml_grid picks by N)."""
+    import ctypes as C
+
+    torch = gp.torch
+    Xd, yd, cd = gp._dev(X), gp._dev(y), gp._dev(cells)
+    N, d, G = X.shape[0], X.shape[1], cells.shape[0]
+    out = torch.empty(G, dtype=torch.float32, device=gp.device)
+    if batched:
+        need = int(gp.lib.gpbo_nlml_grid_batched_workspace_bytes(N, G))
+        work = torch.empty(need // 8 + 1, dtype=torch.float64, device=gp.device)
+        st = gp.lib.gpbo_nlml_grid_batched_f64(gp._ptr(Xd), gp._ptr(yd), N, d, gp._ptr(cd), G, 1e-4, gp._ptr(out),
+                                               gp._ptr(work), need, gp._stream())
+    else:
+        st = gp.lib.gpbo_nlml_grid_f64(gp._ptr(Xd), gp._ptr(yd), N, d, gp._ptr(cd), G, 1e-4, gp._ptr(out), gp._stream())
+    assert st == 0
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("N,d", [(2, 2), (63, 1), (64, 3), (65, 2), (150, 8), (176, 2)])
+def test_nlml_batched_cholesky_agrees_with_the_in_lds_kernel(env, N, d):
+    """Same cells through both routes (the batched blocked Cholesky takes over above N = 176): float32 values equal to
+    rounding, identical first minimum."""
+    from bayesian_optimisation_amd import DeviceGP
+
+    X, y, _, _ = make_problem(N, 8, d)
+    rng = np.random.default_rng(N)
+    cells = np.exp(rng.uniform(np.log(0.02), np.log(3.0), size=(70, d)))
+    gp = DeviceGP()
+    a, b = _nlml_direct(gp, X, y, cells, batched=False), _nlml_direct(gp, X, y, cells, batched=True)
+    fin = np.isfinite(a)
+    assert np.array_equal(fin, np.isfinite(b)) and np.array_equal(a[~fin], b[~fin], equal_nan=True)
+    np.testing.assert_allclose(b[fin], a[fin], rtol=3e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,d,G", [(300, 2, 90), (512, 3, 64), (700, 8, 40), (1030, 2, 12)])
+def test_nlml_batched_large_n_vs_oracle(env, N, d, G):
+    """Beyond the LDS kernel: the reference's formula (inv + det, oracle nlml_cells) where its det is a normal number,
+    its -inf where det underflows; everywhere the Cholesky form of the same quantity."""
+    from bayesian_optimisation_amd import DeviceGP
+
+    X, y, _, _ = make_problem(N, 8, d)
+    rng = np.random.default_rng(N + d)
+    cells = np.exp(rng.uniform(np.log(0.01), np.log(0.4), size=(G, d)))
+    cells[0] = 3.0   # a smooth cell: det underflows in the reference
+    out = DeviceGP().nlml_grid(X, y, cells)
+    assert out.dtype == np.float32 and out.shape == (G,)
+    ref = O.nlml_cells(X, y, cells)
+    stable = O.nlml_cells_stable(X, y, cells)
+    assert np.isneginf(out[0]) or np.isnan(out[0])
+    n_fin = 0
+    for o, r, s in zip(out, ref, stable):
+        if np.isfinite(s):
+            assert abs(o - s) <= 3e-6 * abs(s) + 1e-3
+        else:
+            assert o == s or (np.isnan(o) and np.isnan(s))
+        if np.isfinite(r) and np.isfinite(s) and abs(r - s) <= 1e-3 * abs(s):   # LU det still accurate here
+            assert abs(o - r) <= 1e-5 * abs(r) + 1e-2
+            n_fin += 1
+    assert n_fin >= G // 4
+    fin = np.isfinite(stable)
+    if fin.all():
+        assert int(np.flatnonzero(out == out.min())[0]) == int(np.flatnonzero(stable.astype(np.float32) == stable.astype(np.float32).min())[0])

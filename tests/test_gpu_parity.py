@@ -615,3 +615,50 @@ def test_two_stream_overlap_mode_gives_identical_results():
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(p.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1]
+
+
+# ----------------------------------------------------------------------------------------------
+# ARD search beyond the reference's two layouts (d > 2)
+# ----------------------------------------------------------------------------------------------
+def _selector_for(X, y, Xs):
+    ps = PointSelector()
+    ps.name, ps.iteration = "T", 0
+    ps.measured_pts, ps.measured_vals = X, y
+    ps.feature_domain, ps.predicted_pts = [len(Xs)], Xs
+    return ps
+
+
+@pytest.mark.parametrize("d,N", [(3, 40), (8, 90), (5, 300)])
+def test_ard_coordinate_search_for_more_than_two_features(d, N):
+    """length_scales = one axis per feature: coordinate-wise search from the axis mid-points, first minimum per axis,
+    two sweeps - the reference's likelihood (point_selector.py:111-120) evaluated on the GPU; same winner as the oracle."""
+    X, y, Xs, _ = make_problem(N, 2048, d)
+    axes = [np.linspace(0.05 + 0.01 * k, 0.6 + 0.05 * k, 9 + k) for k in range(d)]
+    ps = _selector_for(X, y, Xs)
+    ps.length_scales = axes
+    ps.update_surrogate()
+    idx = ps.lower_confidence_bound()
+    ls_o, grids_o = O.coordinate_search(X, y, axes, sweeps=2)
+    assert np.array_equal(ps.kernel_params, ls_o)
+    for g, go in zip(ps.nlogml, grids_o):
+        fin = np.isfinite(go)
+        np.testing.assert_allclose(g[fin], go[fin], rtol=1e-5, atol=1e-2)
+    mu_o, sig_o = O.posterior_chol(X, y, Xs, ls_o)
+    assert idx[0] == _first_argmax(O.lcb(mu_o, sig_o, 4))
+
+
+def test_ard_explicit_cell_list_d8():
+    X, y, Xs, _ = make_problem(60, 1024, 8)
+    cells = np.exp(np.random.default_rng(3).uniform(np.log(0.05), np.log(0.8), size=(300, 8)))
+    ps = _selector_for(X, y, Xs)
+    ps.set_length_scale_cells(cells)
+    ps.update_surrogate()
+    ref = O.nlml_cells(X, y, cells)
+    assert np.array_equal(ps.kernel_params, cells[int(np.argwhere(ref == np.amin(ref))[0][0])])
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(ps.nlogml[fin], ref[fin], rtol=1e-5, atol=1e-2)
+    # one observation: no search, the middle cell (the reference's mid-point rule, point_selector.py:63-73)
+    ps1 = _selector_for(X[:1], y[:1], Xs)
+    ps1.set_length_scale_cells(cells)
+    ps1.update_surrogate()
+    assert np.array_equal(ps1.kernel_params, cells[150])

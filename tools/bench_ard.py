@@ -8,7 +8,7 @@ from bayesian_optimisation_amd.synthetic import make_problem
 a1, a2 = np.linspace(0.05, 3.0, 50), np.linspace(0.05, 3.0, 50)
 cells = np.stack(np.meshgrid(a1, a2, indexing="ij"), -1).reshape(-1, 2)
 gp = DeviceGP()
-for N in (32, 64, 128, 176, 200):
+for N in (32, 64, 128, 176, 200, 512, 1024):
     X, y, _, _ = make_problem(N, 8, 2)
     gp.nlml_grid(X, y, cells[:50])
     torch.cuda.synchronize()
