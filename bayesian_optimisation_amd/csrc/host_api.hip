@@ -129,28 +129,19 @@ extern "C" int gpbo_nlml_grid_host_f64(const double *X, const double *y, int64_t
     if (!A.ok) return GPBO_ERR_WORKSPACE;
     if (!A.h2d(dX, X, sizeof(double) * N * d) || !A.h2d(dy, y, sizeof(double) * N)) return GPBO_ERR_LAUNCH;
     int rc;
-    if (N <= gpbo_nlml_grid_max_n()) {
-        double *dcells = A.alloc<double>(G * d);
-        if (!A.ok) return GPBO_ERR_WORKSPACE;
-        if (!A.h2d(dcells, ls_cells, sizeof(double) * G * d)) return GPBO_ERR_LAUNCH;
+    double *dcells = A.alloc<double>(G * d);
+    if (!A.ok) return GPBO_ERR_WORKSPACE;
+    if (!A.h2d(dcells, ls_cells, sizeof(double) * G * d)) return GPBO_ERR_LAUNCH;
+    if (N <= 64) {   // the in-LDS kernel (DeviceGP.ARD_LDS_MAX_N: the same switch as the tensor-resident binding)
         rc = gpbo_nlml_grid_f64(dX, dy, N, d, dcells, G, jitter, dout, st);
         if (rc != GPBO_OK) return rc;
-    } else {
-        // beyond the in-LDS kernel: one full factorisation per cell (the reference's own det-based likelihood
-        // is -inf for most cells at such N, which gpbo_nlml_cell_f64 reproduces)
-        const int64_t Np = gpbo_padded_n(N);
-        const int64_t wfact = gpbo_factorise_workspace_bytes(Np);
-        double *dK = A.alloc<double>(Np * Np), *dU = A.alloc<double>(Np * Np), *dalpha = A.alloc<double>(Np);
-        int32_t *dinfo = A.alloc<int32_t>(1);
-        char *dwork = A.alloc<char>(wfact);
+    } else {         // every cell's bordered matrix through one batched blocked Cholesky
+        const int64_t wb = gpbo_nlml_grid_batched_workspace_bytes(N, G);
+        if (wb < 0) return GPBO_ERR_ARG;
+        char *dwork = A.alloc<char>(wb);
         if (!A.ok) return GPBO_ERR_WORKSPACE;
-        for (int64_t g = 0; g < G; ++g) {
-            rc = gpbo_factorise_f64(dX, dy, N, d, ls_cells + g * d, jitter, 0.0, Np, dK, dU, dalpha, dinfo, dwork, wfact,
-                                    st);
-            if (rc != GPBO_OK) return rc;
-            rc = gpbo_nlml_cell_f64(dU, dalpha, dy, N, Np, dinfo, dout + g, st);
-            if (rc != GPBO_OK) return rc;
-        }
+        rc = gpbo_nlml_grid_batched_f64(dX, dy, N, d, dcells, G, jitter, dout, dwork, wb, st);
+        if (rc != GPBO_OK) return rc;
     }
     if (!A.d2h(out, dout, sizeof(float) * G) || !A.sync()) return GPBO_ERR_LAUNCH;
     return GPBO_OK;

@@ -557,6 +557,8 @@ class DeviceGP:
         return ScoreResult(v, i, n, mu, sigma, acq)
 
     # -- ARD grid ------------------------------------------------------------------------------------
+    ARD_LDS_MAX_N = 64   # above: the batched blocked Cholesky (faster from here on; see nlml_grid)
+
     def nlml_grid(self, X, y, ls_cells, jitter: float = JITTER_KERNEL) -> np.ndarray:
         """float32 -log marginal likelihood of every row of ls_cells [G x d]  (point_selector.py:111-156)."""
         torch = self.torch
@@ -564,9 +566,12 @@ class DeviceGP:
         N, d = int(Xd.shape[0]), int(Xd.shape[1])
         cells = self._dev(np.asarray(ls_cells, dtype=np.float64).reshape(-1, d))
         G = int(cells.shape[0])
-        if N > int(self.lib.gpbo_nlml_grid_max_n()):
-            # beyond the in-LDS kernel's size: every cell's bordered matrix through one batched blocked Cholesky
-            # (the reference's own det-based likelihood is -inf for most cells at such N: log(exp(logdet)) reproduces it)
+        if N > self.ARD_LDS_MAX_N:
+            # every cell's bordered matrix through one batched blocked Cholesky: measured on MI355X, 2,500 cells take
+            # 0.30 / 0.80 / 1.43 / 11.9 / 62 ms at N = 64 / 128 / 176 / 512 / 1024 (the one-workgroup-per-cell in-LDS kernel:
+            # 0.52 / 5.4 / 11.7 ms at N = 64 / 128 / 176, and it stops at 176); small N stays on the in-LDS kernel, whose
+            # elimination order is the one pinned against the reference's float32 ties (golden g4_ard_n2).
+            # (the reference's det-based likelihood is -inf for most cells beyond N ~ 100: log(exp(logdet)) reproduces it)
             with torch.cuda.device(self.device):
                 out = torch.empty(G, dtype=torch.float32, device=self.device)
                 need = int(self.lib.gpbo_nlml_grid_batched_workspace_bytes(N, G))

@@ -16,3 +16,20 @@ for N in (32, 64, 128, 176, 200, 512, 1024):
     out = gp.nlml_grid(X, y, cells)
     dt = time.perf_counter() - t
     print(f"N={N}: 2,500 cells in {dt*1e3:.2f} ms  (finite cells: {int(np.isfinite(out).sum())})", flush=True)
+
+# the batched blocked Cholesky at sizes the in-LDS kernel also handles (where is the cross-over?)
+import ctypes as C
+for N in (64, 96, 128, 176):
+    X, y, _, _ = make_problem(N, 8, 2)
+    Xd, yd, cd = gp._dev(X), gp._dev(y), gp._dev(cells)
+    out = torch.empty(len(cells), dtype=torch.float32, device=gp.device)
+    need = int(gp.lib.gpbo_nlml_grid_batched_workspace_bytes(N, len(cells)))
+    work = torch.empty(need // 8 + 1, dtype=torch.float64, device=gp.device)
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        gp.lib.gpbo_nlml_grid_batched_f64(gp._ptr(Xd), gp._ptr(yd), N, 2, gp._ptr(cd), len(cells), 1e-4, gp._ptr(out),
+                                          gp._ptr(work), need, gp._stream())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+    print(f"batched route, N={N}: 2,500 cells in {dt*1e3:.2f} ms", flush=True)
