@@ -107,12 +107,20 @@ def _bind_to_pytorch_hip_runtime():
         spec = None
     if spec is None or not spec.origin:
         return
-    rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(rt):
-        try:
-            C.CDLL(rt, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass  # fall back to the system runtime
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    # The whole ROCm stack PyTorch bundles, in dependency order, so that a later `import torch` finds every one of its
+    # runtime libraries already in place and from ITS directory (tools/maps_probe.py shows what is mapped in each
+    # load order; with only libamdhip64 preloaded the system ROCm's libhsa-amd-aqlprofile64 ended up inside PyTorch's
+    # HSA runtime in the library-first order and in no other).
+    for name in ("librocm-core.so", "libdrm.so", "libdrm_amdgpu.so", "libnuma.so", "libelf.so", "librocprofiler-register.so",
+                 "libhsa-runtime64.so", "libamd_comgr.so", "libamdhip64.so", "libhiprtc.so", "libroctx64.so",
+                 "libroctracer64.so"):
+        rt = os.path.join(libdir, name)
+        if os.path.exists(rt):
+            try:
+                C.CDLL(rt, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass  # fall back to whatever the dynamic linker resolves
 
 
 def note_hip_use():

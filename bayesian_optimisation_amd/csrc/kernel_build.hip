@@ -111,15 +111,25 @@ constexpr int KS_SLICE = GPBO_KS_SLICE;
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
 // two adjacent candidates' entries of one K*^T row: 16 B (fp64) or, rounded once to fp32, 8 B (the fp32 screen)
-__device__ __forceinline__ void store_pair(double *p, double a, double b) { *reinterpret_cast<d2_t *>(p) = d2_t{a, b}; }
+// NT: the non-temporal hint on the rows of K*^T.  Measured on MI355X (same box, tools/ab_kstar.sh): at N = 4096 a
+// 2^17-candidate slab is 4.3 GB - nothing of it survives in the 256-MiB Infinity Cache until the variance kernel reads it,
+// and with the hint the build runs 0.966 -> 0.807 ms (4.5 -> 5.3 TB/s); at N = 512 (537 MB) the variance kernel still
+// finds part of the slab on chip and the hint costs it 2 % for a 2 % shorter build: the host picks by slab size.
+template <bool NT>
+__device__ __forceinline__ void store_pair(double *p, double a, double b) {
+    if (NT) __builtin_nontemporal_store(d2_t{a, b}, reinterpret_cast<d2_t *>(p));
+    else *reinterpret_cast<d2_t *>(p) = d2_t{a, b};
+}
+template <bool NT>
 __device__ __forceinline__ void store_pair(float *p, double a, double b) {
-    *reinterpret_cast<f2_t *>(p) = f2_t{(float)a, (float)b};
+    if (NT) __builtin_nontemporal_store(f2_t{(float)a, (float)b}, reinterpret_cast<f2_t *>(p));
+    else *reinterpret_cast<f2_t *>(p) = f2_t{(float)a, (float)b};
 }
 
 // TK = double: the fp64 path.  TK = float (gpbo_kstar_mu_mixed): entries and means are computed exactly as in the
 // fp64 path - the mean partials are the same doubles bit for bit - and only the stored K*^T is rounded to fp32
 // (relative error <= 2^-24 per entry) for the fp32 variance screen.
-template <int D, int VARIANT, bool HAS_DIAG, typename TK>
+template <int D, int VARIANT, bool HAS_DIAG, typename TK, bool NT>
 __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict__ Xs, int64_t Mc,
                                                        const double *__restrict__ Xsc, int N, LsArgs ls,
                                                        const double *__restrict__ alpha, double diag_add,
@@ -177,8 +187,8 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
         mua = fma(k10, a1, mua);
         mub = fma(k11, a1, mub);
         if (VARIANT != 1) {
-            store_pair(out, k00, k01);
-            store_pair(out + ldk, k10, k11);
+            store_pair<NT>(out, k00, k01);
+            store_pair<NT>(out + ldk, k10, k11);
         } else {
             mua += (k00 + k10) * 1e-300;
             mub += (k01 + k11) * 1e-300;
@@ -202,12 +212,12 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
         const double an = alpha[n];
         mua = fma(ka, an, mua);
         mub = fma(kb, an, mub);
-        store_pair(out, ka, kb);
+        store_pair<NT>(out, ka, kb);
         out += ldk;
         ++n;
     }
     for (n = (nend > n0 ? nend : n0); n < n0 + KS_SLICE; ++n) {
-        store_pair(out, 0.0, 0.0);
+        store_pair<NT>(out, 0.0, 0.0);
         out += ldk;
     }
     d2_t m = {nan_a ? __builtin_nan("") : mua, nan_b ? __builtin_nan("") : mub};
@@ -318,9 +328,12 @@ extern "C" int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *Xsc
 #else
     constexpr int variant = 0;
 #endif
-#define KSTAR_LAUNCH(DD, V, H)                                                                                       \
-    hipLaunchKernelGGL((kstar_mu_kernel<DD, V, H, double>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, Xsc, (int)N, ls, \
-                       alpha, diag_add, cand_base, KsT, ldk, mu_part)
+    const bool nt = (int64_t)sizeof(double) * Np * ldk > ((int64_t)1 << 30);  // slab beyond what the Infinity Cache keeps
+#define KSTAR_LAUNCH1(DD, V, H, NTF)                                                                                  \
+    hipLaunchKernelGGL((kstar_mu_kernel<DD, V, H, double, NTF>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, Xsc, (int)N, \
+                       ls, alpha, diag_add, cand_base, KsT, ldk, mu_part)
+#define KSTAR_LAUNCH(DD, V, H) \
+    do { if (nt) KSTAR_LAUNCH1(DD, V, H, true); else KSTAR_LAUNCH1(DD, V, H, false); } while (0)
 #ifdef GPBO_DIAGNOSTICS
 #define CALL(DD)                                        \
     if (diag_add != 0.0) KSTAR_LAUNCH(DD, 0, true);     \
@@ -351,13 +364,17 @@ int gpbo_kstar_mu_mixed(const double *Xs, int64_t Mc, const double *Xsc, int64_t
     if (rc != GPBO_OK) return rc;
     const int64_t used = (Mc + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
     dim3 grid((unsigned)(used / 512), (unsigned)(Np / KS_SLICE));
+    const bool nt = (int64_t)sizeof(float) * Np * ldk > ((int64_t)1 << 30);
 #define CALL(DD)                                                                                                     \
     if (diag_add != 0.0)                                                                                             \
-        hipLaunchKernelGGL((kstar_mu_kernel<DD, 0, true, float>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, Xsc,    \
-                           (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part);                               \
+        hipLaunchKernelGGL((kstar_mu_kernel<DD, 0, true, float, false>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc,  \
+                           Xsc, (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part);                          \
+    else if (nt)                                                                                                     \
+        hipLaunchKernelGGL((kstar_mu_kernel<DD, 0, false, float, true>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc,  \
+                           Xsc, (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part);                          \
     else                                                                                                             \
-        hipLaunchKernelGGL((kstar_mu_kernel<DD, 0, false, float>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, Xsc,   \
-                           (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part)
+        hipLaunchKernelGGL((kstar_mu_kernel<DD, 0, false, float, false>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, \
+                           Xsc, (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part)
     GPBO_DISPATCH_D(d, CALL)
 #undef CALL
     GPBO_CHECK_LAUNCH();

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void u_slices_kernel(const double *__restrict_
 // ---- K(X*,X) chunk -> int8 fragments + fp64 mean partials ---------------------------------------------------------------
 // grid (ldk_used/256, Np/64), block 256: thread = one candidate, blockIdx.y = 64 observations (four 16-entry lane
 // operands).  Entries and mean partials are the fp64 path's (same distance / exp arithmetic, same fma order over n).
-template <int D>
+template <int D, bool NT /* non-temporal stores: slabs far beyond the Infinity Cache (see kernel_build.hip) */>
 __global__ __launch_bounds__(256) void kstar_slices_kernel(const double *__restrict__ Xs, int64_t Mc,
                                                            const double *__restrict__ Xsc, int N, LsArgsI8 ls,
                                                            const double *__restrict__ alpha, char *__restrict__ A8,
@@ -203,8 +203,11 @@ __global__ __launch_bounds__(256) void kstar_slices_kernel(const double *__restr
         const int kb = n0 >> 5, kg = (n0 >> 4) & 1;
         char *base = A8 + (((int64_t)kb * RT + (c >> 5)) * NS) * FRAG + kg * 512 + (int)(c & 31) * 16;
 #pragma unroll
-        for (int a = 0; a < NS; ++a)
-            *reinterpret_cast<i4_t *>(base + a * FRAG) = i4_t{(int)out[a][0], (int)out[a][1], (int)out[a][2], (int)out[a][3]};
+        for (int a = 0; a < NS; ++a) {
+            const i4_t v = {(int)out[a][0], (int)out[a][1], (int)out[a][2], (int)out[a][3]};
+            if (NT) __builtin_nontemporal_store(v, reinterpret_cast<i4_t *>(base + a * FRAG));
+            else *reinterpret_cast<i4_t *>(base + a * FRAG) = v;
+        }
     }
     mu_part[(int64_t)blockIdx.y * ldk + c] = nan_c ? __builtin_nan("") : mu;
 }
@@ -567,9 +570,12 @@ extern "C" int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *
         // fragments of whole 128-candidate blocks are read by the variance kernel: build them for every block touched
         const int64_t used = (Mc + 255) / 256 * 256;
         dim3 kgrid((unsigned)(used / 256), (unsigned)(Np / KS_SLICE));
-#define CALL(DD)                                                                                                     \
-    hipLaunchKernelGGL(kstar_slices_kernel<DD>, kgrid, dim3(256), 0, st, Xs + s * d, Mc, Xsc, (int)N, ls, alpha, A8, RT, \
-                       mu_part, chunk)
+        const bool nt = Np * chunk * NS > ((int64_t)1 << 30);
+#define CALL(DD)                                                                                                          \
+    if (nt) hipLaunchKernelGGL((kstar_slices_kernel<DD, true>), kgrid, dim3(256), 0, st, Xs + s * d, Mc, Xsc, (int)N, ls,     \
+                               alpha, A8, RT, mu_part, chunk);                                                            \
+    else hipLaunchKernelGGL((kstar_slices_kernel<DD, false>), kgrid, dim3(256), 0, st, Xs + s * d, Mc, Xsc, (int)N, ls,       \
+                            alpha, A8, RT, mu_part, chunk)
         switch (d) {
             case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;   case 4: CALL(4); break;
             case 5: CALL(5); break;   case 6: CALL(6); break;   case 7: CALL(7); break;   case 8: CALL(8); break;
