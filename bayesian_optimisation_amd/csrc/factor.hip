@@ -330,11 +330,12 @@ extern "C" int gpbo_trtri_f64(const double *L, const double *dinv, int64_t Np, d
         const int64_t stride = 2 * s * (Np + 1);
         if (full > 0) {
             // T21 = L21 * W11 ; W21 = -W22 * T21      (block (p): rows o+s.., cols o.., o = 2ps)
-            int rc = gpbo_gemm_launch(0, s, s, s, 1.0, L + s * Np, Np, stride, W, Np, stride, 0.0, T + s * Np, Np,
-                                      stride, (int)full, 0, st);
+            // (W11 and W22 are lower triangular: the zero halves of the k ranges are skipped, tri = 1 / 2)
+            int rc = gpbo_gemm_launch_tri(0, s, s, s, 1.0, L + s * Np, Np, stride, W, Np, stride, 0.0, T + s * Np, Np,
+                                          stride, (int)full, 0, 1, st);
             if (rc != GPBO_OK) return rc;
-            rc = gpbo_gemm_launch(0, s, s, s, -1.0, W + s * Np + s, Np, stride, T + s * Np, Np, stride, 0.0,
-                                  W + s * Np, Np, stride, (int)full, 0, st);
+            rc = gpbo_gemm_launch_tri(0, s, s, s, -1.0, W + s * Np + s, Np, stride, T + s * Np, Np, stride, 0.0,
+                                      W + s * Np, Np, stride, (int)full, 0, 2, st);
             if (rc != GPBO_OK) return rc;
         }
         if (rem > s) {  // ragged last pair: W11 is s x s, W22 is m2 x m2 with m2 = rem - s < s

@@ -22,12 +22,17 @@ constexpr int LDA_S = 17;  // As[m][k] / Bt[n][k] row stride (doubles)
 // T = tile edge (64 or 32).  The 32 x 32 variant serves the small products of the factorisation (N <= 1024: a
 // 448 x 448 trailing update is 28 tiles of 64 x 64 - 28 of 256 CUs - and every k tile then costs 16 dependent MFMAs
 // per wave; with 32 x 32 tiles the same update runs on 105 workgroups with 4 MFMAs per k tile).
+// tri: 1 = B [K x N] is lower triangular (rows k < n are zero): the k loop of column tile bx starts at bx T;
+//      2 = A [M x K] is lower triangular (columns k > m are zero): the k loop of row tile by ends at (by + 1) T
+// (the two products of each level of the triangular inverse; N = 4096: factorisation 3.42 -> 3.17 ms).
+// (A 128 x 128 tile - wave tile 64 x 64, 210 registers - was measured and is SLOWER than this one on every shape of the
+//  factorisation: 8192^2 x 256 lower-triangle update 29.5 against 39.3 TFLOP/s, 4096^3 49.8 against 54.2.)
 template <int TRANSB, int T>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int64_t K, double alpha,
                                                         const double *__restrict__ A, int64_t lda, int64_t strideA,
                                                         const double *__restrict__ B, int64_t ldb, int64_t strideB,
                                                         double beta, double *__restrict__ C, int64_t ldc,
-                                                        int64_t strideC, int lower_only) {
+                                                        int64_t strideC, int lower_only, int tri) {
     constexpr int TM = T, TN = T;
     constexpr int FM = T / 32;            // 16 x 16 MFMA tiles per wave in each direction (wave tile T/2 x T/2)
     constexpr int LDB_S = T + 16;         // Bs[k][n] row stride (doubles): lanes 16-31 land 32 banks away
@@ -75,8 +80,12 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int
             b0 = bp[0]; b1 = bp[1];
         }
     };
-    gload(0);
-    for (int64_t k0 = 0; k0 < K; k0 += BK) {
+    // k range of this tile (triangular operands of the inverse: the zero part is never read)
+    int64_t kbeg = 0, kend = K;
+    if (tri == 1) kbeg = (int64_t)bx * T;
+    if (tri == 2 && (int64_t)(by + 1) * T < K) kend = (int64_t)(by + 1) * T;
+    gload(kbeg);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();  // previous tile fully consumed
         if (stager) {
             As[ar * LDA_S + ak + 0] = a0.x; As[ar * LDA_S + ak + 1] = a0.y;
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int
             }
         }
         __syncthreads();
-        if (k0 + BK < K) gload(k0 + BK);
+        if (k0 + BK < kend) gload(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             double af[FM], bf[FM];
@@ -127,7 +136,15 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int
 int gpbo_gemm_launch(int transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
                      int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double beta, double *C,
                      int64_t ldc, int64_t strideC, int batch, int lower_only, hipStream_t st) {
+    return gpbo_gemm_launch_tri(transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch,
+                                lower_only, 0, st);
+}
+
+int gpbo_gemm_launch_tri(int transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                         int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double beta, double *C,
+                         int64_t ldc, int64_t strideC, int batch, int lower_only, int tri, hipStream_t st) {
     if (M <= 0 || N <= 0 || batch <= 0) return GPBO_OK;
+    if (tri < 0 || tri > 2 || (tri == 1 && (transB || K != N)) || (tri == 2 && K != M)) return GPBO_ERR_ARG;
     if (!A || !B || !C || M % 64 || N % 64 || K % BK || K <= 0 || (lda & 1) || (ldb & 1)) return GPBO_ERR_ARG;
     if (((uintptr_t)A | (uintptr_t)B) & 15) return GPBO_ERR_ARG;
     if (N / 32 > 65535 || M / 32 > 65535 || batch > 65535) return GPBO_ERR_ARG;
@@ -143,7 +160,7 @@ int gpbo_gemm_launch(int transB, int64_t M, int64_t N, int64_t K, double alpha, 
     dim3 grid((unsigned)(N / T), (unsigned)(M / T), (unsigned)batch);
 #define GPBO_GEMM_LAUNCH(TB, TT)                                                                                        \
     hipLaunchKernelGGL((gemm_f64_kernel<TB, TT>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, \
-                       beta, C, ldc, strideC, lower_only)
+                       beta, C, ldc, strideC, lower_only, tri)
     if (transB) {
         if (small) GPBO_GEMM_LAUNCH(1, 32); else GPBO_GEMM_LAUNCH(1, 64);
     } else {
