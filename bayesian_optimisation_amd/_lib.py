@@ -37,6 +37,8 @@ SIGNATURES = {
     "gpbo_factorise_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _f64, _f64, _i64, _p, _p, _p, _p, _p, _i64, _p]),
     "gpbo_select_next_host_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _f64, _f64, _p, _i64, _i32, _f64, _f64, _f64, _i64,
                                             _p, _p, _p, _p, _p, _p]),
+    "gpbo_select_qei_host_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _f64, _f64, _p, _i64, _f64, _f64, _p, _i32, _i64, _p,
+                                           _p, _p]),
     "gpbo_nlml_grid_host_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p]),
     "gpbo_append_workspace_bytes": (_i64, [_i64]),
     "gpbo_append_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _f64, _f64, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),

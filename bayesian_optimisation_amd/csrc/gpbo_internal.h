@@ -65,3 +65,7 @@ int gpbo_potrf_batched(double *Ab, int64_t Ne, int nbf, int batch, double *dinv,
 int gpbo_gemm_launch_tri(int transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
                          int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double beta, double *C,
                          int64_t ldc, int64_t strideC, int batch, int lower_only, int tri, hipStream_t st);
+int gpbo_launch_split_finish(const double *ss_part, int S, int64_t ldk, const double *mu_part, int nsl, int64_t Mc,
+                             double prior_var, int acq_kind, double p0, double p1, int64_t idx_base, double *mu_out,
+                             double *sigma_out, double *acq_out, double *var_out, double *part_val, int64_t *part_idx,
+                             unsigned long long *nan_count, hipStream_t st);

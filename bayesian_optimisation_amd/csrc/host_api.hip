@@ -115,6 +115,59 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
     return GPBO_OK;
 }
 
+// q = 8 Monte-Carlo qEI on host arrays (same conventions as gpbo_select_next_host_f64; Z: [S x 8] base samples)
+extern "C" int gpbo_select_qei_host_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls,
+                                        double jitter1, double jitter2, const double *Xs, int64_t M, double f_best,
+                                        double xi, const double *Z, int32_t S, int64_t chunk, double *qei_out,
+                                        gpbo_result *result, int32_t *info) {
+    if (!X || !y || !ls || !Xs || !Z || !result || !info) return GPBO_ERR_ARG;
+    if (N < 1 || M < 8 || M % 8 || d < 1 || d > GPBO_MAX_D || S < 1) return GPBO_ERR_ARG;
+    if (chunk == 0) chunk = (int64_t)1 << 15;
+    if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
+    for (int k = 0; k < d; ++k)
+        if (!(ls[k] > 0.0)) return GPBO_ERR_ARG;
+    {
+        const int64_t need = (M + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
+        if (chunk > need) chunk = need;
+    }
+    const int64_t Np = gpbo_padded_n(N);
+    const int64_t wfact = gpbo_factorise_workspace_bytes(Np);
+    const int64_t wq = gpbo_qei_workspace_bytes(Np, chunk, M);
+    if (wq < 0) return GPBO_ERR_ARG;
+    DeviceArena A;
+    if (!A.ok) return GPBO_ERR_LAUNCH;
+    double *dX = A.alloc<double>(N * d), *dy = A.alloc<double>(N), *dXs = A.alloc<double>(M * d);
+    double *dZ = A.alloc<double>((int64_t)S * 8);
+    double *dK = A.alloc<double>(Np * Np), *dU = A.alloc<double>(Np * Np), *dalpha = A.alloc<double>(Np);
+    int32_t *dinfo = A.alloc<int32_t>(1);
+    gpbo_result *dres = A.alloc<gpbo_result>(1);
+    char *dwork = A.alloc<char>((wfact > wq ? wfact : wq) + 256);
+    double *dq = qei_out ? A.alloc<double>(M / 8) : nullptr;
+    if (!A.ok) return GPBO_ERR_WORKSPACE;
+    void *st = reinterpret_cast<void *>(A.stream);
+    if (!A.h2d(dX, X, sizeof(double) * N * d) || !A.h2d(dy, y, sizeof(double) * N) ||
+        !A.h2d(dXs, Xs, sizeof(double) * M * d) || !A.h2d(dZ, Z, sizeof(double) * S * 8))
+        return GPBO_ERR_LAUNCH;
+    int rc = gpbo_factorise_f64(dX, dy, N, d, ls, jitter1, jitter2, Np, dK, dU, dalpha, dinfo, dwork, wfact, st);
+    if (rc != GPBO_OK) return rc;
+    if (!A.d2h(info, dinfo, sizeof(int32_t)) || !A.sync()) return GPBO_ERR_LAUNCH;
+    if (*info != 0) {
+        result->best_val = 0.0;
+        result->best_idx = -1;
+        result->nan_count = 0;
+        result->reserved = 0;
+        return GPBO_OK;
+    }
+    const double prior_var = (1.0 + jitter1) + jitter2;
+    rc = gpbo_posterior_qei_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, f_best, xi, dZ, S, 0, chunk, dq, dres,
+                                dwork, wq, st);
+    if (rc != GPBO_OK) return rc;
+    bool okc = A.d2h(result, dres, sizeof(gpbo_result));
+    if (qei_out) okc = okc && A.d2h(qei_out, dq, sizeof(double) * (M / 8));
+    if (!okc || !A.sync()) return GPBO_ERR_LAUNCH;
+    return GPBO_OK;
+}
+
 extern "C" int gpbo_nlml_grid_host_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells,
                                        int64_t G, double jitter, float *out) {
     if (!X || !y || !ls_cells || !out || N < 1 || d < 1 || d > GPBO_MAX_D || G < 1 || G > (1 << 30))

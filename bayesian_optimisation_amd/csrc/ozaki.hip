@@ -218,8 +218,24 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
     const double *__restrict__ mu_part, int nsl, int64_t ldk, int64_t Mc, double prior_var, int acq_kind, double p0,
     double p1, int64_t idx_base, double *__restrict__ mu_out, double *__restrict__ sigma_out,
     double *__restrict__ acq_out, double *__restrict__ var_out, double *__restrict__ part_val,
-    int64_t *__restrict__ part_idx, unsigned long long *__restrict__ nan_count) {
+    int64_t *__restrict__ part_idx, unsigned long long *__restrict__ nan_count, int G, int nblk,
+    double *__restrict__ ss_part /* G > 1: [G x ldk] partial |v|^2 per column group, epilogue in split_finish_kernel */) {
     __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+    // Column groups (G > 1).  One workgroup streams its 128 rows of K* once per column block of V: with a workgroup per
+    // candidate tile and compute unit, 256 such slabs (3 MB each at N = 4096) are live at a time - far beyond the 256-MiB
+    // Infinity Cache, so every re-read comes from HBM (55 GB per 2^17 candidates).  Splitting the column blocks of a tile
+    // over G workgroups keeps 256 / G slabs live (G = 8: 96 MB beside the 100 MB of U slices).  The G workgroups of a tile
+    // get linear ids 8 apart - the same XCD under the round-robin dispatch (speed only) - and column blocks in
+    // boustrophedon rounds (g, 2G-1-g, 2G+g, ...: block jb costs jb + 1 stages, so every group gets the same work).
+    int tile = blockIdx.x, grp = 0;
+    if (G > 1) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int q = slot / G;
+        grp = slot - q * G;
+        tile = q * 8 + xcd;
+        if (tile >= nblk) return;
+    }
+    auto jb_of = [&](int r) { return r * G + ((r & 1) ? (G - 1 - grp) : grp); };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -233,11 +249,11 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
 #ifdef GPBO_I8_DIAG_SAME_A  // timing-only diagnostic (wrong results): every workgroup streams the same K* rows (L2 hits)
     const char *a0p = A8;
 #else
-    const char *a0p = A8 + ((int64_t)blockIdx.x * (BM / 32) * NS) * FRAG;  // k block 0 of this workgroup's row tiles
+    const char *a0p = A8 + ((int64_t)tile * (BM / 32) * NS) * FRAG;  // k block 0 of this workgroup's row tiles
 #endif
     const int64_t a_step = RT * NS * FRAG, b_step = (int64_t)CT * NS * FRAG;
-    const char *pa = a0p, *pb = U8;
-    int pj = 0, pk = 0, pbuf = 0;
+    int pr = 0, pj = jb_of(0), pk = 0, pbuf = 0;
+    const char *pa = a0p, *pb = U8 + ((int64_t)pj * (BN / 32) * NS) * FRAG;
     auto stage_next = [&]() {
         char *St = smem + pbuf * STAGE;
 #pragma unroll
@@ -246,7 +262,7 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
         for (int r = 0; r < 3; ++r) glds16b(pb + (wid + 8 * r) * FRAG + lane16, St + HALF_STAGE + (wid + 8 * r) * FRAG);
         pbuf = (pbuf == 2) ? 0 : pbuf + 1;
         if (++pk == (pj + 1) * (BN / BK)) {
-            ++pj;
+            pj = jb_of(++pr);
             pk = 0;
             pa = a0p;
             pb = U8 + ((int64_t)pj * (BN / 32) * NS) * FRAG;
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
         da = pa; db = pb; dbuf = pbuf;
         pbuf = (pbuf == 2) ? 0 : pbuf + 1;
         if (++pk == (pj + 1) * (BN / BK)) {
-            ++pj;
+            pj = jb_of(++pr);
             pk = 0;
             pa = a0p;
             pb = U8 + ((int64_t)pj * (BN / 32) * NS) * FRAG;
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
 #undef MM
 #undef SB
 
-    for (int jb = 0; jb < nJ; ++jb) {
+    for (int rr = 0, jb = jb_of(0); jb < nJ; jb = jb_of(++rr)) {
         const int ct = jb * (BN / 32) + wq;        // this wave's 32-column tile of V
         const int nkb = (jb + 1) * (BN / BK);
         for (int kb = 0; kb < nkb; ++kb) stage_body(kb <= ct);  // U is upper triangular: k tiles below the diagonal are zero
@@ -433,10 +449,16 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
         red[wq * BM + row] = ssrow;
     }
     __syncthreads();
+    if (ss_part) {  // (kernel-argument uniform) column-group launch: partial sums only
+        if (tid < BM)
+            ss_part[(int64_t)grp * ldk + (int64_t)tile * BM + tid] =
+                ((red[tid] + red[BM + tid]) + red[2 * BM + tid]) + red[3 * BM + tid];
+        return;
+    }
     double *s_val = red + 4 * BM;
     int64_t *s_idx = reinterpret_cast<int64_t *>(red + 4 * BM + 4);
     if (tid < BM) {
-        const int64_t c = (int64_t)blockIdx.x * BM + tid;
+        const int64_t c = (int64_t)tile * BM + tid;
         const bool valid = c < Mc;
         const double ssq = ((red[tid] + red[BM + tid]) + red[2 * BM + tid]) + red[3 * BM + tid];
         double mu = 0.0;
@@ -468,21 +490,34 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
         double bv = s_val[0];
         int64_t bi = s_idx[0];
         if (gpbo_better(s_val[1], s_idx[1], bv, bi)) { bv = s_val[1]; bi = s_idx[1]; }
-        part_val[blockIdx.x] = bv;
-        part_idx[blockIdx.x] = bi;
+        part_val[tile] = bv;
+        part_idx[tile] = bi;
     }
 }
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct LayoutI8 {
-    int64_t a8_off, mup_off, xsc_off, pval_off, pidx_off, nan_off, total, nparts_cap;
+    int64_t a8_off, mup_off, xsc_off, pval_off, pidx_off, nan_off, ssp_off, total, nparts_cap;
 };
+
+#ifndef GPBO_I8_G
+#define GPBO_I8_G 8
+#endif
+constexpr int I8_GROUPS_MAX = 16;
+
+// column groups per candidate tile: none for short problems (few column blocks: the fused epilogue is worth more)
+int i8_groups(int64_t Np) {
+    const int64_t nJ = Np / BN;
+    if (nJ < 16) return 1;
+    return (GPBO_I8_G <= nJ / 2) ? GPBO_I8_G : (int)(nJ / 2);
+}
 
 LayoutI8 layout_i8(int64_t Np, int64_t chunk, int64_t M) {
     LayoutI8 L;
     const int64_t nchunks = (M + chunk - 1) / chunk;
-    L.nparts_cap = nchunks * (chunk / BM);
+    L.nparts_cap = nchunks * ((chunk + 255) / 256);   // partials of the 128-row fused epilogue or the 256-row split one
+    if (L.nparts_cap < nchunks * (chunk / BM)) L.nparts_cap = nchunks * (chunk / BM);
     int64_t off = 0;
     L.a8_off = off; off += align_up(Np * chunk * NS, 256);
     L.mup_off = off; off += align_up((int64_t)sizeof(double) * (Np / KS_SLICE) * chunk, 256);
@@ -490,6 +525,7 @@ LayoutI8 layout_i8(int64_t Np, int64_t chunk, int64_t M) {
     L.pval_off = off; off += align_up((int64_t)sizeof(double) * L.nparts_cap, 256);
     L.pidx_off = off; off += align_up((int64_t)sizeof(int64_t) * L.nparts_cap, 256);
     L.nan_off = off; off += 256;
+    L.ssp_off = off; off += align_up((int64_t)sizeof(double) * I8_GROUPS_MAX * chunk, 256);
     L.total = off;
     return L;
 }
@@ -587,11 +623,28 @@ extern "C" int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *
         const int64_t nblk = (Mc + BM - 1) / BM;
         if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
-        hipLaunchKernelGGL(sigma_i8_kernel, dim3((unsigned)nblk), dim3(512), 0, st, A8, RT, U8, (int)Np, colscale, mu_part,
-                           (int)(Np / KS_SLICE), chunk, Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
-                           mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
-                           acq_out ? acq_out + s : nullptr, var_out ? var_out + s : nullptr, part_val + nparts,
-                           part_idx + nparts, nan_count);
+        const int G = i8_groups(Np);
+        int64_t nparts_here = nblk;
+        if (G > 1) {
+            double *ss_part = reinterpret_cast<double *>(w + L.ssp_off);
+            const int64_t grid = (nblk + 7) / 8 * 8 * G;
+            hipLaunchKernelGGL(sigma_i8_kernel, dim3((unsigned)grid), dim3(512), 0, st, A8, RT, U8, (int)Np, colscale, mu_part,
+                               (int)(Np / KS_SLICE), chunk, Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
+                               (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, part_val + nparts,
+                               part_idx + nparts, nan_count, G, (int)nblk, ss_part);
+            nparts_here = (Mc + 255) / 256;
+            int rc2 = gpbo_launch_split_finish(ss_part, G, chunk, mu_part, (int)(Np / KS_SLICE), Mc, prior_var, acq_kind, p0, p1,
+                                               idx_offset + s, mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
+                                               acq_out ? acq_out + s : nullptr, var_out ? var_out + s : nullptr,
+                                               part_val + nparts, part_idx + nparts, nan_count, st);
+            if (rc2 != GPBO_OK) return rc2;
+        } else {
+            hipLaunchKernelGGL(sigma_i8_kernel, dim3((unsigned)nblk), dim3(512), 0, st, A8, RT, U8, (int)Np, colscale, mu_part,
+                               (int)(Np / KS_SLICE), chunk, Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
+                               mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
+                               acq_out ? acq_out + s : nullptr, var_out ? var_out + s : nullptr, part_val + nparts,
+                               part_idx + nparts, nan_count, 1, (int)nblk, (double *)nullptr);
+        }
         if (rec) {
             if (hipEventRecord(reinterpret_cast<hipEvent_t>(prof->end[prof->count]), st) != hipSuccess)
                 return GPBO_ERR_LAUNCH;
@@ -600,7 +653,7 @@ extern "C" int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *
         }
         prev_recorded = rec;
         GPBO_CHECK_LAUNCH();
-        nparts += nblk;
+        nparts += nparts_here;
     }
     return gpbo_launch_argmax_finish(part_val, part_idx, nparts, nan_count, result, st);
 }

@@ -359,6 +359,7 @@ __global__ __launch_bounds__(256) void split_finish_kernel(const double *__restr
                                                            double prior_var, int acq_kind, double p0, double p1,
                                                            int64_t idx_base, double *__restrict__ mu_out,
                                                            double *__restrict__ sigma_out, double *__restrict__ acq_out,
+                                                           double *__restrict__ var_out,
                                                            double *__restrict__ part_val, int64_t *__restrict__ part_idx,
                                                            unsigned long long *__restrict__ nan_count) {
     __shared__ double s_val[4];
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(256) void split_finish_kernel(const double *__restr
         if (mu_out) mu_out[c] = mu;
         if (sigma_out) sigma_out[c] = sigma;
         if (acq_out) acq_out[c] = acq;
+        if (var_out) var_out[c] = var;
     }
     const bool is_nan = valid && (acq != acq);
     const unsigned long long nan_mask = __ballot(is_nan);
@@ -658,6 +660,17 @@ QeiLayout qei_layout(int64_t Np, int64_t chunk, int64_t M) {
 
 }  // namespace
 
+int gpbo_launch_split_finish(const double *ss_part, int S, int64_t ldk, const double *mu_part, int nsl, int64_t Mc,
+                             double prior_var, int acq_kind, double p0, double p1, int64_t idx_base, double *mu_out,
+                             double *sigma_out, double *acq_out, double *var_out, double *part_val, int64_t *part_idx,
+                             unsigned long long *nan_count, hipStream_t st) {
+    const int64_t nb = (Mc + 255) / 256;
+    hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, ss_part, S, ldk, mu_part, nsl, Mc, prior_var,
+                       acq_kind, p0, p1, idx_base, mu_out, sigma_out, acq_out, var_out, part_val, part_idx, nan_count);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
 int gpbo_launch_argmax_finish(const double *part_val, const int64_t *part_idx, int64_t nparts,
                               const unsigned long long *nan_count, gpbo_result *result, hipStream_t st) {
     hipLaunchKernelGGL(argmax_finish_kernel, dim3(1), dim3(256), 0, st, part_val, part_idx, nparts, nan_count, result);
@@ -790,7 +803,8 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
             hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, S, chunk, mu_part[b],
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                                mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
-                               acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count);
+                               acq_out ? acq_out + s : nullptr, (double *)nullptr, part_val + nparts, part_idx + nparts,
+                               nan_count);
         } else {
 #define GPBO_SIGMA_LAUNCH(V)                                                                                        \
     hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT[b], chunk, U, (int)Np,          \

@@ -6,7 +6,7 @@ This is the ctypes stub a maintainer of the reference would write against includ
 `acq_func_eval` and the selected index come back.  Every call allocates and frees its device buffers inside the
 library, which costs a few milliseconds per step against the tensor-resident `PointSelector`; the numbers are the
 same (same kernels).  Not available here: candidate sharding over several GPUs, the incremental factorisation,
-fp32 scoring, q-EI - those need the device-pointer API behind `PointSelector`.
+fp32 / int8 screening - those need the device-pointer API behind `PointSelector`.
 A process that uses both this binding and the PyTorch-based classes must `import torch` before its first call here
 (bringing PyTorch's GPU context up after this library has initialised HIP was seen to dead-lock now and then; the
 PyTorch-based classes refuse that order with a clear error).
@@ -139,5 +139,31 @@ class PointSelectorHost(PointSelector):
             raise IndexError("index 0 is out of bounds for axis 0 with size 0 (acquisition contains NaN)")
         return np.array(np.unravel_index(best_idx, fd), dtype=np.int64)
 
-    def q_expected_improvement(self, *a, **kw):
-        raise NotImplementedError("q-EI needs the device-pointer API: use bayesian_optimisation_amd.PointSelector")
+    def q_expected_improvement(self, n_samples=512, seed=7, xi=0.0):
+        """q = 8 Monte-Carlo Expected Improvement on the host-pointer route (same definition and return value as
+        PointSelector.q_expected_improvement: the (8, ndim) multi-indices of the first batch with the largest qEI)."""
+        if self._inputs is None:
+            raise RuntimeError("call update_surrogate() first")
+        X, y, ls, Xs = self._inputs
+        fd = [int(v) for v in self.feature_domain]
+        M = int(np.prod(fd))
+        if M % 8:
+            raise ValueError("q_expected_improvement needs a candidate count that is a multiple of 8")
+        Z = _f64(np.random.default_rng(seed).standard_normal((int(n_samples), 8)))
+        X, y, Xs, ls = _f64(X), _f64(y).reshape(-1), _f64(Xs), _f64(np.asarray(ls, dtype=np.float64).reshape(-1))
+        qei = np.empty(M // 8)
+        res = (C.c_int64 * 4)()
+        info = C.c_int32(0)
+        _lib.note_hip_use()
+        st = self.lib.gpbo_select_qei_host_f64(_ptr(X), _ptr(y), X.shape[0], X.shape[1], _ptr(ls), JITTER_KERNEL,
+                                               JITTER_ASSEMBLY, _ptr(Xs), M, float(np.min(y)), float(xi), _ptr(Z),
+                                               int(n_samples), self._chunk, _ptr(qei), C.cast(res, C.c_void_p),
+                                               C.cast(C.pointer(info), C.c_void_p))
+        _lib.check(st, "gpbo_select_qei_host_f64")
+        if info.value != 0:
+            raise np.linalg.LinAlgError(f"covariance matrix is not positive definite (pivot {info.value} of {len(X)})")
+        self.acq_func_eval = qei
+        if int(res[2]) > 0 or int(res[1]) >= M // 8 or int(res[1]) < 0:
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0 (acquisition contains NaN)")
+        flat = int(res[1]) * 8 + np.arange(8)
+        return np.stack(np.unravel_index(flat, fd), axis=1).astype(np.int64)

@@ -244,6 +244,12 @@ int gpbo_select_next_host_f64(const double *X_host, const double *y_host, int64_
                               double p0, double p1, double diag_add, int64_t chunk, double *mu_out_host,
                               double *sigma_out_host, double *acq_out_host, double *cov_meas_out_host,
                               gpbo_result *result_host, int32_t *info_host);
+/* q = 8 Monte-Carlo qEI on host arrays (gpbo_posterior_qei_f64 behind the same device handling): Z_host [S x 8] base
+ * samples, M a multiple of 8; qei_out_host optional [M/8]; result->best_idx = first batch with the largest qEI. */
+int gpbo_select_qei_host_f64(const double *X_host, const double *y_host, int64_t N, int32_t d, const double *ls_host,
+                             double jitter1, double jitter2, const double *Xs_host, int64_t M, double f_best, double xi,
+                             const double *Z_host, int32_t S, int64_t chunk, double *qei_out_host,
+                             gpbo_result *result_host, int32_t *info_host);
 int gpbo_nlml_grid_host_f64(const double *X_host, const double *y_host, int64_t N, int32_t d,
                             const double *ls_cells_host, int64_t G, double jitter, float *out_host);
 

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 import torch  # noqa: E402,F401  (this process mixes both routes: PyTorch first, see test_mixing_...)
 
-from bayesian_optimisation_amd import DeviceGP  # noqa: E402
+from bayesian_optimisation_amd import DeviceGP, PointSelector  # noqa: E402
 from bayesian_optimisation_amd import host_binding as H  # noqa: E402
 from bayesian_optimisation_amd.synthetic import make_problem  # noqa: E402
 from oracle import gp_oracle as O  # noqa: E402
@@ -182,3 +182,18 @@ def test_mixing_host_binding_and_pytorch_in_one_process():
     out = subprocess.run([sys.executable, "-c", refused], capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().endswith("refused")
+
+
+def test_host_binding_q_expected_improvement_matches_the_tensor_resident_class():
+    X, y, Xs, ls = make_problem(30, 1600, 2)
+    out = []
+    for cls in (H.PointSelectorHost, PointSelector):
+        ps = cls()
+        ps.measured_pts, ps.measured_vals = X, y
+        ps.feature_domain, ps.predicted_pts = [40, 40], Xs
+        ps.set_kernel_params(ls)
+        ps.update_surrogate()
+        out.append((ps.q_expected_improvement(n_samples=256, seed=7), ps.acq_func_eval.copy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    ref = O.qei_mc(X, y, Xs, ls, O.qei_base_samples(256, 8, 7), float(np.min(y)))
+    np.testing.assert_allclose(out[0][1], ref, rtol=0, atol=1e-9)

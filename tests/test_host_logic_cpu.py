@@ -89,8 +89,8 @@ def test_host_binding_checks_shapes_before_touching_the_device():
 def test_precision_and_q_ei_argument_checks():
     with pytest.raises(ValueError):
         PointSelector(precision="fp16")
-    with pytest.raises(NotImplementedError):
-        H.PointSelectorHost().q_expected_improvement()
+    with pytest.raises(RuntimeError):
+        H.PointSelectorHost().q_expected_improvement()                   # before update_surrogate()
     ps = PointSelector()
     with pytest.raises(RuntimeError):
         ps.lower_confidence_bound()                                      # before update_surrogate()
