@@ -4,25 +4,32 @@
 // but the N^2 multiply-adds per candidate run on v_mfma_i32_32x32x32_i8 (64x the fp64 MFMA rate per clock) instead of
 // v_mfma_f64_16x16x4_f64.
 //
-// Splitting.  k in [0, 1] and the column-scaled U_ij 2^-e_j in [-1, 1] are rounded ONCE to 47-bit fixed point,
-//     T = rint(x 2^46),  |T| <= 2^46,
-// and T is written in balanced base-256 digits  T = sum_a D_a 256^(5-a),  D_a in [-128, 127]  (six int8 slices; the
-// digits come out of T + 0x8080808080 byte by byte, xor 0x80).  Then
+// Splitting.  k in [0, 1] and the column-scaled U_ij 2^-e_j in [-1, 1] are rounded ONCE to fixed point,
+//     T_k = rint(k 2^38)  (five digits),      T_u = rint(U_ij 2^-e_j 2^46)  (six digits),
+// and written in balanced base-256 digits  T = sum_a D_a 256^(n-1-a),  D_a in [-128, 127]  (int8 slices; the digits come
+// out of T + 0x80..80 byte by byte, xor 0x80).  Digit a of either operand has weight 2^(-6-8a), so
 //     v_j = 2^e_j sum_{a,b} 2^(-12 - 8(a+b)) (K_a U_b)_j
 // where every K_a U_b is an EXACT integer (|sum| <= N 2^14 < 2^31 for N <= 16384: int32 accumulators).  The digit
 // pairs are accumulated per diagonal g = a + b (six int32 accumulator sets) and pairs with a + b > 5 are dropped:
-// 21 of the 36 slice products.  Error (tools/ozaki_error.py, the benchmark problem): the dropped diagonals and the two
-// 2^-47 roundings leave |dv_j| <= 1.6e-10 and |dsigma| <= 1.3e-10 at N = 4096 (fp64 MFMA path: 1.3e-13); everything
-// after the two roundings is exact integer arithmetic, so the result does not depend on tile shapes or summation order.
+// 20 slice products (a sixth digit of K* would only meet U's first: pair (5,0), below the other dropped terms).
+// Error (tools/ozaki_error.py, the benchmark problem, "sk=5 su=6 keep=6"): the dropped diagonals and the two roundings
+// leave |dv_j| <= 2.7e-10 and |dsigma| <= 1.7e-10 at N = 4096 (fp64 MFMA path: 1.3e-13); with five digits of U as well
+// (19 products) it would be 1.8e-9, with 15 products 2e-8.  Everything after the two roundings is exact integer
+// arithmetic, so the result does not depend on tile shapes, chunking or summation order.
 // The arg-max is still decided in fp64 (rescore.hip) - this pass is a screen with a 1e-10-accurate variance.
 //
 // Geometry.  Operands live in HBM as ready-made MFMA fragments: 1-KiB blocks [32 rows x 32 k] in lane order (lane l =
 // row l & 31, k half l >> 5, 16 consecutive k per lane), indexed [k block][row tile][slice].  A stage (32 k) of a
-// 128 x 128 block tile is two contiguous 24-KiB pieces (4 row tiles x 6 slices of K*, 4 column tiles x 6 slices of U):
-// 48 LDS-DMA instructions, fragments land in LDS exactly as ds_read_b128 will fetch them (no bank conflicts, no
-// repacking).  Workgroup = 512 threads = 8 waves as 2 (candidates) x 4 (columns): wave tile 64 x 32 = two 32 x 32 MFMA
-// tiles x 6 diagonals = 192 accumulator registers; 42 MFMAs per wave and stage; three-stage LDS ring (144 KiB), one
-// barrier in the middle of each stage (same protocol as sigma_acq.hip).
+// 128 x 128 block tile is two contiguous pieces (4 row tiles x 5 slices of K* = 20 KiB, 4 column tiles x 6 slices of
+// U = 24 KiB): 44 LDS-DMA instructions, fragments land in LDS exactly as ds_read_b128 will fetch them (no bank
+// conflicts, no repacking).  Workgroup = 512 threads = 8 waves as 2 (candidates) x 4 (columns): wave tile 64 x 32 = two
+// 32 x 32 MFMA tiles x 6 diagonals = 192 accumulator registers; 40 MFMAs per wave and stage; three-stage LDS ring
+// (132 KiB), one barrier per stage.
+//
+// What bounds it (MI355X, N = 4096, PMC passes in profiles/): the matrix pipes are 68 % busy; the rest is waiting for
+// operands - 44 KiB per stage and compute unit is 12 B/clk/CU of L2 -> LDS traffic (5.8 TB/s chip-wide, 75 % L2 hits),
+// the per-CU delivery rate of this access pattern.  Removing work from the MFMA stream no longer helps (21 -> 20
+// products: -0.5 %), removing bytes does (column groups, below: -9 %).
 #include "gpbo_internal.h"
 
 #include <limits>
@@ -34,14 +41,18 @@ typedef int i16_t __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-constexpr int NS = 6;                      // int8 slices per operand
+constexpr int NS = 6;                      // int8 slices of U = diagonals a + b kept (int32 accumulator sets)
+constexpr int NSA = 5;                     // int8 slices of K*: its sixth digit would only meet U's first (pair (5,0), dropped)
 constexpr int BM = 128, BN = 128, BK = 32;  // candidates x columns of V per workgroup, k depth of a stage
 constexpr int FRAG = 1024;                 // bytes of one 32 x 32 int8 fragment
-constexpr int HALF_STAGE = (BM / 32) * NS * FRAG;  // 24 KiB: the K* part (= the U part) of a stage
-constexpr int STAGE = 2 * HALF_STAGE;      // 48 KiB
+constexpr int A_STAGE = (BM / 32) * NSA * FRAG;  // 20 KiB: the K* part of a stage
+constexpr int B_STAGE = (BN / 32) * NS * FRAG;   // 24 KiB: the U part
+constexpr int STAGE = A_STAGE + B_STAGE;   // 44 KiB
+constexpr int A_PIECES = A_STAGE / FRAG, PIECES = STAGE / FRAG;  // 20 + 24 DMA pieces per stage: 6 for waves 0-3, 5 for 4-7
 constexpr int KS_SLICE = GPBO_KS_SLICE;    // observations per mu_part slice (64)
 constexpr double MAGIC = 6755399441055744.0;  // 1.5 2^52: x + MAGIC has rint(x) in its low mantissa bits
 constexpr double TWO46 = 70368744177664.0;
+constexpr double TWO38 = 274877906944.0;
 
 struct LsArgsI8 {
     double isc[GPBO_MAX_D];  // 1 / (ls_k sqrt 2)
@@ -105,6 +116,29 @@ __device__ __forceinline__ void digits4(const double (&z)[4], unsigned (&P)[NS])
     P[2] = __builtin_amdgcn_perm(u23, u01, 0x07060302u) ^ 0x80808080u;
     P[1] = __builtin_amdgcn_perm(h23, h01, 0x05040100u) ^ 0x80808080u;
     P[0] = __builtin_amdgcn_perm(h23, h01, 0x07060302u);                // top digit: plain two's complement byte
+}
+
+// Five digits (K*): z[q] = k_q 2^38 + MAGIC, T < 2^39, T' = T + 0x80808080; P[0] = top digit (plain), P[1..4] below it.
+__device__ __forceinline__ void digits4_k(const double (&z)[4], unsigned (&P)[NSA]) {
+    unsigned lo[4], hi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned l = (unsigned)__double2loint(z[q]);
+        const unsigned h = (unsigned)__double2hiint(z[q]) - 0x43380000u;
+        lo[q] = l + 0x80808080u;
+        hi[q] = h + (lo[q] < l ? 1u : 0u);
+    }
+    const unsigned t01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400u);
+    const unsigned t23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400u);
+    const unsigned u01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602u);
+    const unsigned u23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602u);
+    const unsigned h01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u);
+    const unsigned h23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400u);
+    P[4] = __builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u;
+    P[3] = __builtin_amdgcn_perm(t23, t01, 0x07060302u) ^ 0x80808080u;
+    P[2] = __builtin_amdgcn_perm(u23, u01, 0x05040100u) ^ 0x80808080u;
+    P[1] = __builtin_amdgcn_perm(u23, u01, 0x07060302u) ^ 0x80808080u;
+    P[0] = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
 }
 
 // ---- U -> column scales and int8 fragments (once per factorisation) ---------------------------------------------------
@@ -174,7 +208,7 @@ __global__ __launch_bounds__(256) void kstar_slices_kernel(const double *__restr
 #pragma unroll 1
     for (int g16 = 0; g16 < KS_SLICE / 16; ++g16) {
         const int n0 = nb + g16 * 16;
-        unsigned out[NS][4];
+        unsigned out[NSA][4];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             double z[4];
@@ -193,17 +227,17 @@ __global__ __launch_bounds__(256) void kstar_slices_kernel(const double *__restr
                     kv = exp_neg_i8(s, tab);
                     mu = fma(kv, alpha[n], mu);
                 }
-                z[q] = fma(kv, TWO46, MAGIC);
+                z[q] = fma(kv, TWO38, MAGIC);
             }
-            unsigned P[NS];
-            digits4(z, P);
+            unsigned P[NSA];
+            digits4_k(z, P);
 #pragma unroll
-            for (int a = 0; a < NS; ++a) out[a][q4] = P[a];
+            for (int a = 0; a < NSA; ++a) out[a][q4] = P[a];
         }
         const int kb = n0 >> 5, kg = (n0 >> 4) & 1;
-        char *base = A8 + (((int64_t)kb * RT + (c >> 5)) * NS) * FRAG + kg * 512 + (int)(c & 31) * 16;
+        char *base = A8 + (((int64_t)kb * RT + (c >> 5)) * NSA) * FRAG + kg * 512 + (int)(c & 31) * 16;
 #pragma unroll
-        for (int a = 0; a < NS; ++a) {
+        for (int a = 0; a < NSA; ++a) {
             const i4_t v = {(int)out[a][0], (int)out[a][1], (int)out[a][2], (int)out[a][3]};
             if (NT) __builtin_nontemporal_store(v, reinterpret_cast<i4_t *>(base + a * FRAG));
             else *reinterpret_cast<i4_t *>(base + a * FRAG) = v;
@@ -249,17 +283,21 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
 #ifdef GPBO_I8_DIAG_SAME_A  // timing-only diagnostic (wrong results): every workgroup streams the same K* rows (L2 hits)
     const char *a0p = A8;
 #else
-    const char *a0p = A8 + ((int64_t)tile * (BM / 32) * NS) * FRAG;  // k block 0 of this workgroup's row tiles
+    const char *a0p = A8 + ((int64_t)tile * (BM / 32) * NSA) * FRAG;  // k block 0 of this workgroup's row tiles
 #endif
-    const int64_t a_step = RT * NS * FRAG, b_step = (int64_t)CT * NS * FRAG;
+    const int64_t a_step = RT * NSA * FRAG, b_step = (int64_t)CT * NS * FRAG;
     int pr = 0, pj = jb_of(0), pk = 0, pbuf = 0;
     const char *pa = a0p, *pb = U8 + ((int64_t)pj * (BN / 32) * NS) * FRAG;
+    // one DMA piece of a stage: piece p = wid + 8 q of the 44 (20 of K*, then 24 of U; the LDS image is the same order)
+    auto piece = [&](const char *ga, const char *gb, int buf, int q) {
+        const int p = wid + 8 * q;
+        char *dst = smem + buf * STAGE + p * FRAG;
+        if (p < A_PIECES) glds16b(ga + p * FRAG + lane16, dst);
+        else if (p < PIECES) glds16b(gb + (p - A_PIECES) * FRAG + lane16, dst);
+    };
     auto stage_next = [&]() {
-        char *St = smem + pbuf * STAGE;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) glds16b(pa + (wid + 8 * r) * FRAG + lane16, St + (wid + 8 * r) * FRAG);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) glds16b(pb + (wid + 8 * r) * FRAG + lane16, St + HALF_STAGE + (wid + 8 * r) * FRAG);
+        for (int q = 0; q < 6; ++q) piece(pa, pb, pbuf, q);
         pbuf = (pbuf == 2) ? 0 : pbuf + 1;
         if (++pk == (pj + 1) * (BN / BK)) {
             pj = jb_of(++pr);
@@ -282,21 +320,29 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
     double ssrow = 0.0;  // |v|^2 of ONE row of this wave's tile (which row: see the butterfly below)
 
     // ---- software pipeline ---------------------------------------------------------------------------------------
-    // Slice pairs of a stage in row order: M(i) = { K*_i x U_j : j <= 5 - i }, i = 0..5 (12, 10, 8, 6, 4, 2 MFMAs).
-    // LDS ring, three stages, ONE barrier per stage, placed before M(4):
-    //   before it  every wave has all its LDS operands of stage t in registers (K* slices 4 and 5 are fetched early) and
+    // Slice pairs of a stage in row order: M(i) = { K*_i x U_j : j <= 5 - i }, i = 0..4 (12, 10, 8, 6, 4 MFMAs: 20 pairs).
+    // LDS ring, three stages, ONE barrier per stage, placed before M(3):
+    //   before it  every wave has all its LDS operands of stage t in registers (K* slices 3 and 4 are fetched early) and
     //              has waited for its own DMA pieces of stage t+1 (issued a whole stage earlier; the pieces of stage
-    //              t+2 may still be in flight: counted vmcnt);
-    //   after it   stage t+1 is complete for everyone, so its first operands are fetched under the cover of M(4), M(5)
+    //              t+2 may still be in flight: counted vmcnt, 6 pieces for waves 0-3, 5 for waves 4-7);
+    //   after it   stage t+1 is complete for everyone, so its first operands are fetched under the cover of M(3), M(4)
     //              of stage t - the matrix pipe does not drain at a stage boundary - and the buffer of stage t is free:
     //              it takes the DMA of stage t+3, which the two waves of a SIMD issue at different times (waves 0-3
-    //              inside M(0), waves 4-7 inside M(2) of the next stage), one piece after every second MFMA.
+    //              inside M(0), waves 4-7 inside M(1) / M(2) of the next stage), one piece after every second MFMA.
+    const bool early = wid < 4;  // which of the two waves of a SIMD issues its DMA pieces first (and has 6, not 5)
+    auto wait_own = [&](int stages_left_in_flight) {  // own pieces of all but the youngest `stages_left_in_flight` stages
+        if (stages_left_in_flight >= 1) {
+            if (early) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+    };
     int inflight = 0;  // stages issued and not yet waited for
     stage_next();
     ++inflight;
     if (pj < nJ) { stage_next(); ++inflight; }
-    if (inflight == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_own(inflight - 1);
     --inflight;
     __builtin_amdgcn_s_barrier();
     bool dma_due = pj < nJ;   // a stage is waiting to be issued into the free buffer (stage 2 into buffer 2 at first)
@@ -304,21 +350,16 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
     int cur = 0;
     i4_t b[NS], a0[2];       // U slices of the current stage, K* slice 0 of the current stage (both row tiles)
     auto lds_a = [&](i4_t (&dst)[2], int buf, int i) {
-        const char *As = smem + buf * STAGE + (2 * wr) * NS * FRAG + lane16;
+        const char *As = smem + buf * STAGE + (2 * wr) * NSA * FRAG + lane16;
         dst[0] = *reinterpret_cast<const i4_t *>(As + i * FRAG);
-        dst[1] = *reinterpret_cast<const i4_t *>(As + (NS + i) * FRAG);
+        dst[1] = *reinterpret_cast<const i4_t *>(As + (NSA + i) * FRAG);
     };
     auto lds_b = [&](int buf, int j) {
-        b[j] = *reinterpret_cast<const i4_t *>(smem + buf * STAGE + HALF_STAGE + (wq * NS + j) * FRAG + lane16);
+        b[j] = *reinterpret_cast<const i4_t *>(smem + buf * STAGE + A_STAGE + (wq * NS + j) * FRAG + lane16);
     };
-    // one DMA piece of the pending stage (wave-uniform piece index q = 0..5: 3 of K*, 3 of U)
     const char *da = pa, *db = pb;   // sources of the stage being issued piecewise
     int dbuf = pbuf;
-    auto dma_piece = [&](int q) {
-        char *St = smem + dbuf * STAGE;
-        if (q < 3) glds16b(da + (wid + 8 * q) * FRAG + lane16, St + (wid + 8 * q) * FRAG);
-        else glds16b(db + (wid + 8 * (q - 3)) * FRAG + lane16, St + HALF_STAGE + (wid + 8 * (q - 3)) * FRAG);
-    };
+    auto dma_piece = [&](int q) { piece(da, db, dbuf, q); };
     auto dma_begin = [&]() {  // latch the sources of the next stage and advance the iterator
         da = pa; db = pb; dbuf = pbuf;
         pbuf = (pbuf == 2) ? 0 : pbuf + 1;
@@ -336,7 +377,6 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
     for (int j = 0; j < NS; ++j) lds_b(0, j);
     lds_a(a0, 0, 0);
 
-    const bool early = wid < 4;  // which of the two waves of a SIMD issues its DMA pieces first
 #define MM(av, i, j)                                                                                         \
     do {                                                                                                     \
         acc[(i) + (j)][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0], b[j], acc[(i) + (j)][0], 0, 0, 0); \
@@ -345,7 +385,7 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
 #define SB() __builtin_amdgcn_sched_barrier(0)
     auto stage_body = [&](bool active) {
         const int nxt = (cur == 2) ? 0 : cur + 1;
-        i4_t a1[2], a2[2], a3[2], a4[2], a5[2];
+        i4_t a1[2], a2[2], a3[2], a4[2];
         const bool issue_now = dma_due;
         if (issue_now) dma_begin();
         SB();
@@ -360,39 +400,36 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
         if (active) { MM(a0, 0, 0); } SB(); if (issue_now && early) dma_piece(5); SB();
         lds_a(a2, cur, 2);
         SB();
-        if (active) { MM(a1, 1, 0); MM(a1, 1, 1); MM(a1, 1, 2); MM(a1, 1, 3); MM(a1, 1, 4); }
+        if (active) { MM(a1, 1, 0); } SB(); if (issue_now && !early) dma_piece(0); SB();
+        if (active) { MM(a1, 1, 1); } SB(); if (issue_now && !early) dma_piece(1); SB();
+        if (active) { MM(a1, 1, 2); } SB(); if (issue_now && !early) dma_piece(2); SB();
+        if (active) { MM(a1, 1, 3); } SB(); if (issue_now && !early) dma_piece(3); SB();
+        if (active) { MM(a1, 1, 4); }
         SB();
         lds_a(a3, cur, 3);
-        SB();
-        if (active) { MM(a2, 2, 0); } SB(); if (issue_now && !early) dma_piece(0); SB();
-        if (active) { MM(a2, 2, 1); } SB(); if (issue_now && !early) dma_piece(1); SB();
-        if (active) { MM(a2, 2, 2); } SB(); if (issue_now && !early) dma_piece(2); SB();
-        if (active) { MM(a2, 2, 3); } SB(); if (issue_now && !early) dma_piece(3); SB();
         lds_a(a4, cur, 4);
-        lds_a(a5, cur, 5);
         SB();
-        if (active) { MM(a3, 3, 0); } SB(); if (issue_now && !early) dma_piece(4); SB();
-        if (active) { MM(a3, 3, 1); } SB(); if (issue_now && !early) dma_piece(5); SB();
-        if (active) { MM(a3, 3, 2); }
+        if (active) { MM(a2, 2, 0); } SB(); if (issue_now && !early) dma_piece(4); SB();
+        if (active) { MM(a2, 2, 1); MM(a2, 2, 2); MM(a2, 2, 3); }
         SB();
         if (issue_now) ++inflight;
         // all LDS operands of this stage are in registers; own pieces of the next stage have landed
-        if (inflight >= 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        wait_own(inflight - 1);
         if (inflight > 0) --inflight;
         __builtin_amdgcn_s_barrier();
         dma_due = pj < nJ;   // the buffer of this stage is free from here on
         SB();
-        // next stage's operands under the cover of M(4), M(5); registers of dead U slices are reused as they die
-        lds_b(nxt, 5); lds_b(nxt, 4); lds_b(nxt, 3); lds_b(nxt, 2);
+        // next stage's operands under the cover of M(3), M(4); registers of dead U slices are reused as they die
+        lds_b(nxt, 5); lds_b(nxt, 4); lds_b(nxt, 3);
+        lds_a(a0, nxt, 0);
+        SB();
+        if (active) { MM(a3, 3, 0); MM(a3, 3, 1); MM(a3, 3, 2); }
+        SB();
+        lds_b(nxt, 2);
         SB();
         if (active) { MM(a4, 4, 0); MM(a4, 4, 1); }
         SB();
         lds_b(nxt, 1);
-        lds_a(a0, nxt, 0);
-        SB();
-        if (active) { MM(a5, 5, 0); }
-        SB();
         lds_b(nxt, 0);
         SB();
         cur = nxt;
@@ -519,7 +556,7 @@ LayoutI8 layout_i8(int64_t Np, int64_t chunk, int64_t M) {
     L.nparts_cap = nchunks * ((chunk + 255) / 256);   // partials of the 128-row fused epilogue or the 256-row split one
     if (L.nparts_cap < nchunks * (chunk / BM)) L.nparts_cap = nchunks * (chunk / BM);
     int64_t off = 0;
-    L.a8_off = off; off += align_up(Np * chunk * NS, 256);
+    L.a8_off = off; off += align_up(Np * chunk * NSA, 256);
     L.mup_off = off; off += align_up((int64_t)sizeof(double) * (Np / KS_SLICE) * chunk, 256);
     L.xsc_off = off; off += align_up((int64_t)sizeof(double) * Np * GPBO_MAX_D, 256);
     L.pval_off = off; off += align_up((int64_t)sizeof(double) * L.nparts_cap, 256);
@@ -606,7 +643,7 @@ extern "C" int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *
         // fragments of whole 128-candidate blocks are read by the variance kernel: build them for every block touched
         const int64_t used = (Mc + 255) / 256 * 256;
         dim3 kgrid((unsigned)(used / 256), (unsigned)(Np / KS_SLICE));
-        const bool nt = Np * chunk * NS > ((int64_t)1 << 30);
+        const bool nt = Np * chunk * NSA > ((int64_t)1 << 30);
 #define CALL(DD)                                                                                                          \
     if (nt) hipLaunchKernelGGL((kstar_slices_kernel<DD, true>), kgrid, dim3(256), 0, st, Xs + s * d, Mc, Xsc, (int)N, ls,     \
                                alpha, A8, RT, mu_part, chunk);                                                            \

@@ -33,7 +33,7 @@ sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
 I8_MFMA_PEAK_TOPS = 5033.0  # v_mfma_i32_32x32x32_i8: 2048 int8 op/clk/SIMD x 1024 SIMDs x 2.4 GHz (2x the bf16 rate)
-I8_SLICE_PRODUCTS = 21     # int8 slice products per fp64-equivalent multiply-add (csrc/ozaki.hip)
+I8_SLICE_PRODUCTS = 20     # int8 slice products per fp64-equivalent multiply-add (csrc/ozaki.hip)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak = fp64 vector peak (half the 157.3 TF fp32 rate
 #                               listed in MI355X_MICROARCH.md; AMD data sheet value)
 HBM_PEAK_GBS = 8000.0
@@ -274,7 +274,7 @@ def main():
             pass
         peak = FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS
         unit = "TFLOP/s"
-        if i8:  # algorithmic work of this kernel: 21 int8 slice products per multiply-add of the triangular product
+        if i8:  # algorithmic work of this kernel: 20 int8 slice products per multiply-add of the triangular product
             flop_per_cand = I8_SLICE_PRODUCTS * float(N) * N
             achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
             peak, unit = I8_MFMA_PEAK_TOPS, "TOP/s (int8)"
@@ -341,7 +341,7 @@ def main():
             res["int8_sliced_same_workload"] = dict(
                 value=(hi - lo) / (ms * 1e-3), unit="candidates/s", ms_per_step=ms, argmax_index=i,
                 argmax_matches_fp64=bool(i == best[1]), steps=reps2, screen=gp.last_screen,
-                note="variance product = 21 exact int8 slice products on v_mfma_i32_32x32x32_i8 (|dsigma| ~ 1e-10 against "
+                note="variance product = 20 exact int8 slice products on v_mfma_i32_32x32x32_i8 (|dsigma| ~ 1e-10 against "
                      "the fp64 kernels); means and the selected point are the fp64 kernels'; --dtype i8 times it as the "
                      "main workload")
         if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb"):

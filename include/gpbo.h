@@ -201,7 +201,7 @@ int gpbo_rescore_f64(const double *Xs, int64_t M, const double *mu, const double
                      gpbo_screen_stats *stats_host, void *work, int64_t work_bytes, void *stream);
 
 /* int8-sliced variance screen (Ozaki-style splitting on the integer matrix cores, csrc/ozaki.hip): same role and
- * outputs as gpbo_posterior_acq_f32 - mean exactly the fp64 path's, variance from 21 exact int8 slice products
+ * outputs as gpbo_posterior_acq_f32 - mean exactly the fp64 path's, variance from 20 exact int8 slice products
  * (|dsigma| ~ 1e-10 at N = 4096), decision by gpbo_rescore_f64 - at N <= GPBO_I8_MAX_N (int32 accumulators).
  * gpbo_prepare_i8: once per factorisation, U -> column scales + int8 MFMA fragments in `u8`
  * (gpbo_prepare_i8_bytes(Np) bytes, 256-byte aligned).  chunk: a multiple of 512.  No N == M diagonal quirk. */

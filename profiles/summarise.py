@@ -18,8 +18,8 @@ src, out = sys.argv[1], sys.argv[2]
 N, d, dtype, cands = 4096, 8, "f64", 131072
 if len(sys.argv) > 4:
     N, d, dtype, cands = int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7])
-w = 4 if dtype == "f32" else 8
-kern = "sigma_acq_f32_kernel" if dtype == "f32" else "sigma_acq_kernel"
+w = {"f32": 4, "i8": 6}.get(dtype, 8)
+kern = {"f32": "sigma_acq_f32_kernel", "i8": "sigma_i8_kernel"}.get(dtype, "sigma_acq_kernel")
 here = os.path.dirname(os.path.abspath(__file__))
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(here, f"{out}_kernel_stats.csv"))
 
@@ -29,7 +29,8 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
         k = k.split("(")[0].split("<")[0]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-keep = ("sigma_acq_kernel", "kstar_mu_kernel", "sigma_acq_f32_kernel", "kstar_mu_f32_kernel", "rescore_gather_kernel", "potrf_diag_kernel", "gemm_f64_kernel", "kxx_kernel", "utv_kernel",
+keep = ("sigma_acq_kernel", "kstar_mu_kernel", "sigma_acq_f32_kernel", "sigma_i8_kernel", "kstar_slices_kernel",
+        "split_finish_kernel", "u_slices_kernel", "u_colscale_kernel", "potrf_diag_kernel", "gemm_f64_kernel", "kxx_kernel", "utv_kernel",
         "uv_kernel")
 with open(os.path.join(here, f"{out}_pmc_summary.csv"), "w") as fo:
     fo.write("# rocprofv3 --pmc passes (one pass per counter group, profiles/collect.sh), bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also,\n")

@@ -1,4 +1,4 @@
-"""int8-sliced variance screen (csrc/ozaki.hip): the N^2-per-candidate product from 21 exact int8 slice products on the
+"""int8-sliced variance screen (csrc/ozaki.hip): the N^2-per-candidate product from 20 exact int8 slice products on the
 integer matrix cores, fp64 means, fp64 decision behind it (csrc/rescore.hip).
 
 Tolerances (written here): |dmu| = 0 against the fp64 kernels (same arithmetic); |dsigma| <= 2e-9 against the oracle
