@@ -51,7 +51,6 @@ constexpr int STAGE = A_STAGE + B_STAGE;   // 44 KiB
 constexpr int A_PIECES = A_STAGE / FRAG, PIECES = STAGE / FRAG;  // 20 + 24 DMA pieces per stage: 6 for waves 0-3, 5 for 4-7
 constexpr int KS_SLICE = GPBO_KS_SLICE;    // observations per mu_part slice (64)
 constexpr double MAGIC = 6755399441055744.0;  // 1.5 2^52: x + MAGIC has rint(x) in its low mantissa bits
-constexpr double TWO46 = 70368744177664.0;
 constexpr double TWO38 = 274877906944.0;
 
 struct LsArgsI8 {
