@@ -73,12 +73,26 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
     int64_t idx_base, double *__restrict__ mu_out, double *__restrict__ sigma_out, double *__restrict__ acq_out,
     double *__restrict__ part_val, int64_t *__restrict__ part_idx, unsigned long long *__restrict__ nan_count,
     double *__restrict__ vbuf /* optional [chunk x Np]: V = K* U itself, for the joint (qEI) posterior */,
-    double *__restrict__ ss_part /* column-split launches (gridDim.y = S > 1): [S x ldk] partial |v|^2, no epilogue */) {
+    double *__restrict__ ss_part /* column-split launches (gridDim.y = S > 1): [S x ldk] partial |v|^2, no epilogue */,
+    int xg /* > 1: one-dimensional launch, the xg column groups of a candidate tile 8 linear ids apart (same XCD) */,
+    int ntile) {
     __shared__ double smem[3 * STAGE];
     // Column split (few candidates, e.g. the re-scoring behind a screen): workgroup (x, s) of S takes the column
     // blocks s, 2S-1-s, 2S+s, 4S-1-s, ... (boustrophedon rounds: block jb costs jb+1 k tiles, so pairing a cheap
     // with an expensive one balances the S workgroups) and leaves its partial row sums for split_finish_kernel.
-    const int S = (int)gridDim.y, sp = (int)blockIdx.y;
+    int S = (int)gridDim.y, sp = (int)blockIdx.y, tile_x = (int)blockIdx.x;
+    if (xg > 1) {
+        // Column groups for LARGE launches: with one workgroup per candidate tile, 256 slabs of K*^T (8.4 MB each at
+        // N = 4096) are live at a time and every re-read comes from HBM (72 GB per 2^17 candidates, profiles/).  The xg
+        // groups of a tile run side by side on one XCD instead (ids 8 apart under the round-robin dispatch - speed only),
+        // so 256 / xg slabs are live and the re-reads are served on chip.
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int q = slot / xg;
+        S = xg;
+        sp = slot - q * xg;
+        tile_x = q * 8 + xcd;
+        if (tile_x >= ntile) return;
+    }
     auto jb_of = [&](int r) { return r * S + ((r & 1) ? (S - 1 - sp) : sp); };
 
     const int tid = threadIdx.x;
@@ -86,7 +100,7 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid % WR, wq = wid / WR;  // SIMD partners w, w+4 get different column groups
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int64_t cand0 = (int64_t)blockIdx.x * BM;
+    const int64_t cand0 = (int64_t)tile_x * BM;
 
     // staging: global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPRs).
     // LDS image rows are padded, and every wave instruction's 1 KiB lies inside one row:
@@ -497,7 +511,7 @@ PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M, int split
     L.pidx_off = off; off += align_up((int64_t)sizeof(int64_t) * L.nparts_cap, 256);
     L.nan_off = off; off += 256;
     L.ssp_off = off;
-    if (split_max > 1) off += align_up((int64_t)sizeof(double) * split_max * chunk, 256);
+    off += align_up((int64_t)sizeof(double) * (split_max > 16 ? split_max : 16) * chunk, 256);
     L.total = off;
     return L;
 }
@@ -795,11 +809,27 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
         if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
         const int S = split_factor(nblk, Np / BN, split_max);
-        if (S > 1) {
+        // Column groups on one XCD for large calls (see the kernel): measured on MI355X at N = 4096, 2^21 candidates,
+        // same box: 543 -> 509 ms per step with 8 groups (16: 512), the variance launches 32.9 -> 30.7 ms.  The rule depends
+        // on the problem (N, candidates of the CALL), never on the chunking, so results stay chunk-size invariant bit for
+        // bit.  GPBO_F64_GROUPS=1 switches it off (A/B runs).
+        static const int xg_env = getenv("GPBO_F64_GROUPS") ? atoi(getenv("GPBO_F64_GROUPS")) : 8;
+        if (xg_env > 1 && S == 1 && M >= 32768 && Np / BN >= 2 * xg_env && xg_env <= 16) {
+            const int64_t grid1 = (nblk + 7) / 8 * 8 * xg_env;
+            hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)grid1), dim3(NW * 64), 0, st, KsT[b], chunk, U, (int)Np,
+                               mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
+                               (double *)nullptr, (double *)nullptr, (double *)nullptr, part_val + nparts,
+                               part_idx + nparts, nan_count, (double *)nullptr, ss_part, xg_env, (int)nblk);
+            hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, xg_env, chunk, mu_part[b],
+                               (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
+                               mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
+                               acq_out ? acq_out + s : nullptr, (double *)nullptr, part_val + nparts, part_idx + nparts,
+                               nan_count);
+        } else if (S > 1) {
             hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk, (unsigned)S), dim3(NW * 64), 0, st, KsT[b], chunk, U,
                                (int)Np, mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1,
                                idx_offset + s, (double *)nullptr, (double *)nullptr, (double *)nullptr, part_val + nparts,
-                               part_idx + nparts, nan_count, (double *)nullptr, ss_part);
+                               part_idx + nparts, nan_count, (double *)nullptr, ss_part, 1, (int)nblk);
             hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, S, chunk, mu_part[b],
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                                mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
@@ -811,7 +841,8 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                        mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,               \
                        mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                              \
                        acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count,                     \
-                       (V == 6 && c == nchunks - 1 && nchunks > 1) ? KsT[(c + 1) & 1] : (double *)nullptr, (double *)nullptr)
+                       (V == 6 && c == nchunks - 1 && nchunks > 1) ? KsT[(c + 1) & 1] : (double *)nullptr, (double *)nullptr, 1, \
+                       (int)nblk)
 #ifdef GPBO_DIAGNOSTICS
         if (variant == 1) GPBO_SIGMA_LAUNCH(1);
         else if (variant == 2) GPBO_SIGMA_LAUNCH(2);
@@ -916,7 +947,7 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
         // the variance kernel also leaves V (vbuf) and mu; its own single-point acquisition result is ignored
         hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
                            (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
-                           (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb, (double *)nullptr);
+                           (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb, (double *)nullptr, 1, (int)nblk);
         GPBO_CHECK_LAUNCH();
         const int64_t nbatch = Mc / QQ;
         const int64_t qblk = (nbatch + 3) / 4;

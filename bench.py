@@ -324,7 +324,7 @@ def main():
             ms = (time.perf_counter() - t) / reps2 * 1e3
             res["ei_same_workload"] = dict(value=(hi - lo) / (ms * 1e-3), unit="candidates/s", ms_per_step=ms,
                                            argmax_index=i, steps=reps2)
-        if args.dtype == "f64" and N <= 16384:
+        if args.dtype == "f64" and N <= 16384 and not qei:
             # the same workload with the variance product from int8 slices on the integer matrix cores (csrc/ozaki.hip:
             # |dsigma| ~ 1e-10, means and the selected point still from the fp64 kernels)
             gp.prepare_i8()

@@ -18,7 +18,7 @@ src, out = sys.argv[1], sys.argv[2]
 N, d, dtype, cands = 4096, 8, "f64", 131072
 if len(sys.argv) > 4:
     N, d, dtype, cands = int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7])
-w = {"f32": 4, "i8": 6}.get(dtype, 8)
+w = {"f32": 4, "i8": 5}.get(dtype, 8)   # bytes of K* per entry (int8: five slices)
 kern = {"f32": "sigma_acq_f32_kernel", "i8": "sigma_i8_kernel"}.get(dtype, "sigma_acq_kernel")
 here = os.path.dirname(os.path.abspath(__file__))
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(here, f"{out}_kernel_stats.csv"))
@@ -41,6 +41,12 @@ with open(os.path.join(here, f"{out}_pmc_summary.csv"), "w") as fo:
             fo.write(f"{k},{c},{len(v)},{sum(v) / len(v):.6g}\n")
 
 s = agg[kern]
+if "FETCH_SIZE" not in s:   # TRACE_ONLY collection: kernel stats only
+    if len(sys.argv) > 3:
+        line = [l for l in open(sys.argv[3]) if l.startswith("{")][-1]
+        open(os.path.join(here, f"{out}_bench_line.json"), "w").write(line)
+    print(f"{out}: kernel stats only (no PMC passes)")
+    sys.exit(0)
 fetch = sum(s["FETCH_SIZE"]) / len(s["FETCH_SIZE"])
 write = sum(s["WRITE_SIZE"]) / len(s["WRITE_SIZE"])
 path = os.path.join(here, "pmc_sigma_acq.json")
