@@ -9,6 +9,8 @@
 // gpbo_prepare_f32.  This pass is a SCREEN: its variance carries fp32 error, so the arg-max is decided by
 // rescore.hip, which re-scores every candidate that could still be the maximum through the fp64 kernels.
 //
+// (Column groups on one XCD, which give the fp64 and int8 kernels 6-9 %, were measured here too: nothing at N = 8192,
+//  269.4 against 270.0 ms per step - the fp32 copy of U alone is 268 MB, more than the Infinity Cache holds.)
 // Variance kernel geometry (differs from the fp64 one because elements are 4 bytes):
 //   workgroup 512 threads, 256 candidates x 256 columns of V, 16-deep k tiles, 3-stage LDS ring fed by
 //   global_load_lds_dwordx4 (one 1-KiB piece = one 256-float row); wave tile 64 x 128 = 4 x 8 MFMA tiles;
