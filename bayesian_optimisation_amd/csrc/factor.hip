@@ -7,6 +7,8 @@
 // (sigma_acq.hip) instead of a sequential triangular solve per candidate.
 #include "gpbo_internal.h"
 
+#include <cstdlib>
+
 int gpbo_gemm_launch(int transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
                      int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double beta, double *C,
                      int64_t ldc, int64_t strideC, int batch, int lower_only, hipStream_t st);
@@ -233,6 +235,28 @@ __global__ void zero_i32_kernel(int32_t *p) { *p = 0; }
 
 }  // namespace
 
+// Helper stream for the look-ahead of the Cholesky (one per device, created on first use, kept for the life of the
+// process; nothing is retained about the caller's buffers).
+struct LookAhead {
+    hipStream_t stream;
+    hipEvent_t panel_done, rest_done;
+};
+
+static LookAhead *lookahead_for_current_device() {
+    static LookAhead *tab[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!tab[dev]) {
+        LookAhead *h = new LookAhead;
+        bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&h->panel_done, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&h->rest_done, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { delete h; return nullptr; }
+        tab[dev] = h;
+    }
+    return tab[dev];
+}
+
 // info_is_zero: the caller has already cleared *info on this stream (gpbo_factorise_f64 does it in the K(X,X) build)
 static int potrf_run(double *Kp, int64_t Np, double *dinv, int32_t *info, bool info_is_zero, void *stream) {
     if (!Kp || !dinv || !info || Np < NB || Np % NB) return GPBO_ERR_ARG;
@@ -247,6 +271,17 @@ static int potrf_run(double *Kp, int64_t Np, double *dinv, int32_t *info, bool i
     // critical path with a longer K loop.  Measured (whole factorisation, ms, G = 1 / 2 / 4 / 8):
     // N = 2048: 1.36 / 1.37 / 1.45 / 1.62;  N = 4096: 3.77 / 3.63 / 3.76 / 4.10;  N = 8192: 17.1 / 15.3 / 15.1 / 15.9.
     const int G = (Np >= 8192) ? 4 : (Np >= 4096) ? 2 : 1;
+    // Look-ahead (N >= 8192): the trailing update of a group is cut in two - the block columns of the NEXT group, applied
+    // on the caller's stream so that their diagonal blocks and panels (64 launches of ~15 + ~8 us at N = 4096: sequential,
+    // one workgroup wide) can start at once, and everything to the right of them, applied on a helper stream meanwhile.
+    // Events: panel_done (caller -> helper: the group's panel is final), rest_done (helper -> caller: the columns the next
+    // update of the caller touches are no longer being written).  Fork and join inside this call: still capturable.
+    // Measured on MI355X (GPBO_NO_LOOKAHEAD=1 against 0, whole factorisation): N = 2048: 1.17 -> 1.49 ms, N = 4096:
+    // 3.18 -> 3.44 ms (two events and two waits per group cost more than the ~25 us of diagonal block + panel they hide),
+    // N = 8192: 12.9 -> 12.3 ms - so it is used from N = 8192 up only.
+    static const bool la_env = !(getenv("GPBO_NO_LOOKAHEAD") && atoi(getenv("GPBO_NO_LOOKAHEAD")));
+    LookAhead *la = (Np >= 8192 && la_env) ? lookahead_for_current_device() : nullptr;
+    bool rest_pending = false;  // a helper-stream update has been issued and not yet waited for
     for (int j0 = 0; j0 < nb; j0 += G) {
         const int gend = (j0 + G < nb) ? j0 + G : nb;
         for (int j = j0; j < gend; ++j) {
@@ -275,10 +310,33 @@ static int potrf_run(double *Kp, int64_t Np, double *dinv, int32_t *info, bool i
         // trailing lower triangle beyond the group -= P * P^T,  P = rows gend.., block columns j0..gend-1
         const double *P = Kp + (int64_t)gend * NB * Np + (int64_t)j0 * NB;
         double *trail = Kp + (int64_t)gend * NB * Np + (int64_t)gend * NB;
-        int rc = gpbo_gemm_launch(1, restg, restg, (int64_t)NB * (gend - j0), -1.0, P, Np, 0, P, Np, 0, 1.0, trail, Np, 0, 1,
-                                  1, st);
+        const int64_t kdim = (int64_t)NB * (gend - j0);
+        const int gend2 = (gend + G < nb) ? gend + G : nb;
+        const int64_t ncols_a = (int64_t)(gend2 - gend) * NB, rest_b = restg - ncols_a;
+        if (!la || rest_b <= 0) {
+            if (rest_pending) {  // the helper's last update wrote this region
+                if (hipStreamWaitEvent(st, la->rest_done, 0) != hipSuccess) return GPBO_ERR_LAUNCH;
+                rest_pending = false;
+            }
+            int rc = gpbo_gemm_launch(1, restg, restg, kdim, -1.0, P, Np, 0, P, Np, 0, 1.0, trail, Np, 0, 1, 1, st);
+            if (rc != GPBO_OK) return rc;
+            continue;
+        }
+        if (hipEventRecord(la->panel_done, st) != hipSuccess) return GPBO_ERR_LAUNCH;
+        // (a) the next group's block columns, all rows below: on the caller's stream, after the helper's previous update
+        if (rest_pending && hipStreamWaitEvent(st, la->rest_done, 0) != hipSuccess) return GPBO_ERR_LAUNCH;
+        int rc = gpbo_gemm_launch(1, restg, ncols_a, kdim, -1.0, P, Np, 0, P, Np, 0, 1.0, trail, Np, 0, 1, 0, st);
         if (rc != GPBO_OK) return rc;
+        // (b) the lower triangle to the right of them: helper stream (in order behind its previous update)
+        if (hipStreamWaitEvent(la->stream, la->panel_done, 0) != hipSuccess) return GPBO_ERR_LAUNCH;
+        const double *Pb = P + ncols_a * Np;
+        double *trail_b = trail + ncols_a * Np + ncols_a;
+        rc = gpbo_gemm_launch(1, rest_b, rest_b, kdim, -1.0, Pb, Np, 0, Pb, Np, 0, 1.0, trail_b, Np, 0, 1, 1, la->stream);
+        if (rc != GPBO_OK) return rc;
+        if (hipEventRecord(la->rest_done, la->stream) != hipSuccess) return GPBO_ERR_LAUNCH;
+        rest_pending = true;
     }
+    if (rest_pending && hipStreamWaitEvent(st, la->rest_done, 0) != hipSuccess) return GPBO_ERR_LAUNCH;  // join
     return GPBO_OK;
 }
 
