@@ -94,7 +94,7 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best):
+def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best, variance_dtype="f64"):
     """The oracle's Cholesky route (NumPy/LAPACK, BLAS threads = host cores) on a bounded sample of the
     same workload; factorisation excluded (it is amortised over the 2^21 candidates of a real step).  The sample is
     sized from a 1024-candidate probe so that the leg takes about `target_s` seconds."""
@@ -115,8 +115,10 @@ def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best):
     N, d = X.shape
     _, L, alpha = O.factorise(X, y, ls)
 
+    vdt = np.float32 if variance_dtype == "f32" else np.float64   # config 4: the fp32 restatement
+
     def run(P):
-        mu, sig = O.posterior_chol(X, y, P, ls, L=L, alpha=alpha)
+        mu, sig = O.posterior_chol(X, y, P, ls, L=L, alpha=alpha, variance_dtype=vdt)
         a = O.lcb(mu, sig, 4) if acq == "lcb" else O.expected_improvement(mu, sig, f_best, 0.0)
         return int(np.flatnonzero(a == a.max())[0])
 
@@ -131,9 +133,13 @@ def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best):
     t0 = time.perf_counter()
     idx = run(Xs[:ns])
     dt = time.perf_counter() - t0
+    if vdt is np.float32:   # what is TIMED is the fp32 restatement; what the GPU's decision is checked against is fp64
+        vdt = np.float64
+        idx = run(Xs[:ns])
     return dict(value=ns / dt, unit="candidate acquisitions/s", cores=int(threads), kind="port",
                 sample=f"first {ns} of the rank's candidates, N={N}, d={d}, posterior + {acq.upper()} + arg-max, "
-                       f"{dt:.1f} s wall, factorisation excluded (oracle/gp_oracle.py posterior_chol)"), idx, ns
+                       f"{dt:.1f} s wall, factorisation excluded (oracle/gp_oracle.py posterior_chol"
+                       f"{', variance product in fp32; arg-max checked against the fp64 route' if variance_dtype == 'f32' else ''})"), idx, ns
 
 
 def main():
@@ -386,7 +392,8 @@ def main():
             "argmax_index": best[1], "roofline": roofline, "kstar_roofline": kstar_roofline,
         }
         if world == 1 and not args.no_cpu_baseline and not qei:
-            cb, idx_cpu, ns = cpu_baseline(X, y, Xs_local, ls, args.acq, args.cpu_seconds, args.cpu_sample, f_best)
+            cb, idx_cpu, ns = cpu_baseline(X, y, Xs_local, ls, args.acq, args.cpu_seconds, args.cpu_sample, f_best,
+                                           "f32" if f32 else "f64")
             r = {"f32": gp.score_f32, "i8": gp.score_i8}.get(args.dtype, gp.score)(Xsd[:ns], **acq_kw)
             cb["argmax_match_on_sample"] = bool(r.best_idx == idx_cpu)
             out["cpu_baseline"] = cb

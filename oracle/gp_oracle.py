@@ -202,12 +202,16 @@ def factorise(X, y, ls):
     return K, L, alpha
 
 
-def posterior_chol(X, y, Xs, ls, chunk: int = 16384, L=None, alpha=None):
-    """Cholesky route: v = L^-1 k*, sigma^2 = c - |v|^2, mu = k* . alpha; chunked over candidates."""
+def posterior_chol(X, y, Xs, ls, chunk: int = 16384, L=None, alpha=None, variance_dtype=np.float64):
+    """Cholesky route: v = L^-1 k*, sigma^2 = c - |v|^2, mu = k* . alpha; chunked over candidates.
+    variance_dtype=np.float32: the restatement of BASELINE config 4's arithmetic - fp64 factorisation,
+    K* entries and mean; L and K* rounded to fp32 for the N^2-per-candidate triangular solve and |v|^2 - i.e. what the
+    fp32 screen computes (csrc/posterior_f32.hip), on the CPU."""
     X = np.asarray(X, dtype=np.float64)
     Xs = np.asarray(Xs, dtype=np.float64)
     if L is None:
         _, L, alpha = factorise(X, y, ls)
+    Lv = L if variance_dtype == np.float64 else np.asarray(L, dtype=variance_dtype)
     M = len(Xs)
     mu = np.empty(M)
     sig = np.empty(M)
@@ -216,8 +220,8 @@ def posterior_chol(X, y, Xs, ls, chunk: int = 16384, L=None, alpha=None):
         e = min(M, s + chunk)
         kmp = kernel_rbf(X, Xs[s:e], ls) if not same_shape else kernel_rbf(X, Xs, ls)[:, s:e]
         mu[s:e] = kmp.T @ alpha
-        v = sla.solve_triangular(L, kmp, lower=True, check_finite=False)
-        sig[s:e] = np.sqrt(np.abs(PRIOR_VAR - np.einsum("nm,nm->m", v, v)))
+        v = sla.solve_triangular(Lv, kmp.astype(variance_dtype, copy=False), lower=True, check_finite=False)
+        sig[s:e] = np.sqrt(np.abs(PRIOR_VAR - np.einsum("nm,nm->m", v, v).astype(np.float64)))
     return mu, sig
 
 

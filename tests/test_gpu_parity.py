@@ -378,6 +378,9 @@ def test_config4_shape_n8192_fp32_subsampled():
     acq_o = O.lcb(mu_o, sig_o, 4)
     assert np.max(np.abs(mu[sub] - mu_o)) <= 1e-9 * max(1.0, np.abs(y).max()) + 1e-12 * float(np.abs(alpha_o).sum())
     assert np.max(np.abs(sig[sub] ** 2 - sig_o ** 2)) <= 5e-3
+    # against the fp32 CPU restatement of the same arithmetic: both carry fp32 error of the same size
+    _, sig_o32 = O.posterior_chol(X, y, Xs[sub], ls, variance_dtype=np.float32)
+    assert np.max(np.abs(sig[sub] ** 2 - sig_o32 ** 2)) <= 5e-3
     top2 = np.sort(acq_o)[-2:]
     if top2[1] - top2[0] > 1e-7:
         assert sub[_first_argmax(acq_o)] == r.best_idx     # the oracle's first arg-max (the fp32 top-16 are in `sub`)
