@@ -245,6 +245,18 @@ __global__ __launch_bounds__(256) void kstar_slices_kernel(const double *__restr
     mu_part[(int64_t)blockIdx.y * ldk + c] = nan_c ? __builtin_nan("") : mu;
 }
 
+#ifdef GPBO_I8_STAMPS  // diagnostics build only (tools/build_variant.sh): where do the waves wait?  cycles summed over waves
+__device__ unsigned long long g_i8_stamps[4];  // [0] total wave cycles, [1] in the pre-barrier s_waitcnt, [2] in s_barrier, [3] waves
+__device__ unsigned long long g_i8_timeline[2][96][8];  // waves 0 and 4 of workgroup 0: stamps of stages 100..195
+#define I8_TL(slot)                                                                                         \
+    do {                                                                                                    \
+        if (tl_on && tl_stage >= 100 && tl_stage < 196 && lane == 0)                                        \
+            g_i8_timeline[wid >> 2][tl_stage - 100][slot] = __builtin_amdgcn_s_memtime();                  \
+    } while (0)
+#else
+#define I8_TL(slot) do {} while (0)
+#endif
+
 // ---- the variance kernel -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void sigma_i8_kernel(
     const char *__restrict__ A8, int64_t RT, const char *__restrict__ U8, int Np, const double *__restrict__ colscale,
@@ -329,6 +341,9 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
     //              it takes the DMA of stage t+3, which the two waves of a SIMD issue at different times (waves 0-3
     //              inside M(0), waves 4-7 inside M(1) / M(2) of the next stage), one piece after every second MFMA.
     const bool early = wid < 4;  // which of the two waves of a SIMD issues its DMA pieces first (and has 6, not 5)
+    // static priority for the second-dispatched half, the loser of the SIMD's age-based arbitration (same-box A/B:
+    // 71.1 -> 70.7 ms per 2^19 candidates; priority for the first half instead: 71.5)
+    if (!early) __builtin_amdgcn_s_setprio(1);
     auto wait_own = [&](int stages_left_in_flight) {  // own pieces of all but the youngest `stages_left_in_flight` stages
         if (stages_left_in_flight >= 1) {
             if (early) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
@@ -346,6 +361,12 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
     __builtin_amdgcn_s_barrier();
     bool dma_due = pj < nJ;   // a stage is waiting to be issued into the free buffer (stage 2 into buffer 2 at first)
 
+#ifdef GPBO_I8_STAMPS
+    unsigned long long st_wait = 0, st_bar = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+    const bool tl_on = blockIdx.x == 0 && (wid == 0 || wid == 4);
+    int tl_stage = 0;
+#endif
     int cur = 0;
     i4_t b[NS], a0[2];       // U slices of the current stage, K* slice 0 of the current stage (both row tiles)
     auto lds_a = [&](i4_t (&dst)[2], int buf, int i) {
@@ -388,6 +409,7 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
         const bool issue_now = dma_due;
         if (issue_now) dma_begin();
         SB();
+        I8_TL(0);
         lds_a(a1, cur, 1);
         SB();
         // M(0): j descending - U slice 0 of this stage was the last operand fetched
@@ -397,6 +419,7 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
         if (active) { MM(a0, 0, 2); } SB(); if (issue_now && early) dma_piece(3); SB();
         if (active) { MM(a0, 0, 1); } SB(); if (issue_now && early) dma_piece(4); SB();
         if (active) { MM(a0, 0, 0); } SB(); if (issue_now && early) dma_piece(5); SB();
+        I8_TL(1);
         lds_a(a2, cur, 2);
         SB();
         if (active) { MM(a1, 1, 0); } SB(); if (issue_now && !early) dma_piece(0); SB();
@@ -405,17 +428,34 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
         if (active) { MM(a1, 1, 3); } SB(); if (issue_now && !early) dma_piece(3); SB();
         if (active) { MM(a1, 1, 4); }
         SB();
+        I8_TL(2);
         lds_a(a3, cur, 3);
         lds_a(a4, cur, 4);
         SB();
         if (active) { MM(a2, 2, 0); } SB(); if (issue_now && !early) dma_piece(4); SB();
         if (active) { MM(a2, 2, 1); MM(a2, 2, 2); MM(a2, 2, 3); }
         SB();
+        I8_TL(3);
         if (issue_now) ++inflight;
         // all LDS operands of this stage are in registers; own pieces of the next stage have landed
+#ifdef GPBO_I8_STAMPS
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
         wait_own(inflight - 1);
         if (inflight > 0) --inflight;
+#ifdef GPBO_I8_STAMPS
+        const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef GPBO_I8_STAMPS
+        const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+        st_wait += ts1 - ts0;
+        st_bar += ts2 - ts1;
+        if (tl_on && tl_stage >= 100 && tl_stage < 196 && lane == 0) {
+            g_i8_timeline[wid >> 2][tl_stage - 100][4] = ts1;
+            g_i8_timeline[wid >> 2][tl_stage - 100][5] = ts2;
+        }
+#endif
         dma_due = pj < nJ;   // the buffer of this stage is free from here on
         SB();
         // next stage's operands under the cover of M(3), M(4); registers of dead U slices are reused as they die
@@ -424,13 +464,18 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
         SB();
         if (active) { MM(a3, 3, 0); MM(a3, 3, 1); MM(a3, 3, 2); }
         SB();
+        I8_TL(6);
         lds_b(nxt, 2);
         SB();
         if (active) { MM(a4, 4, 0); MM(a4, 4, 1); }
         SB();
+        I8_TL(7);
         lds_b(nxt, 1);
         lds_b(nxt, 0);
         SB();
+#ifdef GPBO_I8_STAMPS
+        ++tl_stage;
+#endif
         cur = nxt;
     };
 #undef MM
@@ -474,6 +519,14 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
         ssrow += x[0];
     }
 
+#ifdef GPBO_I8_STAMPS
+    if (lane == 0) {
+        atomicAdd(&g_i8_stamps[0], __builtin_amdgcn_s_memtime() - st_begin);
+        atomicAdd(&g_i8_stamps[1], st_wait);
+        atomicAdd(&g_i8_stamps[2], st_bar);
+        atomicAdd(&g_i8_stamps[3], 1ull);
+    }
+#endif
     // ---- row sums to LDS: red[wq][row of the block]
     __syncthreads();
     double *red = reinterpret_cast<double *>(smem);  // [4][BM]
@@ -567,6 +620,20 @@ LayoutI8 layout_i8(int64_t Np, int64_t chunk, int64_t M) {
 }
 
 }  // namespace
+
+#ifdef GPBO_I8_STAMPS
+extern "C" int gpbo_i8_timeline_read(unsigned long long *out_host /* [2][96][8] */) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_i8_timeline), sizeof(unsigned long long) * 2 * 96 * 8) == hipSuccess ? 0 : -2;
+}
+extern "C" int gpbo_i8_stamps_read(unsigned long long *out4_host, int reset) {
+    if (hipMemcpyFromSymbol(out4_host, HIP_SYMBOL(g_i8_stamps), 4 * sizeof(unsigned long long)) != hipSuccess) return -2;
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_i8_stamps), z, sizeof(z)) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int64_t gpbo_prepare_i8_bytes(int64_t Np) {
     if (Np < GPBO_NPAD || Np % GPBO_NPAD || Np > GPBO_I8_MAX_N) return GPBO_ERR_ARG;

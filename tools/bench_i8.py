@@ -2,7 +2,7 @@
 # modes: i8 (screen + fp64 decision), f64 (plain fp64 pass), i8raw (the int8 pass alone: gpbo_posterior_acq_i8 through ctypes)
 import ctypes as C
 import sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np, torch
 from bayesian_optimisation_amd import DeviceGP, _lib
 from bayesian_optimisation_amd.gp_device import PRIOR_VAR
@@ -45,3 +45,24 @@ for name in modes:
         r = fn(Xd)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
     print(name, "N=%d %.2f ms per 2^19" % (N, dt * 1e3), "%.4g cand/s" % (M / dt), r.best_idx, flush=True)
+
+if hasattr(gp.lib, "gpbo_i8_stamps_read"):   # diagnostics build (-DGPBO_I8_STAMPS): where the waves of sigma_i8_kernel wait
+    buf = (C.c_ulonglong * 4)()
+    gp.lib.gpbo_i8_stamps_read(buf, 1)
+    i8raw(Xd)
+    torch.cuda.synchronize()
+    gp.lib.gpbo_i8_stamps_read(buf, 0)
+    tot, w, b, n = [int(v) for v in buf]
+    print(f"stamps over {n} waves: wave lifetime {tot/n:.0f} cycles, pre-barrier s_waitcnt {100*w/tot:.1f} %, s_barrier {100*b/tot:.1f} %")
+    tl = (C.c_ulonglong * (2 * 96 * 8))()
+    gp.lib.gpbo_i8_timeline_read(tl)
+    T = np.array(list(tl), dtype=np.int64).reshape(2, 96, 8)
+    # per stage: [0] body start, [1] after M(0), [2] after M(1), [3] after M(2), [4] after s_waitcnt, [5] after s_barrier,
+    #            [6] after M(3), [7] after M(4)
+    for w in range(2):
+        d = np.diff(T[w], axis=1)
+        nxt = T[w, 1:, 0] - T[w, :-1, 7]
+        print(f"wave {4*w}: median cycles  M(0) {np.median(d[:,0]):.0f}  M(1) {np.median(d[:,1]):.0f}  M(2) {np.median(d[:,2]):.0f}  "
+              f"waitcnt {np.median(d[:,3]):.0f}  barrier {np.median(d[:,4]):.0f}  M(3) {np.median(d[:,5]):.0f}  M(4) {np.median(d[:,6]):.0f}  "
+              f"to next stage {np.median(nxt):.0f}  stage {np.median(T[w,1:,0]-T[w,:-1,0]):.0f}")
+    print("wave 4 start minus wave 0 start per stage (median):", np.median(T[1,:,0] - T[0,:,0]))

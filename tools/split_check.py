@@ -1,6 +1,6 @@
 # column-split fp64 launch against the plain one: a few candidates, N = 4096
 import sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np, torch
 from bayesian_optimisation_amd import DeviceGP
 from bayesian_optimisation_amd.synthetic import make_problem
