@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
         dma_due = pj < nJ;   // the buffer of this stage is free from here on
         SB();
         // (issuing the pieces of waves 4-7 right here, after the barrier, instead of inside M(1) / M(2) changes nothing:
-        //  69.8 against 69.7 ms per 2^19 candidates - when the DMA is issued is not what costs)
+        //  69.8 against 69.7 ms per 2^19 candidates; letting waves 0-3 issue all 44 pieces, 11 each, LOSES: 71.1 -> 74.3 ms)
         // next stage's operands under the cover of M(3), M(4); registers of dead U slices are reused as they die
         lds_b(nxt, 5); lds_b(nxt, 4); lds_b(nxt, 3);
         lds_a(a0, nxt, 0);
