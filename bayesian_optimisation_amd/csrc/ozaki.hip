@@ -141,17 +141,26 @@ __device__ __forceinline__ void digits4_k(const double (&z)[4], unsigned (&P)[NS
 }
 
 // ---- U -> column scales and int8 fragments (once per factorisation) ---------------------------------------------------
-// scale[j] = 2^e_j >= max_i |U_ij|  (exact power of two), inv[j] = 2^(46 - e_j).   grid Np/256, block 256.
-__global__ __launch_bounds__(256) void u_colscale_kernel(const double *__restrict__ U, int Np, double *__restrict__ scale,
-                                                         double *__restrict__ inv) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= Np) return;
+// scale[j] = 2^e_j >= max_i |U_ij|  (exact power of two), inv[j] = 2^(46 - e_j).
+// grid Np/64, block 1024: 64 columns x 16 row groups (a column's rows are strided over the groups, one 512-byte row
+// segment per wave load), maximum over the groups through LDS.  (One thread per column walking all its rows took 1 ms at
+// N = 4096 - as long as the whole K* slicing of a chunk.)
+__global__ __launch_bounds__(1024) void u_colscale_kernel(const double *__restrict__ U, int Np, double *__restrict__ scale,
+                                                          double *__restrict__ inv) {
+    __shared__ double part[16][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
     double m = 0.0;
-    for (int i = 0; i <= j; ++i) m = fmax(m, fabs(U[(int64_t)i * Np + j]));  // upper triangular: rows <= j
-    int e = 0;
-    if (m > 0.0) (void)frexp(m, &e);  // m = f 2^e, f in [0.5, 1)
-    scale[j] = ldexp(1.0, e);
-    inv[j] = ldexp(1.0, 46 - e);
+    for (int i = rg; i <= j; i += 16) m = fmax(m, fabs(U[(int64_t)i * Np + j]));  // upper triangular: rows <= j
+    part[rg][c] = m;
+    __syncthreads();
+    if (rg == 0) {
+        for (int q = 1; q < 16; ++q) m = fmax(m, part[q][c]);
+        int e = 0;
+        if (m > 0.0) (void)frexp(m, &e);  // m = f 2^e, f in [0.5, 1)
+        scale[j] = ldexp(1.0, e);
+        inv[j] = ldexp(1.0, 46 - e);
+    }
 }
 
 // thread = (k block of 16, column): 16 entries -> six 16-byte lane operands.  grid (Np/256, Np/16), block 256.
@@ -650,7 +659,7 @@ extern "C" int gpbo_prepare_i8(const double *U, int64_t Np, void *u8, int64_t u8
     char *U8 = reinterpret_cast<char *>(u8);
     double *scale = reinterpret_cast<double *>(U8 + align_up(Np * Np * NS, 256));
     double *inv = scale + align_up((int64_t)sizeof(double) * Np, 256) / 8;
-    hipLaunchKernelGGL(u_colscale_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, U, (int)Np, scale, inv);
+    hipLaunchKernelGGL(u_colscale_kernel, dim3((unsigned)(Np / 64)), dim3(1024), 0, st, U, (int)Np, scale, inv);
     hipLaunchKernelGGL(u_slices_kernel, dim3((unsigned)(Np / 256 + (Np % 256 ? 1 : 0)), (unsigned)(Np / 16)), dim3(256), 0, st,
                        U, (int)Np, inv, U8);
     GPBO_CHECK_LAUNCH();
