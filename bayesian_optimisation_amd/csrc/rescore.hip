@@ -24,8 +24,11 @@ __device__ __forceinline__ void bounds(int kind, double mu, double var, double t
                                        double &hi) {
     const double a = fabs(var);
     const double s_lo = sqrt(fmax(a - tau, 0.0)), s_hi = sqrt(a + tau);
-    lo = gpbo_acquisition(kind, mu, s_lo, p0, p1);
-    hi = gpbo_acquisition(kind, mu, s_hi, p0, p1);
+    const double a_lo = gpbo_acquisition(kind, mu, s_lo, p0, p1);
+    const double a_hi = gpbo_acquisition(kind, mu, s_hi, p0, p1);
+    // both acquisitions are monotone in sigma (LCB: increasing for explore > 0, decreasing for a negative explore)
+    lo = (a_hi < a_lo) ? a_hi : a_lo;   // NaN (mu NaN) stays NaN in both
+    hi = (a_hi < a_lo) ? a_lo : a_hi;
 }
 
 // per-workgroup maximum of the lower bounds (NaNs skipped: they survive the selection unconditionally)

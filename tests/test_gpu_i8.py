@@ -102,3 +102,15 @@ def test_dropin_class_with_the_int8_screen_reproduces_the_reference(golden, name
     assert np.max(np.abs(ps.acq_func_eval - g["acq_func_eval"])) <= 1e-8 * ys
     if g["top2_gap"] > 1e-7 * ys or g["n_max_ties"] > 1:
         assert np.array_equal(idx, g["index"])
+
+
+def test_screens_with_a_negative_explore_weight():
+    """lower_confidence_bound(explore < 0) makes the acquisition DEcrease with sigma: the screen's interval must still
+    bracket the fp64 value (bounds are ordered, not assumed)."""
+    X, y, Xs, ls = make_problem(300, 40000, 4)
+    gp = DeviceGP(chunk=8192).factorise(X, y, ls)
+    r64 = gp.score(Xs, acquisition="lcb", explore=-2.5)
+    for route in ("score_i8", "score_f32"):
+        r = getattr(gp, route)(Xs, acquisition="lcb", explore=-2.5)
+        assert r.best_idx == r64.best_idx and abs(r.best_val - r64.best_val) <= 1e-12 * max(1.0, abs(r64.best_val))
+        assert not gp.last_screen["fallback"]
