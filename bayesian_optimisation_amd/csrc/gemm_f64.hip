@@ -25,8 +25,14 @@ constexpr int LDA_S = 17;  // As[m][k] / Bt[n][k] row stride (doubles)
 // tri: 1 = B [K x N] is lower triangular (rows k < n are zero): the k loop of column tile bx starts at bx T;
 //      2 = A [M x K] is lower triangular (columns k > m are zero): the k loop of row tile by ends at (by + 1) T
 // (the two products of each level of the triangular inverse; N = 4096: factorisation 3.42 -> 3.17 ms).
-// (A 128 x 128 tile - wave tile 64 x 64, 210 registers - was measured and is SLOWER than this one on every shape of the
-//  factorisation: 8192^2 x 256 lower-triangle update 29.5 against 39.3 TFLOP/s, 4096^3 49.8 against 54.2.)
+// Why 38-54 TFLOP/s: the 64 x 64 tile moves 16 KB per 16-deep k tile for 2 x 64 x 64 x 16 flop = 8 flop/B, and at the
+// ~12 B/clk/CU these kernels get out of L2 (the rate ozaki.hip measures for its operands too) that is ~52 TFLOP/s.
+// 128 x 128 tiles double the intensity; both forms were built and measured (tools/bench_gemm.py) and are not kept:
+//  - 4 waves, wave tile 64 x 64 (210 registers, two waves per SIMD): slower on every shape (8192^2 x 256 lower-triangle
+//    update 29.5 against 39.3 TFLOP/s, 4096^3 49.8 against 54.2);
+//  - 8 waves, wave tile 32 x 64 (122 registers): 68 TFLOP/s at 4096^3, but the factorisation is made of K <= 256 updates,
+//    where a quarter as many tiles leaves compute units idle (4096^2 x 128: 28 against 39 TFLOP/s; whole factorisation at
+//    N = 8192 12.6 against 12.3 ms) and the batched ARD products got 18x slower.
 template <int TRANSB, int T>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int64_t K, double alpha,
                                                         const double *__restrict__ A, int64_t lda, int64_t strideA,
