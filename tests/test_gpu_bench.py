@@ -18,8 +18,9 @@ def _bench(*flags):
 
 
 @pytest.mark.gpu
-def test_two_self_launched_ranks_pick_the_point_one_rank_picks_over_the_same_candidates():
-    common = ["--n-obs", "384", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also"]
+@pytest.mark.parametrize("dtype", ["f64", "i8"])
+def test_two_self_launched_ranks_pick_the_point_one_rank_picks_over_the_same_candidates(dtype):
+    common = ["--n-obs", "384", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--dtype", dtype]
     two = _bench("--gpus", "2", "--backend", "gloo", "--all-on-device", "0", "--m-per-gpu", "65536", *common)
     one = _bench("--gpus", "1", "--m-per-gpu", "131072", *common)
     assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and one["n_gpus"] == 1
