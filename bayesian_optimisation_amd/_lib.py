@@ -125,6 +125,15 @@ def _bind_to_pytorch_hip_runtime():
                 pass  # fall back to whatever the dynamic linker resolves
 
 
+def mapped_hip_runtimes():
+    """Paths of every libamdhip64 mapped into this process (Linux: /proc/self/maps)."""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({line.split()[-1] for line in f if "libamdhip64" in line and line.split()[-1].startswith("/")})
+    except OSError:
+        return []
+
+
 def note_hip_use():
     """Called by the NumPy-only binding right before a call that initialises HIP (see gp_device._torch)."""
     global hip_used_before_pytorch
@@ -145,6 +154,12 @@ def load():
             "(there is no CPU fallback for the acquisition path)")
     _bind_to_pytorch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
+    rts = mapped_hip_runtimes()
+    if len({os.path.realpath(p) for p in rts}) > 1:
+        # two HIP runtimes in one process do not share the device: whichever initialises second sees no GPU (seen in
+        # round 1 as torch.cuda.is_available() == False after a host-pointer call).  Fail here, loudly, not later.
+        raise GpboError("two different HIP runtimes are mapped into this process: " + ", ".join(rts) + ". Load PyTorch (or "
+                        "this package) before any other library that links libamdhip64, so that all of them share one.")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res

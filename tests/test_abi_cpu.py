@@ -136,3 +136,30 @@ def test_python_constants_match_the_header():
     assert defs["GPBO_NPAD"] == _lib.NPAD and defs["GPBO_CHUNK_GRANULE"] == _lib.CHUNK_GRANULE
     assert defs["GPBO_MAX_D"] == _lib.MAX_D and defs["GPBO_ACQ_LCB"] == _lib.ACQ_LCB and defs["GPBO_ACQ_EI"] == _lib.ACQ_EI
     assert defs["GPBO_VERSION"] == _lib.load().gpbo_version()
+
+
+def test_loader_refuses_a_second_hip_runtime():
+    """Two HIP runtimes in one process do not share the device (round 1: torch.cuda.is_available() turned False after a
+    host-pointer call through the other one).  If the system's libamdhip64 is already mapped when the package loads -
+    and PyTorch's copy is what the loader binds to - loading must fail with a clear message, not at the first kernel."""
+    import subprocess
+    import sys
+
+    sysrt = "/opt/rocm/lib/libamdhip64.so"
+    if not os.path.exists(sysrt):
+        pytest.skip("no system ROCm runtime in this image")
+    code = (
+        "import ctypes, sys\n"
+        f"sys.path.insert(0, {REPO!r})\n"
+        f"ctypes.CDLL({sysrt!r}, mode=ctypes.RTLD_GLOBAL)\n"
+        "from bayesian_optimisation_amd import _lib\n"
+        "try:\n"
+        "    _lib.load()\n"
+        "    print('loaded', len(_lib.mapped_hip_runtimes()))\n"
+        "except _lib.GpboError as e:\n"
+        "    print('refused' if 'two different HIP runtimes' in str(e) else 'other: ' + str(e))\n"
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1500:]
+    # either PyTorch is absent / shares the system runtime (one copy mapped: fine) or the clash is reported
+    assert out.stdout.strip() in ("refused", "loaded 1"), out.stdout
