@@ -350,6 +350,41 @@ def main():
                 note="variance product = 20 exact int8 slice products on v_mfma_i32_32x32x32_i8 (|dsigma| ~ 1e-10 against "
                      "the fp64 kernels); means and the selected point are the fp64 kernels'; --dtype i8 times it as the "
                      "main workload")
+        g1 = os.path.join(REPO, "tests", "golden", "g1_m32.npz")
+        if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb") and os.path.exists(g1):
+            # BASELINE configs[0] (d=2, N=32, M=32x32 grid, 50x50 ARD search - the sizes the reference's DAG runs): the
+            # drop-in class on the committed fixture the REFERENCE produced (tests/golden/make_golden.py), host arrays in and
+            # out, against the oracle on the host cores and the reference's own selected point
+            from bayesian_optimisation_amd import PointSelector
+            from oracle import gp_oracle as O
+
+            g = dict(np.load(g1))
+            fd = [int(v) for v in g["feature_domain"]]
+
+            def dropin():
+                ps = PointSelector(device=dev)
+                ps.name, ps.iteration = "T", 0
+                ps.measured_pts, ps.measured_vals = g["X"], g["y"]
+                ps.feature_domain, ps.predicted_pts, ps.length_scales = fd, g["Xs"], g["length_scales"]
+                ps.update_surrogate()
+                return ps.lower_confidence_bound()
+
+            dropin(); dropin()
+            ts = []
+            for _ in range(15):
+                t = time.perf_counter()
+                idx = dropin()
+                ts.append(time.perf_counter() - t)
+            ms = float(np.median(ts)) * 1e3
+            t = time.perf_counter()
+            o = O.select_next(g["X"], g["y"], g["Xs"], fd, length_scales=g["length_scales"])
+            cpu_ms = (time.perf_counter() - t) * 1e3
+            res["configs[0]"] = dict(workload="d=2, N=32, M=32x32, 50x50 ARD grid + posterior + LCB through the drop-in class",
+                                     value=len(g["Xs"]) / (ms * 1e-3), unit="candidates/s", ms_per_step=ms, steps=15,
+                                     index=[int(v) for v in idx], reference_index=[int(v) for v in g["index"]],
+                                     index_matches_reference=bool(np.array_equal(idx, g["index"])),
+                                     cpu_port_ms=cpu_ms, cpu_port_index_matches=bool(np.array_equal(o["index"], g["index"])),
+                                     note="the reference itself took 587 ms on this shape in the survey container (BASELINE.md 2)")
         if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb"):
             n2, m2 = 512, 1 << 20
             X2 = sobol_points(0, n2, d)

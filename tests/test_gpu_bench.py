@@ -38,6 +38,8 @@ def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
     assert "N=4096" in line["cpu_baseline"]["sample"]
     assert 0.5 < line["roofline"]["frac"] <= 1.0
     assert line["also"]["configs[1]"]["value"] > 0 and line["also"]["ei_same_workload"]["value"] > 0
+    c0 = line["also"]["configs[0]"]
+    assert c0["index_matches_reference"] is True and c0["cpu_port_index_matches"] is True and c0["ms_per_step"] < 50
     i8 = line["also"]["int8_sliced_same_workload"]
     assert i8["argmax_matches_fp64"] is True and not i8["screen"]["fallback"] and i8["value"] > line["value"]
 
