@@ -10,8 +10,9 @@ Workload (default): the configuration BASELINE.json's metric is quoted on - d=8,
 fp64, 2^21 Sobol candidates per GPU (= configs[2]'s per-GPU shard: 8 ranks score 2^24), LCB(explore=4), the
 reference's acquisition (point_selector.py:197-207).  `--acq ei` / `--acq qei` time the acquisitions the north star
 names; configs[1] (N=512, M=2^20), configs[3] (--dtype f32 --d 16 --n-obs 8192 --m-per-gpu 524288) and configs[4]
-(--acq qei --n-obs 2048 --m-per-gpu 1048576) stay reachable by flags; the default run reports configs[1] and EI
-under "also".
+(--acq qei --n-obs 2048 --m-per-gpu 1048576) stay reachable by flags; the default run also reports, under "also": EI on
+the same workload, the same workload through the int8-sliced variance screen, configs[1], and configs[0] (the reference's
+own sizes, on the fixture the reference produced, with the oracle timed beside it).
 For N>1 the candidate set grows with N (contiguous shards): weak scaling; the reported value is the whole-job
 rate M_total / max-over-ranks step time.
 
