@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256) void qei_kernel(const double *__restrict__ V, 
 }
 
 struct QeiLayout {
-    int64_t kst_off, mup_off, xsc_off, v_off, mu_off, spv_off, spi_off, pval_off, pidx_off, nan_off, total;
+    int64_t kst_off, mup_off, xsc_off, v_off, mu_off, spv_off, spi_off, pval_off, pidx_off, nan_off, ssp_off, total;
 };
 
 QeiLayout qei_layout(int64_t Np, int64_t chunk, int64_t M) {
@@ -668,6 +668,7 @@ QeiLayout qei_layout(int64_t Np, int64_t chunk, int64_t M) {
     L.pval_off = off; off += align_up((int64_t)sizeof(double) * nparts, 256);
     L.pidx_off = off; off += align_up((int64_t)sizeof(int64_t) * nparts, 256);
     L.nan_off = off; off += 256;
+    L.ssp_off = off; off += align_up((int64_t)sizeof(double) * 16 * chunk, 256);  // column-group partials (large calls)
     L.total = off;
     return L;
 }
@@ -944,10 +945,26 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
         rc = gpbo_kstar_mu_f64(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, 0.0, 0, KsT, chunk, mu_part, stream);
         if (rc != GPBO_OK) return rc;
         const int64_t nblk = (Mc + BM - 1) / BM;
-        // the variance kernel also leaves V (vbuf) and mu; its own single-point acquisition result is ignored
-        hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
-                           (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
-                           (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb, (double *)nullptr, 1, (int)nblk);
+        // the variance kernel also leaves V (vbuf) and mu; its own single-point acquisition result is ignored.
+        // Large calls: column groups on one XCD as in gpbo_posterior_acq_f64 (each group writes its column blocks of V;
+        // the mean then comes from split_finish_kernel).
+        static const int xg_env = getenv("GPBO_F64_GROUPS") ? atoi(getenv("GPBO_F64_GROUPS")) : 8;
+        if (xg_env > 1 && xg_env <= 16 && M >= 32768 && Np / BN >= 2 * xg_env) {
+            double *ss_part = reinterpret_cast<double *>(w + L.ssp_off);
+            const int64_t grid1 = (nblk + 7) / 8 * 8 * xg_env;
+            hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)grid1), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
+                               (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0,
+                               (double *)nullptr, (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb, ss_part,
+                               xg_env, (int)nblk);
+            hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, xg_env, chunk, mu_part,
+                               (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
+                               (double *)nullptr, (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch);
+        } else {
+            hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
+                               (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
+                               (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb, (double *)nullptr, 1,
+                               (int)nblk);
+        }
         GPBO_CHECK_LAUNCH();
         const int64_t nbatch = Mc / QQ;
         const int64_t qblk = (nbatch + 3) / 4;
