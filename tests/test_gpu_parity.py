@@ -665,3 +665,28 @@ def test_ard_explicit_cell_list_d8():
     ps1.set_length_scale_cells(cells)
     ps1.update_surrogate()
     assert np.array_equal(ps1.kernel_params, cells[150])
+
+
+def test_large_call_column_groups_agree_with_the_ungrouped_kernel_and_the_oracle():
+    """Calls of >= 32,768 candidates with >= 16 column blocks (N >= 2048) split a candidate tile's column blocks over 8
+    workgroups (sigma_acq.hip); smaller calls do not.  Same candidates through both: dense values equal to the rounding of a
+    different summation order, same selected point; oracle on a sub-sample; chunk-size invariance bit for bit."""
+    N, M, d = 2048, 40960, 8
+    X, y, Xs, ls = make_problem(N, M, d)
+    gp = DeviceGP(chunk=1 << 14).factorise(X, y, ls)
+    big = gp.score(Xs, dense=True)                                   # grouped
+    h = M // 2
+    a, b = gp.score(Xs[:h], dense=True), gp.score(Xs[h:], dense=True, idx_offset=h)   # 20,480 each: ungrouped
+    sig2 = np.concatenate([a.sigma.cpu().numpy(), b.sigma.cpu().numpy()])
+    mu2 = np.concatenate([a.mu.cpu().numpy(), b.mu.cpu().numpy()])
+    assert np.array_equal(big.mu.cpu().numpy(), mu2)
+    assert np.max(np.abs(big.sigma.cpu().numpy() - sig2)) <= 1e-12
+    best2 = max([(a.best_val, -a.best_idx), (b.best_val, -b.best_idx)])
+    assert abs(big.best_val - best2[0]) <= 1e-12 and (big.best_idx == -best2[1] or abs(a.best_val - b.best_val) <= 1e-12)
+    sub = np.unique(np.concatenate([np.random.default_rng(5).choice(M, 200, replace=False),
+                                    np.argsort(big.acq.cpu().numpy())[-8:]]))
+    mu_o, sig_o = O.posterior_chol(X, y, Xs[sub], ls)
+    assert np.max(np.abs(big.mu.cpu().numpy()[sub] - mu_o)) <= 1e-9 * max(1.0, np.abs(y).max())
+    assert np.max(np.abs(big.sigma.cpu().numpy()[sub] - sig_o)) <= 1e-8
+    other = DeviceGP(chunk=1 << 13).factorise(X, y, ls).score(Xs, dense=True)
+    assert np.array_equal(other.sigma.cpu().numpy(), big.sigma.cpu().numpy()) and other.best_idx == big.best_idx
