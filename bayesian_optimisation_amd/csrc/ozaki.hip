@@ -195,7 +195,9 @@ __global__ __launch_bounds__(256) void u_slices_kernel(const double *__restrict_
 // ---- K(X*,X) chunk -> int8 fragments + fp64 mean partials ---------------------------------------------------------------
 // grid (ldk_used/256, Np/64), block 256: thread = one candidate, blockIdx.y = 64 observations (four 16-entry lane
 // operands).  Entries and mean partials are the fp64 path's (same distance / exp arithmetic, same fma order over n).
-template <int D, bool NT /* non-temporal stores: slabs far beyond the Infinity Cache (see kernel_build.hip) */>
+// NA = digits stored per entry: 5 for the full pass, 3 (the leading ones: a balanced representation truncates to nearest)
+// for the coarse screen below.
+template <int D, bool NT /* non-temporal stores: slabs far beyond the Infinity Cache (see kernel_build.hip) */, int NA>
 __global__ __launch_bounds__(256) void kstar_slices_kernel(const double *__restrict__ Xs, int64_t Mc,
                                                            const double *__restrict__ Xsc, int N, LsArgsI8 ls,
                                                            const double *__restrict__ alpha, char *__restrict__ A8,
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void kstar_slices_kernel(const double *__restr
 #pragma unroll 1
     for (int g16 = 0; g16 < KS_SLICE / 16; ++g16) {
         const int n0 = nb + g16 * 16;
-        unsigned out[NSA][4];
+        unsigned out[NA][4];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             double z[4];
@@ -240,12 +242,12 @@ __global__ __launch_bounds__(256) void kstar_slices_kernel(const double *__restr
             unsigned P[NSA];
             digits4_k(z, P);
 #pragma unroll
-            for (int a = 0; a < NSA; ++a) out[a][q4] = P[a];
+            for (int a = 0; a < NA; ++a) out[a][q4] = P[a];
         }
         const int kb = n0 >> 5, kg = (n0 >> 4) & 1;
-        char *base = A8 + (((int64_t)kb * RT + (c >> 5)) * NSA) * FRAG + kg * 512 + (int)(c & 31) * 16;
+        char *base = A8 + (((int64_t)kb * RT + (c >> 5)) * NA) * FRAG + kg * 512 + (int)(c & 31) * 16;
 #pragma unroll
-        for (int a = 0; a < NSA; ++a) {
+        for (int a = 0; a < NA; ++a) {
             const i4_t v = {(int)out[a][0], (int)out[a][1], (int)out[a][2], (int)out[a][3]};
             if (NT) __builtin_nontemporal_store(v, reinterpret_cast<i4_t *>(base + a * FRAG));
             else *reinterpret_cast<i4_t *>(base + a * FRAG) = v;
@@ -594,6 +596,179 @@ __global__ __launch_bounds__(512) void sigma_i8_kernel(
     }
 }
 
+// ---- coarse screen: three digits per operand, three diagonals ------------------------------------------------------------
+// The screen in front of rescore.hip does not need a 1e-10 variance: the arg-max is decided in fp64 among the candidates
+// whose interval [acq(var - tau), acq(var + tau)] reaches the best lower bound, and on the benchmark problem a tau of
+// 1e-3 still leaves a handful of candidates per 2^16 (tools/ozaki_error.py + DESIGN 4c).  Keeping the three leading
+// digits of both operands (k to 2^-23, U to 2^(e_j - 23): the leading digits of a balanced representation ARE the
+// round-to-nearest truncation) and the diagonals a + b <= 2 is SIX slice products instead of twenty:
+//     |dsigma^2| <= 1.9e-4 at N = 4096 ("sk=3 su=3 keep=3"), tau is checked on every call like the other screens'.
+// Three int32 accumulator sets leave room for a 256 x 128 block tile (wave tile 64 x 64 = 2 x 2 MFMA tiles x 3 = 192
+// registers): a stage (32 k) is 24 KiB of K* + 12 KiB of U (slices 0-2 of the six that gpbo_prepare_i8 stores) for
+// 6 x 8 x 4 = 192 MFMAs - 18 KiB per 128 x 128 x 32 of the product instead of 44, which is what the full pass is bound by.
+// Ring of four stages (144 KiB): two whole stages are in flight behind the one being consumed.
+constexpr int CNA = 3;                         // digits of K* the coarse pass stores and reads
+constexpr int CND = 3;                         // diagonals kept = digits of U read
+constexpr int CBM = 256, CBN = 128;
+constexpr int CA_PIECES = (CBM / 32) * CNA;    // 24
+constexpr int CB_PIECES = (CBN / 32) * CND;    // 12
+constexpr int CPIECES = CA_PIECES + CB_PIECES; // 36: waves 0-3 issue 5 per stage, waves 4-7 issue 4
+constexpr int CSTAGE = CPIECES * FRAG;         // 36 KiB
+constexpr int CRING = 4;
+
+__global__ __launch_bounds__(512) void sigma_i8c_kernel(const char *__restrict__ A8, int64_t RT, const char *__restrict__ U8,
+                                                        int Np, const double *__restrict__ colscale, int64_t ldk, int G,
+                                                        int nblk, double *__restrict__ ss_part /* [G x ldk] */) {
+    __shared__ __attribute__((aligned(16))) char smem[CRING * CSTAGE];
+    int tile = blockIdx.x, grp = 0;   // column groups exactly as in sigma_i8_kernel
+    if (G > 1) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int q = slot / G;
+        grp = slot - q * G;
+        tile = q * 8 + xcd;
+        if (tile >= nblk) return;
+    }
+    auto jb_of = [&](int r) { return r * G + ((r & 1) ? (G - 1 - grp) : grp); };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid & 3, wq = wid >> 2;   // 4 row groups of 64 candidates x 2 column groups of 64 columns
+    const int CT = Np >> 5;
+    const int nJ = Np / CBN;
+    const int lane16 = lane * 16;
+    const bool five = wid < 4;               // this wave has a fifth DMA piece (32 + wid < 36)
+
+    const char *a0p = A8 + ((int64_t)tile * (CBM / 32) * CNA) * FRAG;
+    const int64_t a_step = RT * CNA * FRAG, b_step = (int64_t)CT * NS * FRAG;
+    int pr = 0, pj = jb_of(0), pk = 0, pbuf = 0;
+    const char *pa = a0p, *pb = U8 + ((int64_t)pj * (CBN / 32) * NS) * FRAG;
+    // DMA pieces of a stage: piece p = wid + 8 q of the 36 (24 of K*, then 12 of U; the LDS image is in the same order), so
+    // q = 0..2 are always K* pieces, q = 3 is U piece `wid`, q = 4 is U piece 8 + wid for waves 0-3 (no branches on p)
+    const int j3 = wid, j4 = 8 + (wid & 3);
+    const int boff3 = ((j3 / CND) * NS + (j3 % CND)) * FRAG + lane16, boff4 = ((j4 / CND) * NS + (j4 % CND)) * FRAG + lane16;
+    const int aoff = wid * FRAG + lane16;
+    auto stage_issue = [&]() {   // all of this wave's pieces of the next stage, then advance the iterator
+        char *dst = smem + pbuf * CSTAGE + wid * FRAG;
+        glds16b(pa + aoff, dst);
+        glds16b(pa + aoff + 8 * FRAG, dst + 8 * FRAG);
+        glds16b(pa + aoff + 16 * FRAG, dst + 16 * FRAG);
+        glds16b(pb + boff3, dst + 24 * FRAG);
+        if (five) glds16b(pb + boff4, dst + 32 * FRAG);
+        pbuf = (pbuf == CRING - 1) ? 0 : pbuf + 1;
+        if (++pk == (pj + 1) * (CBN / BK)) {
+            pj = jb_of(++pr);
+            pk = 0;
+            pa = a0p;
+            pb = U8 + ((int64_t)pj * (CBN / 32) * NS) * FRAG;
+        } else {
+            pa += a_step;
+            pb += b_step;
+        }
+    };
+    // own pieces of every stage but the youngest `younger` ones have landed (counted: loads return in order)
+    auto wait_own = [&](int younger) {
+        if (younger >= 2) {
+            if (five) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        } else if (younger == 1) {
+            if (five) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+    };
+
+    i16_t acc[CND][2][2];   // [diagonal][row tile][column tile]
+#pragma unroll
+    for (int g = 0; g < CND; ++g)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][t][u][r] = 0;
+    double ssrow = 0.0;
+
+    int ahead = 0;   // stages issued beyond the one about to be consumed
+    stage_issue();
+    if (pj < nJ) { stage_issue(); ++ahead; }
+    if (pj < nJ) { stage_issue(); ++ahead; }
+    int cur = 0;
+
+    for (int rr = 0, jb = jb_of(0); jb < nJ; jb = jb_of(++rr)) {
+        const int c0 = jb * (CBN / 32) + wq * 2;   // this wave's first 32-column tile of V
+        const int nkb = (jb + 1) * (CBN / BK);
+        for (int kb = 0; kb < nkb; ++kb) {
+            wait_own(ahead);
+            __builtin_amdgcn_s_barrier();   // stage `cur` is complete for everyone; everyone has left the previous stage
+            if (pj < nJ) stage_issue();     // into the buffer of the previous stage
+            else if (ahead > 0) --ahead;
+            const char *As = smem + cur * CSTAGE + (2 * wr) * CNA * FRAG + lane16;
+            const char *Bs = smem + cur * CSTAGE + (CA_PIECES + (2 * wq) * CND) * FRAG + lane16;
+            i4_t af[2][CNA], bf[2][CND];
+#pragma unroll
+            for (int i = 0; i < CNA; ++i) {   // in the order the products below consume them
+                bf[0][i] = *reinterpret_cast<const i4_t *>(Bs + i * FRAG);
+                bf[1][i] = *reinterpret_cast<const i4_t *>(Bs + (CND + i) * FRAG);
+                af[0][i] = *reinterpret_cast<const i4_t *>(As + i * FRAG);
+                af[1][i] = *reinterpret_cast<const i4_t *>(As + (CNA + i) * FRAG);
+            }
+#define CMM(i, j, t, u) \
+    acc[(i) + (j)][t][u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[t][i], bf[u][j], acc[(i) + (j)][t][u], 0, 0, 0)
+#define CMM4(i, j) do { CMM(i, j, 0, 0); CMM(i, j, 0, 1); CMM(i, j, 1, 0); CMM(i, j, 1, 1); } while (0)
+            // no skipping of the k tiles below a column tile's diagonal (at most 3 of the 4 (jb + 1) stages of a column
+            // block, 2 % of the products): their U digits are stored as zeros, and this kernel is not bound by the MFMAs
+            CMM4(0, 0); CMM4(0, 1); CMM4(1, 0); CMM4(1, 1); CMM4(0, 2); CMM4(2, 0);
+#undef CMM4
+#undef CMM
+            cur = (cur == CRING - 1) ? 0 : cur + 1;
+        }
+        // column block finished: v = 2^e_j (2^-12 G_0 + 2^-20 G_1 + 2^-28 G_2), squared and summed over the wave's 64 columns
+        const double cs0 = colscale[c0 * 32 + (lane & 31)], cs1 = colscale[(c0 + 1) * 32 + (lane & 31)];
+        double x[32];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double v0 = (double)acc[2][t][0][r] * 0x1p-28;
+                v0 = fma((double)acc[1][t][0][r], 0x1p-20, v0);
+                v0 = fma((double)acc[0][t][0][r], 0x1p-12, v0);
+                v0 *= cs0;
+                double v1 = (double)acc[2][t][1][r] * 0x1p-28;
+                v1 = fma((double)acc[1][t][1][r], 0x1p-20, v1);
+                v1 = fma((double)acc[0][t][1][r], 0x1p-12, v1);
+                v1 *= cs1;
+                x[t * 16 + r] = fma(v1, v1, v0 * v0);
+#pragma unroll
+                for (int g = 0; g < CND; ++g) { acc[g][t][0][r] = 0; acc[g][t][1][r] = 0; }
+            }
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {   // butterfly over the 32 lanes of a half wave (see sigma_i8_kernel)
+            const int half = 16 >> s;
+            const bool up = (lane >> s) & 1;
+#pragma unroll
+            for (int q = 0; q < half; ++q) {
+                const double keep = up ? x[q + half] : x[q];
+                const double send = up ? x[q] : x[q + half];
+                x[q] = keep + __shfl_xor(send, 1 << s);
+            }
+        }
+        ssrow += x[0];
+    }
+
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(smem);  // [2][CBM]
+    {
+        const int Q = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+        const int t = Q >> 4, r = Q & 15;
+        const int row = wr * 64 + t * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        red[wq * CBM + row] = ssrow;
+    }
+    __syncthreads();
+    if (tid < CBM) ss_part[(int64_t)grp * ldk + (int64_t)tile * CBM + tid] = red[tid] + red[CBM + tid];
+}
+
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct LayoutI8 {
@@ -673,12 +848,12 @@ extern "C" int64_t gpbo_posterior_workspace_bytes_i8(int64_t Np, int64_t chunk, 
     return layout_i8(Np, chunk, M).total;
 }
 
-extern "C" int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
-                                     const double *ls_host, const void *u8, const double *alpha, double prior_var,
-                                     int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk,
-                                     double *mu_out, double *sigma_out, double *acq_out, double *var_out,
-                                     gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof,
-                                     void *stream) {
+namespace {
+int posterior_i8_impl(bool coarse, const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                      const double *ls_host, const void *u8, const double *alpha, double prior_var, int32_t acq_kind,
+                      double p0, double p1, int64_t idx_offset, int64_t chunk, double *mu_out, double *sigma_out,
+                      double *acq_out, double *var_out, gpbo_result *result, void *work, int64_t work_bytes,
+                      gpbo_profile *prof, void *stream) {
     if (!Xs || !X || !u8 || !alpha || !result || !work || !ls_host) return GPBO_ERR_ARG;
     if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || Np > GPBO_I8_MAX_N || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
     if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
@@ -719,12 +894,15 @@ extern "C" int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *
         // fragments of whole 128-candidate blocks are read by the variance kernel: build them for every block touched
         const int64_t used = (Mc + 255) / 256 * 256;
         dim3 kgrid((unsigned)(used / 256), (unsigned)(Np / KS_SLICE));
-        const bool nt = Np * chunk * NSA > ((int64_t)1 << 30);
+        const bool nt = Np * chunk * (coarse ? CNA : NSA) > ((int64_t)1 << 30);
+#define CALL1(DD, NTT, NAA)                                                                                               \
+    hipLaunchKernelGGL((kstar_slices_kernel<DD, NTT, NAA>), kgrid, dim3(256), 0, st, Xs + s * d, Mc, Xsc, (int)N, ls, alpha,  \
+                       A8, RT, mu_part, chunk)
 #define CALL(DD)                                                                                                          \
-    if (nt) hipLaunchKernelGGL((kstar_slices_kernel<DD, true>), kgrid, dim3(256), 0, st, Xs + s * d, Mc, Xsc, (int)N, ls,     \
-                               alpha, A8, RT, mu_part, chunk);                                                            \
-    else hipLaunchKernelGGL((kstar_slices_kernel<DD, false>), kgrid, dim3(256), 0, st, Xs + s * d, Mc, Xsc, (int)N, ls,       \
-                            alpha, A8, RT, mu_part, chunk)
+    do {                                                                                                                  \
+        if (coarse) { if (nt) CALL1(DD, true, CNA); else CALL1(DD, false, CNA); }                                         \
+        else { if (nt) CALL1(DD, true, NSA); else CALL1(DD, false, NSA); }                                                \
+    } while (0)
         switch (d) {
             case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;   case 4: CALL(4); break;
             case 5: CALL(5); break;   case 6: CALL(6); break;   case 7: CALL(7); break;   case 8: CALL(8); break;
@@ -733,12 +911,25 @@ extern "C" int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *
             default: return GPBO_ERR_ARG;
         }
 #undef CALL
+#undef CALL1
         const int64_t nblk = (Mc + BM - 1) / BM;
         if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
         const int G = i8_groups(Np);
         int64_t nparts_here = nblk;
-        if (G > 1) {
+        if (coarse) {   // 256-row tiles, partial sums always finished by split_finish_kernel
+            double *ss_part = reinterpret_cast<double *>(w + L.ssp_off);
+            const int64_t nblk_c = (Mc + CBM - 1) / CBM;
+            const int64_t grid = (G > 1) ? (nblk_c + 7) / 8 * 8 * G : nblk_c;
+            hipLaunchKernelGGL(sigma_i8c_kernel, dim3((unsigned)grid), dim3(512), 0, st, A8, RT, U8, (int)Np, colscale, chunk, G,
+                               (int)nblk_c, ss_part);
+            nparts_here = nblk_c;
+            int rc2 = gpbo_launch_split_finish(ss_part, G, chunk, mu_part, (int)(Np / KS_SLICE), Mc, prior_var, acq_kind, p0, p1,
+                                               idx_offset + s, mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
+                                               acq_out ? acq_out + s : nullptr, var_out ? var_out + s : nullptr,
+                                               part_val + nparts, part_idx + nparts, nan_count, st);
+            if (rc2 != GPBO_OK) return rc2;
+        } else if (G > 1) {
             double *ss_part = reinterpret_cast<double *>(w + L.ssp_off);
             const int64_t grid = (nblk + 7) / 8 * 8 * G;
             hipLaunchKernelGGL(sigma_i8_kernel, dim3((unsigned)grid), dim3(512), 0, st, A8, RT, U8, (int)Np, colscale, mu_part,
@@ -769,4 +960,25 @@ extern "C" int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *
         nparts += nparts_here;
     }
     return gpbo_launch_argmax_finish(part_val, part_idx, nparts, nan_count, result, st);
+}
+}  // namespace
+
+extern "C" int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                                     const double *ls_host, const void *u8, const double *alpha, double prior_var,
+                                     int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk,
+                                     double *mu_out, double *sigma_out, double *acq_out, double *var_out,
+                                     gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof,
+                                     void *stream) {
+    return posterior_i8_impl(false, Xs, M, X, N, Np, d, ls_host, u8, alpha, prior_var, acq_kind, p0, p1, idx_offset, chunk,
+                             mu_out, sigma_out, acq_out, var_out, result, work, work_bytes, prof, stream);
+}
+
+extern "C" int gpbo_posterior_acq_i8c(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                                      const double *ls_host, const void *u8, const double *alpha, double prior_var,
+                                      int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk,
+                                      double *mu_out, double *sigma_out, double *acq_out, double *var_out,
+                                      gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof,
+                                      void *stream) {
+    return posterior_i8_impl(true, Xs, M, X, N, Np, d, ls_host, u8, alpha, prior_var, acq_kind, p0, p1, idx_offset, chunk,
+                             mu_out, sigma_out, acq_out, var_out, result, work, work_bytes, prof, stream);
 }

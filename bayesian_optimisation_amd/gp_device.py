@@ -371,6 +371,7 @@ class DeviceGP:
         return self
 
     SCREEN_TAU0_I8 = 1e-9       # int8-sliced screen: |var64 - var_i8| is ~1e-11; checked per call like the fp32 one
+    SCREEN_TAU0_I8C = 1e-3      # coarse int8 screen (three digits per operand): |var64 - var| ~ 2e-4 at N = 4096
 
     def _score_screened(self, mode, Xs, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var):
         """A reduced-cost pass over all rows of Xs (mode "f32": fp32 matrix cores; "i8": int8 slices on the integer
@@ -397,7 +398,7 @@ class DeviceGP:
             return self.score_async(Xsd, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var)
         if mode == "f32" and (not getattr(self, "_u32_valid", False) or getattr(self, "U32", None) is None):
             self.prepare_f32()
-        if mode == "i8" and (not getattr(self, "_u8_valid", False) or getattr(self, "U8", None) is None):
+        if mode in ("i8", "i8c") and (not getattr(self, "_u8_valid", False) or getattr(self, "U8", None) is None):
             self.prepare_i8()
         with torch.cuda.device(self.device):
             if getattr(self, "_screen_mu", None) is None or self._screen_mu.numel() < M:
@@ -430,13 +431,14 @@ class DeviceGP:
                 _lib.check(st, "gpbo_posterior_acq_f32")
                 tau0 = float(self.SCREEN_TAU0)
             else:
-                st = self.lib.gpbo_posterior_acq_i8(
+                fn = self.lib.gpbo_posterior_acq_i8c if mode == "i8c" else self.lib.gpbo_posterior_acq_i8
+                st = fn(
                     self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d, lsp, self._ptr(self.U8),
                     self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), chunk, self._ptr(mu_w),
                     self._ptr(sigma), self._ptr(acq), self._ptr(self._screen_var), self._ptr(self._result),
                     self._ptr(self._work_screen), need, prof, self._stream())
-                _lib.check(st, "gpbo_posterior_acq_i8")
-                tau0 = float(self.SCREEN_TAU0_I8)
+                _lib.check(st, "gpbo_posterior_acq_" + mode)
+                tau0 = float(self.SCREEN_TAU0_I8C if mode == "i8c" else self.SCREEN_TAU0_I8)
             cap = self.screen_cap if self.screen_cap else max(4096, min(M, max(M // 16, 1 << 16)))
             chunk64 = self.SCREEN_CHUNK64
             rbytes = int(self.lib.gpbo_rescore_workspace_bytes(self.Np, cap, chunk64))
@@ -475,6 +477,18 @@ class DeviceGP:
 
     def score_i8(self, Xs, **kw) -> ScoreResult:
         res, mu, sigma, acq = self.score_async_i8(Xs, **kw)
+        v, i, n = self.read_result(res)
+        return ScoreResult(v, i, n, mu, sigma, acq)
+
+    def score_async_i8c(self, Xs, acquisition: str = "lcb", explore: float = 4.0, f_best: Optional[float] = None,
+                        xi: float = 0.0, dense: bool = False, idx_offset: int = 0, diag_add: float = 0.0,
+                        prior_var: float = PRIOR_VAR):
+        """Coarse int8 screen (three digits per operand, six slice products, |dsigma^2| ~ 2e-4) + fp64 decision: the
+        cheapest pass that still leaves only a handful of candidates for the fp64 kernels; see _score_screened."""
+        return self._score_screened("i8c", Xs, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var)
+
+    def score_i8c(self, Xs, **kw) -> ScoreResult:
+        res, mu, sigma, acq = self.score_async_i8c(Xs, **kw)
         v, i, n = self.read_result(res)
         return ScoreResult(v, i, n, mu, sigma, acq)
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPBO_VERSION 120 /* 0.2.0: fp32 screen + fp64 re-score (gpbo_rescore_f64), gpbo_posterior_acq_f32 changed */
+#define GPBO_VERSION 121 /* 0.2.0: fp32 screen + fp64 re-score (gpbo_rescore_f64), gpbo_posterior_acq_f32 changed */
 
 #define GPBO_OK 0
 #define GPBO_ERR_ARG (-1)      /* null pointer, bad size/alignment, unsupported d */
@@ -214,6 +214,14 @@ int gpbo_posterior_acq_i8(const double *Xs, int64_t M, const double *X, int64_t 
                           int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk, double *mu_out,
                           double *sigma_out, double *acq_out, double *var_out, gpbo_result *result, void *work,
                           int64_t work_bytes, gpbo_profile *prof /* or NULL */, void *stream);
+/* Coarse variant of the same screen: the three leading digits of both operands, SIX slice products, 256-row tiles
+ * (|dsigma^2| ~ 2e-4 at N = 4096: start gpbo_rescore_f64 with tau0 ~ 1e-3).  Same arguments, buffers and workspace
+ * size as gpbo_posterior_acq_i8 (it reads slices 0-2 of the same `u8`); the mean is still the fp64 path's. */
+int gpbo_posterior_acq_i8c(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                           const double *ls_host, const void *u8, const double *alpha, double prior_var,
+                           int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk, double *mu_out,
+                           double *sigma_out, double *acq_out, double *var_out, gpbo_result *result, void *work,
+                           int64_t work_bytes, gpbo_profile *prof /* or NULL */, void *stream);
 
 /* K7+K8 on a posterior already on the device: acq = LCB/EI of (mu, sigma), first-index arg-max
  * (point_selector.py:204-207).  Used for a second acquisition on the same surrogate.

@@ -1,5 +1,6 @@
 # timing of the int8-sliced screen at the headline shape (N=4096, d=8), 2^19 candidates, beside the fp64 kernels
-# modes: i8 (screen + fp64 decision), f64 (plain fp64 pass), i8raw (the int8 pass alone: gpbo_posterior_acq_i8 through ctypes)
+# modes: i8 (screen + fp64 decision), f64 (plain fp64 pass), i8raw (the int8 pass alone: gpbo_posterior_acq_i8 through ctypes),
+#        i8c / i8craw (the coarse three-digit screen, gpbo_posterior_acq_i8c)
 import ctypes as C
 import sys, time
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
@@ -15,7 +16,7 @@ gp = DeviceGP().factorise(X, y, ls)
 Xd = gp._dev(Xs)
 
 
-def i8raw(P):
+def i8raw(P, entry="gpbo_posterior_acq_i8"):
     if not getattr(gp, "_u8_valid", False):
         gp.prepare_i8()
         import os
@@ -26,7 +27,7 @@ def i8raw(P):
     if getattr(gp, "_w8", None) is None:
         gp._w8 = torch.empty(need // 8 + 1, dtype=torch.float64, device=gp.device)
         gp._v8 = torch.empty(m, dtype=torch.float64, device=gp.device)
-    st = gp.lib.gpbo_posterior_acq_i8(gp._ptr(P), m, gp._ptr(gp.X), gp.N, gp.Np, gp.d, gp.ls_h.ctypes.data_as(C.c_void_p),
+    st = getattr(gp.lib, entry)(gp._ptr(P), m, gp._ptr(gp.X), gp.N, gp.Np, gp.d, gp.ls_h.ctypes.data_as(C.c_void_p),
                                       gp._ptr(gp.U8), gp._ptr(gp.alpha), PRIOR_VAR, 0, 4.0, 0.0, 0, gp.chunk, None, None, None,
                                       gp._ptr(gp._v8), gp._ptr(gp._result), gp._ptr(gp._w8), need, None, gp._stream())
     _lib.check(st, "i8raw")
@@ -38,7 +39,8 @@ def i8raw(P):
 
 
 for name in modes:
-    fn = {"i8": gp.score_i8, "f64": gp.score, "i8raw": i8raw}[name]
+    fn = {"i8": gp.score_i8, "f64": gp.score, "i8raw": i8raw, "i8c": gp.score_i8c,
+          "i8craw": lambda P: i8raw(P, "gpbo_posterior_acq_i8c")}[name]
     fn(Xd)
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(reps):

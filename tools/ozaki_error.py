@@ -66,6 +66,8 @@ def main():
     combos = [(5, 5, 5), (6, 6, 6), (5, 5, 6), (5, 5, 7), (5, 6, 6), (6, 5, 6), (5, 6, 7), (6, 5, 7)]
     if os.environ.get("OZAKI_BUILT_ONLY"):
         combos = [(5, 6, 6)]
+    if os.environ.get("OZAKI_COMBOS"):      # e.g. "3,3,3;3,4,4" = (digits of k, digits of U, diagonals kept)
+        combos = [tuple(int(t) for t in c.split(",")) for c in os.environ["OZAKI_COMBOS"].split(";")]
     for sk, su, keep in combos:
         Kint = np.rint(ks * 2.0 ** (8 * sk - 2)).astype(np.int64)
         Uint = np.rint(Us * 2.0 ** (8 * su - 2)).astype(np.int64)
