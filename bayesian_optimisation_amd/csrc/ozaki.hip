@@ -61,6 +61,14 @@ __device__ __forceinline__ void glds16b(const char *g, char *l) {
     __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)l, 16, 0, 0);
 }
 
+// The same DMA with the address as wave-uniform base (SGPR pair) + one 32-bit lane offset and the LDS destination as a
+// byte address for M0: no address VGPRs (the builtin form above costs a 64-bit VGPR address per piece, which sigma_i8c_kernel
+// cannot afford).  The compiler does not track M0 or the memory counter across this statement: a kernel that uses it issues
+// ALL its DMA this way and counts vmcnt itself.
+__device__ __forceinline__ void glds16b_s(const char *base, unsigned lane_off, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(base) : "memory");
+}
+
 // ---- exp(-t), t >= 0 (same algorithm as kernel_build.hip: 2^(n/32) table x degree-6 polynomial, <= 1 ulp) ----------
 __device__ const double kExp2TabI8[32] = {
     1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237,
@@ -614,13 +622,17 @@ constexpr int CA_PIECES = (CBM / 32) * CNA;    // 24
 constexpr int CB_PIECES = (CBN / 32) * CND;    // 12
 constexpr int CPIECES = CA_PIECES + CB_PIECES; // 36: waves 0-3 issue 5 per stage, waves 4-7 issue 4
 constexpr int CSTAGE = CPIECES * FRAG;         // 36 KiB
-constexpr int CRING = 4;
+#ifndef GPBO_I8C_RING
+#define GPBO_I8C_RING 4
+#endif
+constexpr int CRING = GPBO_I8C_RING;
 
 __global__ __launch_bounds__(512) void sigma_i8c_kernel(const char *__restrict__ A8, int64_t RT, const char *__restrict__ U8,
                                                         int Np, const double *__restrict__ colscale, int64_t ldk, int G,
                                                         int nblk, double *__restrict__ ss_part /* [G x ldk] */) {
-    __shared__ __attribute__((aligned(16))) char smem[CRING * CSTAGE];
-    int tile = blockIdx.x, grp = 0;   // column groups exactly as in sigma_i8_kernel
+    __shared__ __attribute__((aligned(16))) char smem[CRING * CSTAGE + 2 * FRAG];
+    char *scl = smem + CRING * CSTAGE;   // two 1-KiB buffers: the 128 column scales of a column block (by block parity)
+    int tile = blockIdx.x, grp = 0;      // column groups exactly as in sigma_i8_kernel
     if (G > 1) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int q = slot / G;
@@ -639,22 +651,42 @@ __global__ __launch_bounds__(512) void sigma_i8c_kernel(const char *__restrict__
     const int lane16 = lane * 16;
     const bool five = wid < 4;               // this wave has a fifth DMA piece (32 + wid < 36)
 
+#ifdef GPBO_I8C_DIAG_SAME_A   // timing-only diagnostic: every workgroup streams the same K* rows (L2 hits)
+    const char *a0p = A8;
+#else
     const char *a0p = A8 + ((int64_t)tile * (CBM / 32) * CNA) * FRAG;
+#endif
     const int64_t a_step = RT * CNA * FRAG, b_step = (int64_t)CT * NS * FRAG;
     int pr = 0, pj = jb_of(0), pk = 0, pbuf = 0;
     const char *pa = a0p, *pb = U8 + ((int64_t)pj * (CBN / 32) * NS) * FRAG;
     // DMA pieces of a stage: piece p = wid + 8 q of the 36 (24 of K*, then 12 of U; the LDS image is in the same order), so
     // q = 0..2 are always K* pieces, q = 3 is U piece `wid`, q = 4 is U piece 8 + wid for waves 0-3 (no branches on p)
+    // (addresses = wave-uniform base + one 32-bit lane offset: the scalar-base form of the DMA instruction, no address VGPRs)
     const int j3 = wid, j4 = 8 + (wid & 3);
-    const int boff3 = ((j3 / CND) * NS + (j3 % CND)) * FRAG + lane16, boff4 = ((j4 / CND) * NS + (j4 % CND)) * FRAG + lane16;
-    const int aoff = wid * FRAG + lane16;
-    auto stage_issue = [&]() {   // all of this wave's pieces of the next stage, then advance the iterator
-        char *dst = smem + pbuf * CSTAGE + wid * FRAG;
-        glds16b(pa + aoff, dst);
-        glds16b(pa + aoff + 8 * FRAG, dst + 8 * FRAG);
-        glds16b(pa + aoff + 16 * FRAG, dst + 16 * FRAG);
-        glds16b(pb + boff3, dst + 24 * FRAG);
-        if (five) glds16b(pb + boff4, dst + 32 * FRAG);
+    const int boff3 = ((j3 / CND) * NS + (j3 % CND)) * FRAG, boff4 = ((j4 / CND) * NS + (j4 % CND)) * FRAG;
+    const unsigned l16 = (unsigned)lane16;
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_t *)smem;
+#if defined(GPBO_I8C_DIAG_NO_DMA)   // timing-only diagnostics (wrong results; tools/build_variant.sh), never in the shipped library
+    constexpr bool kLoopDma = false;
+#else
+    constexpr bool kLoopDma = true;
+#endif
+    auto stage_issue = [&](bool dma) {   // all of this wave's pieces of the next stage, then advance the iterator
+        if (dma) {
+            // first stage of a column block: its 128 column scales (1 KiB) travel the same way, issued BEFORE the stage's
+            // pieces, so whoever has waited for the stage has them too.  (A global load in the epilogue would drain the
+            // whole DMA queue: the counter is shared.)  The extra piece only makes wave 4's counted waits stricter.
+            if (pk == 0 && wid == 4)
+                glds16b_s(reinterpret_cast<const char *>(colscale + (int64_t)pj * CBN), l16,
+                          lds0 + CRING * CSTAGE + (pr & 1) * FRAG);
+            const unsigned dst = lds0 + pbuf * CSTAGE + wid * FRAG;
+            const char *paw = pa + wid * FRAG;
+            glds16b_s(paw, l16, dst);
+            glds16b_s(paw + 8 * FRAG, l16, dst + 8 * FRAG);
+            glds16b_s(paw + 16 * FRAG, l16, dst + 16 * FRAG);
+            glds16b_s(pb + boff3, l16, dst + 24 * FRAG);
+            if (five) glds16b_s(pb + boff4, l16, dst + 32 * FRAG);
+        }
         pbuf = (pbuf == CRING - 1) ? 0 : pbuf + 1;
         if (++pk == (pj + 1) * (CBN / BK)) {
             pj = jb_of(++pr);
@@ -690,45 +722,93 @@ __global__ __launch_bounds__(512) void sigma_i8c_kernel(const char *__restrict__
                 for (int r = 0; r < 16; ++r) acc[g][t][u][r] = 0;
     double ssrow = 0.0;
 
-    int ahead = 0;   // stages issued beyond the one about to be consumed
-    stage_issue();
-    if (pj < nJ) { stage_issue(); ++ahead; }
-    if (pj < nJ) { stage_issue(); ++ahead; }
+    // ---- software pipeline -----------------------------------------------------------------------------------------
+    // The operands of stage t are in registers when its products start; the six products (four MFMAs each) are ordered
+    // so that operand registers die early,  (0,2) (0,1) | (1,1) (0,0) (1,0) (2,0),  and each dead fragment pair is
+    // refilled with stage t+1's at once - a whole product or more ahead of its first use.  One barrier per stage,
+    // after the second product: before it every wave has waited for its own pieces of stage t+1 (issued three stages
+    // ago) and has every operand of stage t in registers; after it stage t+1 is complete for everyone and the buffer
+    // of stage t is free for the DMA of stage t+4: three whole stages are in flight behind the one being consumed.
+    int ahead = 0;   // stages issued beyond the one in registers
+    stage_issue(true);
+    for (int q = 0; q < CRING - 1; ++q)
+        if (pj < nJ) { stage_issue(true); ++ahead; }
+    wait_own(ahead);
+    __builtin_amdgcn_s_barrier();
     int cur = 0;
-
-    for (int rr = 0, jb = jb_of(0); jb < nJ; jb = jb_of(++rr)) {
-        const int c0 = jb * (CBN / 32) + wq * 2;   // this wave's first 32-column tile of V
-        const int nkb = (jb + 1) * (CBN / BK);
-        for (int kb = 0; kb < nkb; ++kb) {
-            wait_own(ahead);
-            __builtin_amdgcn_s_barrier();   // stage `cur` is complete for everyone; everyone has left the previous stage
-            if (pj < nJ) stage_issue();     // into the buffer of the previous stage
-            else if (ahead > 0) --ahead;
-            const char *As = smem + cur * CSTAGE + (2 * wr) * CNA * FRAG + lane16;
-            const char *Bs = smem + cur * CSTAGE + (CA_PIECES + (2 * wq) * CND) * FRAG + lane16;
-            i4_t af[2][CNA], bf[2][CND];
+    i4_t af[2][CNA], bf[2][CND];
+    auto lds_a = [&](int buf, int i) {
+        const char *As = smem + buf * CSTAGE + (2 * wr) * CNA * FRAG + lane16;
+        af[0][i] = *reinterpret_cast<const i4_t *>(As + i * FRAG);
+        af[1][i] = *reinterpret_cast<const i4_t *>(As + (CNA + i) * FRAG);
+    };
+    auto lds_b = [&](int buf, int j) {
+        const char *Bs = smem + buf * CSTAGE + (CA_PIECES + (2 * wq) * CND) * FRAG + lane16;
+        bf[0][j] = *reinterpret_cast<const i4_t *>(Bs + j * FRAG);
+        bf[1][j] = *reinterpret_cast<const i4_t *>(Bs + (CND + j) * FRAG);
+    };
 #pragma unroll
-            for (int i = 0; i < CNA; ++i) {   // in the order the products below consume them
-                bf[0][i] = *reinterpret_cast<const i4_t *>(Bs + i * FRAG);
-                bf[1][i] = *reinterpret_cast<const i4_t *>(Bs + (CND + i) * FRAG);
-                af[0][i] = *reinterpret_cast<const i4_t *>(As + i * FRAG);
-                af[1][i] = *reinterpret_cast<const i4_t *>(As + (CNA + i) * FRAG);
-            }
+    for (int i = 0; i < CNA; ++i) { lds_b(0, i); lds_a(0, i); }
+
+#ifdef GPBO_I8C_DIAG_NO_MFMA   // timing-only diagnostic: one MFMA per product instead of four
+#define CMM(i, j, t, u) \
+    do { if ((t) + (u) == 0) acc[(i) + (j)][t][u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[t][i] + af[1][i], bf[u][j] + bf[1][j], acc[(i) + (j)][t][u], 0, 0, 0); } while (0)
+#else
 #define CMM(i, j, t, u) \
     acc[(i) + (j)][t][u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[t][i], bf[u][j], acc[(i) + (j)][t][u], 0, 0, 0)
+#endif
+    // No skipping of the k tiles below a column tile's diagonal (at most 3 of the 4 (jb + 1) stages of a column block, 2 %
+    // of the products): their U digits are stored as zeros, and this kernel is not bound by the MFMAs.
 #define CMM4(i, j) do { CMM(i, j, 0, 0); CMM(i, j, 0, 1); CMM(i, j, 1, 0); CMM(i, j, 1, 1); } while (0)
-            // no skipping of the k tiles below a column tile's diagonal (at most 3 of the 4 (jb + 1) stages of a column
-            // block, 2 % of the products): their U digits are stored as zeros, and this kernel is not bound by the MFMAs
-            CMM4(0, 0); CMM4(0, 1); CMM4(1, 0); CMM4(1, 1); CMM4(0, 2); CMM4(2, 0);
-#undef CMM4
-#undef CMM
-            cur = (cur == CRING - 1) ? 0 : cur + 1;
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    int blk = 0;   // column blocks finished by this workgroup (parity = scale buffer)
+    for (int rr = 0, jb = jb_of(0); jb < nJ; jb = jb_of(++rr)) {
+        const int nkb = (jb + 1) * (CBN / BK);
+        for (int kb = 0; kb < nkb; ++kb) {
+            const bool has_next = ahead > 0;
+            const int nxt = (cur == CRING - 1) ? 0 : cur + 1;
+            SB();
+            CMM4(0, 2);
+            CMM4(0, 1);
+            SB();
+            wait_own(has_next ? ahead - 1 : 0);
+            __builtin_amdgcn_s_barrier();
+            SB();
+            // stage t+4 goes into the buffer of stage t, all of this wave's pieces at once (one piece after each of the
+            // remaining products instead: 24.7 -> 24.9 ms per 2^19 candidates on the same box)
+            if (pj < nJ) stage_issue(kLoopDma);
+            else if (ahead > 0) --ahead;
+            SB();
+            if (has_next) lds_b(nxt, 2);
+            SB();
+            CMM4(1, 1);
+            SB();
+            if (has_next) lds_b(nxt, 1);
+            SB();
+            CMM4(0, 0);
+            SB();
+            if (has_next) lds_a(nxt, 0);
+            SB();
+            CMM4(1, 0);
+            SB();
+            if (has_next) lds_a(nxt, 1);
+            SB();
+            CMM4(2, 0);
+            SB();
+            if (has_next) { lds_a(nxt, 2); lds_b(nxt, 0); }
+            SB();
+            cur = nxt;
         }
-        // column block finished: v = 2^e_j (2^-12 G_0 + 2^-20 G_1 + 2^-28 G_2), squared and summed over the wave's 64 columns
-        const double cs0 = colscale[c0 * 32 + (lane & 31)], cs1 = colscale[(c0 + 1) * 32 + (lane & 31)];
-        double x[32];
+        // column block finished: v = 2^e_j (2^-12 G_0 + 2^-20 G_1 + 2^-28 G_2), squared and summed over the wave's 64
+        // columns.  Per row tile: 16 values per lane -> 1 by a butterfly over lane bits 0..3 (level s keeps the half of
+        // the values whose register-index bit 3 - s equals lane bit s), then lane bit 4 chooses the row tile.
+        const double *sc = reinterpret_cast<const double *>(scl + (blk & 1) * FRAG) + wq * 64 + (lane & 31);
+        const double cs0 = sc[0], cs1 = sc[32];
+        ++blk;
+        double y[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            double x[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 double v0 = (double)acc[2][t][0][r] * 0x1p-28;
@@ -739,29 +819,41 @@ __global__ __launch_bounds__(512) void sigma_i8c_kernel(const char *__restrict__
                 v1 = fma((double)acc[1][t][1][r], 0x1p-20, v1);
                 v1 = fma((double)acc[0][t][1][r], 0x1p-12, v1);
                 v1 *= cs1;
-                x[t * 16 + r] = fma(v1, v1, v0 * v0);
+                x[r] = fma(v1, v1, v0 * v0);
 #pragma unroll
                 for (int g = 0; g < CND; ++g) { acc[g][t][0][r] = 0; acc[g][t][1][r] = 0; }
             }
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {   // butterfly over the 32 lanes of a half wave (see sigma_i8_kernel)
-            const int half = 16 >> s;
-            const bool up = (lane >> s) & 1;
+            for (int s = 0; s < 4; ++s) {
+                const int half = 8 >> s;
+                const bool up = (lane >> s) & 1;
 #pragma unroll
-            for (int q = 0; q < half; ++q) {
-                const double keep = up ? x[q + half] : x[q];
-                const double send = up ? x[q] : x[q + half];
-                x[q] = keep + __shfl_xor(send, 1 << s);
+                for (int q = 0; q < half; ++q) {
+                    const double keep = up ? x[q + half] : x[q];
+                    const double send = up ? x[q] : x[q + half];
+                    x[q] = keep + __shfl_xor(send, 1 << s);
+                }
             }
+            y[t] = x[0];
         }
-        ssrow += x[0];
+        {
+            const bool up = (lane >> 4) & 1;
+            const double keep = up ? y[1] : y[0];
+            const double send = up ? y[0] : y[1];
+            ssrow += keep + __shfl_xor(send, 16);
+        }
     }
+#undef CMM4
+#undef CMM
+#undef SB
 
     __syncthreads();
     double *red = reinterpret_cast<double *>(smem);  // [2][CBM]
     {
-        const int Q = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
-        const int t = Q >> 4, r = Q & 15;
+        // the row this lane's sum belongs to: register index r = b0 b1 b2 b3 (lane bits, b0 most significant), row tile b4;
+        // 32 x 32 accumulator map: register r of lane l holds row 8 (r >> 2) + 4 (l >> 5) + (r & 3), column l & 31
+        const int r = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+        const int t = (lane >> 4) & 1;
         const int row = wr * 64 + t * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
         red[wq * CBM + row] = ssrow;
     }

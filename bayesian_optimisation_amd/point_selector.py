@@ -71,9 +71,9 @@ class PointSelector:
         self._device = device
         self._verbose = verbose
         self._shard = shard_candidates
-        if precision not in ("fp64", "fp32", "i8"):
-            raise ValueError("precision must be 'fp64' (reference arithmetic), 'fp32' or 'i8' (fp64 factorisation and "
-                             "decision, variance product screened in fp32 / in int8 slices)")
+        if precision not in ("fp64", "fp32", "i8", "i8c"):
+            raise ValueError("precision must be 'fp64' (reference arithmetic), 'fp32', 'i8' or 'i8c' (fp64 factorisation, "
+                             "means and decision; variance product screened in fp32 / in int8 slices / in three int8 digits)")
         self._precision = precision
         self._gp = None
         self._mu_dev = self._sigma_dev = None
@@ -155,8 +155,8 @@ class PointSelector:
         diag_add = JITTER_KERNEL if Xs.shape == X.shape else 0.0          # :173 shape-coincidence quirk
         world, rank = self._world()
         lo, hi = D.shard_bounds(M, world, rank)
-        if self._precision in ("fp32", "i8"):   # screened variance product (fp32: BASELINE config 4's mode), fp64 decision
-            score = gp.score_f32 if self._precision == "fp32" else gp.score_i8
+        if self._precision in ("fp32", "i8", "i8c"):   # screened variance product (fp32: BASELINE config 4's mode), fp64 decision
+            score = {"fp32": gp.score_f32, "i8": gp.score_i8, "i8c": gp.score_i8c}[self._precision]
             res = score(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
         else:
             res = gp.score(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)

@@ -35,6 +35,7 @@ sys.path.insert(0, REPO)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
 I8_MFMA_PEAK_TOPS = 5033.0  # v_mfma_i32_32x32x32_i8: 2048 int8 op/clk/SIMD x 1024 SIMDs x 2.4 GHz (2x the bf16 rate)
 I8_SLICE_PRODUCTS = 20     # int8 slice products per fp64-equivalent multiply-add (csrc/ozaki.hip)
+I8C_SLICE_PRODUCTS = 6     # the coarse screen: three digits per operand, diagonals a + b <= 2
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak = fp64 vector peak (half the 157.3 TF fp32 rate
 #                               listed in MI355X_MICROARCH.md; AMD data sheet value)
 HBM_PEAK_GBS = 8000.0
@@ -69,7 +70,7 @@ def parse_args(argv=None):
                     help="rehearsal only: initialise the process group and run the exchange step even at N=1")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher check (no GPU): every rank joins the process group, rank 0 prints n_gpus / ranks_seen")
-    ap.add_argument("--dtype", choices=["f64", "f32", "i8"], default="f64",
+    ap.add_argument("--dtype", choices=["f64", "f32", "i8", "i8c"], default="f64",
                     help="f32: fp64 factorisation, fp32 screening of all candidates + fp64 re-scoring of the survivors "
                          "(BASELINE configs[3] shape); i8: the same with the variance product from int8 slices on the "
                          "integer matrix cores (|dsigma| ~ 1e-10)")
@@ -191,7 +192,8 @@ def main():
 
     N, d = args.n_obs, args.d
     f32 = args.dtype == "f32"
-    i8 = args.dtype == "i8"
+    i8c = args.dtype == "i8c"
+    i8 = args.dtype == "i8" or i8c
     qei = args.acq == "qei"
     if qei and (f32 or i8 or args.m_per_gpu % 8):
         sys.exit("bench.py: --acq qei needs fp64 and a multiple of 8 candidates per GPU")
@@ -218,6 +220,8 @@ def main():
             return g.score_qei_async(P, Zd, f_best=f_best, xi=0.0, batch_offset=off // 8)
         if f32:
             return g.score_async_f32(P, idx_offset=off, **acq_kw)
+        if i8c:
+            return g.score_async_i8c(P, idx_offset=off, **acq_kw)
         if i8:
             return g.score_async_i8(P, idx_offset=off, **acq_kw)
         return g.score_async(P, idx_offset=off, **acq_kw)
@@ -281,13 +285,14 @@ def main():
             pass
         peak = FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS
         unit = "TFLOP/s"
-        if i8:  # algorithmic work of this kernel: 20 int8 slice products per multiply-add of the triangular product
-            flop_per_cand = I8_SLICE_PRODUCTS * float(N) * N
+        if i8:  # algorithmic work of this kernel: 20 (coarse: 6) int8 slice products per multiply-add of the triangular product
+            flop_per_cand = (I8C_SLICE_PRODUCTS if i8c else I8_SLICE_PRODUCTS) * float(N) * N
             achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
             peak, unit = I8_MFMA_PEAK_TOPS, "TOP/s (int8)"
         roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit=unit,
                         frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src,
-                        kernel={"f32": "sigma_acq_f32_kernel", "i8": "sigma_i8_kernel"}.get(args.dtype, "sigma_acq_kernel"),
+                        kernel={"f32": "sigma_acq_f32_kernel", "i8": "sigma_i8_kernel", "i8c": "sigma_i8c_kernel"}.get(
+                            args.dtype, "sigma_acq_kernel"),
                         launches=int(k_launches),
                         avg_launch_ms=round(k_avg_ms, 4), flop_per_candidate=flop_per_cand,
                         candidates_per_launch=cand_per_launch,
@@ -297,12 +302,12 @@ def main():
         ks_ms, ks_launches, ks_cands = gp.read_profile_kstar()
         if ks_launches:
             ks_avg = ks_ms / ks_launches
-            bytes_per_cand = {"f32": 4.0, "i8": 6.0}.get(args.dtype, 8.0) * N + 8.0 * d
+            bytes_per_cand = {"f32": 4.0, "i8": 5.0, "i8c": 3.0}.get(args.dtype, 8.0) * N + 8.0 * d
             gbs = bytes_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e9
             kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(gbs / HBM_PEAK_GBS, 4),
-                                  kernel={"f32": "kstar_mu_kernel<..., float>", "i8": "kstar_slices_kernel"}.get(
-                                      args.dtype, "kstar_mu_kernel"),
+                                  kernel={"f32": "kstar_mu_kernel<..., float>", "i8": "kstar_slices_kernel<..., 5>",
+                                          "i8c": "kstar_slices_kernel<..., 3>"}.get(args.dtype, "kstar_mu_kernel"),
                                   launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
                                   bytes_per_candidate=bytes_per_cand)
 
@@ -351,6 +356,22 @@ def main():
                 note="variance product = 20 exact int8 slice products on v_mfma_i32_32x32x32_i8 (|dsigma| ~ 1e-10 against "
                      "the fp64 kernels); means and the selected point are the fp64 kernels'; --dtype i8 times it as the "
                      "main workload")
+            # ... and with the coarse screen in front of the same fp64 decision (three digits per operand, six products)
+            gp.score_async_i8c(Xsd, **kw8)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for _ in range(reps2):
+                gp.factorise(Xd, yd, ls, check=False)
+                gp.prepare_i8()
+                gp.score_async_i8c(Xsd, **kw8)
+                v, i, n, info = D.allreduce_status(gp.status)
+            ms = (time.perf_counter() - t) / reps2 * 1e3
+            res["int8_coarse_screen_same_workload"] = dict(
+                value=(hi - lo) / (ms * 1e-3), unit="candidates/s", ms_per_step=ms, argmax_index=i,
+                argmax_matches_fp64=bool(i == best[1]), steps=reps2, screen=gp.last_screen,
+                note="screen = 6 int8 slice products (three leading digits of K* and U, |dsigma^2| ~ 2e-4, tolerance checked "
+                     "per call); every candidate whose interval reaches the best lower bound is re-scored by the fp64 "
+                     "kernels, which decide: same selected point; --dtype i8c times it as the main workload")
         g1 = os.path.join(REPO, "tests", "golden", "g1_m32.npz")
         if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb") and os.path.exists(g1):
             # BASELINE configs[0] (d=2, N=32, M=32x32 grid, 50x50 ARD search - the sizes the reference's DAG runs): the
@@ -407,6 +428,7 @@ def main():
                 (4096, 8, "f64", "ei"): "configs[2] (per-GPU shard), EI",
                 (8192, 16, "f32", "lcb"): "configs[3] (per-GPU shard)",
                 (4096, 8, "i8", "lcb"): "configs[2] (per-GPU shard), int8-sliced variance screen",
+                (4096, 8, "i8c", "lcb"): "configs[2] (per-GPU shard), coarse int8 variance screen",
                 (2048, 8, "f64", "qei"): "configs[4] (per-GPU shard)"}.get((N, d, args.dtype, args.acq), "custom")
     acq_txt = {"lcb": "LCB(explore=4) arg-max", "ei": "Expected Improvement (f_best=min y, xi=0) arg-max",
                "qei": "q=8 Monte-Carlo qEI (512 fixed base samples) arg-max over batches"}[args.acq]
@@ -420,7 +442,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"{cfg_name}: d={d}, N={N} Sobol observations, M={mtxt} "
                                     f"Sobol candidates per GPU, ARD-SE GP, {acq_txt}, "
-                                    f"{ {'f32': 'fp64 factorisation + fp32 screen + fp64 re-score of the survivors', 'i8': 'fp64 factorisation and means + int8-sliced variance screen + fp64 re-score of the survivors'}.get(args.dtype, 'fp64') }; "
+                                    f"{ {'f32': 'fp64 factorisation + fp32 screen + fp64 re-score of the survivors', 'i8': 'fp64 factorisation and means + int8-sliced variance screen + fp64 re-score of the survivors', 'i8c': 'fp64 factorisation and means + coarse int8 variance screen (three digits per operand, six slice products) + fp64 re-score of the survivors'}.get(args.dtype, 'fp64') }; "
                                     f"step = factorise + score all candidates + reduce"),
                        "candidates_total": M_total, "parallelism": f"candidate-sharded x{world}"},
             "ms_per_step_scoring_only": ms_score,
@@ -430,7 +452,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not qei:
             cb, idx_cpu, ns = cpu_baseline(X, y, Xs_local, ls, args.acq, args.cpu_seconds, args.cpu_sample, f_best,
                                            "f32" if f32 else "f64")
-            r = {"f32": gp.score_f32, "i8": gp.score_i8}.get(args.dtype, gp.score)(Xsd[:ns], **acq_kw)
+            r = {"f32": gp.score_f32, "i8": gp.score_i8, "i8c": gp.score_i8c}.get(args.dtype, gp.score)(Xsd[:ns], **acq_kw)
             cb["argmax_match_on_sample"] = bool(r.best_idx == idx_cpu)
             out["cpu_baseline"] = cb
         if f32 or i8:

@@ -18,7 +18,7 @@ def _bench(*flags):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["f64", "i8"])
+@pytest.mark.parametrize("dtype", ["f64", "i8", "i8c"])
 def test_two_self_launched_ranks_pick_the_point_one_rank_picks_over_the_same_candidates(dtype):
     common = ["--n-obs", "384", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--dtype", dtype]
     two = _bench("--gpus", "2", "--backend", "gloo", "--all-on-device", "0", "--m-per-gpu", "65536", *common)
@@ -42,6 +42,9 @@ def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
     assert c0["index_matches_reference"] is True and c0["cpu_port_index_matches"] is True and c0["ms_per_step"] < 50
     i8 = line["also"]["int8_sliced_same_workload"]
     assert i8["argmax_matches_fp64"] is True and not i8["screen"]["fallback"] and i8["value"] > line["value"]
+    c8 = line["also"]["int8_coarse_screen_same_workload"]
+    assert c8["argmax_matches_fp64"] is True and not c8["screen"]["fallback"] and c8["value"] > 2.0 * i8["value"]
+    assert c8["screen"]["mode"] == "i8c" and 4.0 * c8["screen"]["err_max"] <= c8["screen"]["tau"]
 
 
 @pytest.mark.gpu
@@ -50,3 +53,12 @@ def test_int8_sliced_mode_as_the_main_workload():
                   "--cpu-seconds", "3")
     assert line["dtype"] == "i8" and line["roofline"]["kernel"] == "sigma_i8_kernel" and 0.1 < line["roofline"]["frac"] <= 1.0
     assert line["cpu_baseline"]["argmax_match_on_sample"] is True and not line["screen"]["fallback"]
+
+
+@pytest.mark.gpu
+def test_coarse_int8_screen_as_the_main_workload():
+    line = _bench("--dtype", "i8c", "--n-obs", "1024", "--m-per-gpu", "262144", "--steps", "2", "--warmup", "1",
+                  "--cpu-seconds", "3", "--no-also")
+    assert line["dtype"] == "i8c" and line["roofline"]["kernel"] == "sigma_i8c_kernel" and 0.05 < line["roofline"]["frac"] <= 1.0
+    assert line["roofline"]["unit"].startswith("TOP/s") and line["cpu_baseline"]["argmax_match_on_sample"] is True
+    assert line["screen"]["mode"] == "i8c" and not line["screen"]["fallback"]
