@@ -18,8 +18,8 @@ src, out = sys.argv[1], sys.argv[2]
 N, d, dtype, cands = 4096, 8, "f64", 131072
 if len(sys.argv) > 4:
     N, d, dtype, cands = int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7])
-w = {"f32": 4, "i8": 5}.get(dtype, 8)   # bytes of K* per entry (int8: five slices)
-kern = {"f32": "sigma_acq_f32_kernel", "i8": "sigma_i8_kernel"}.get(dtype, "sigma_acq_kernel")
+w = {"f32": 4, "i8": 5, "i8c": 3}.get(dtype, 8)   # bytes of K* per entry (int8: five slices, coarse screen: three)
+kern = {"f32": "sigma_acq_f32_kernel", "i8": "sigma_i8_kernel", "i8c": "sigma_i8c_kernel"}.get(dtype, "sigma_acq_kernel")
 here = os.path.dirname(os.path.abspath(__file__))
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(here, f"{out}_kernel_stats.csv"))
 
@@ -29,7 +29,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
         k = k.split("(")[0].split("<")[0]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-keep = ("sigma_acq_kernel", "kstar_mu_kernel", "sigma_acq_f32_kernel", "sigma_i8_kernel", "kstar_slices_kernel",
+keep = ("sigma_acq_kernel", "kstar_mu_kernel", "sigma_acq_f32_kernel", "sigma_i8_kernel", "sigma_i8c_kernel", "kstar_slices_kernel",
         "split_finish_kernel", "u_slices_kernel", "u_colscale_kernel", "potrf_diag_kernel", "gemm_f64_kernel", "kxx_kernel", "utv_kernel",
         "uv_kernel")
 with open(os.path.join(here, f"{out}_pmc_summary.csv"), "w") as fo:

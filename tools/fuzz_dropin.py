@@ -114,7 +114,7 @@ while time.time() < t_end:
             quirk = 1e-4 if Xs.shape == X.shape else 0.0  # point_selector.py:173
             ys = max(1.0, float(np.abs(y).max()))
             top2 = np.sort(acq_o)[-2:] if M > 1 else np.array([-np.inf, acq_o[0]])
-            for route, var_tol in (("score_f32", 5e-3), ("score_i8", 1e-8)):
+            for route, var_tol in (("score_f32", 5e-3), ("score_i8", 1e-8), ("score_i8c", 1e-3)):
                 # screened modes (round 2): the mean is the fp64 kernels' (1e-9 |y| against the oracle as everywhere), the
                 # variance carries the screen's error, the selected point is decided in fp64
                 r = getattr(gp, route)(Xs, dense=True, diag_add=quirk)
