@@ -774,28 +774,32 @@ __global__ __launch_bounds__(512) void sigma_i8c_kernel(const char *__restrict__
             wait_own(has_next ? ahead - 1 : 0);
             __builtin_amdgcn_s_barrier();
             SB();
-            // stage t+4 goes into the buffer of stage t, all of this wave's pieces at once (one piece after each of the
-            // remaining products instead: 24.7 -> 24.9 ms per 2^19 candidates on the same box)
+            CMM4(1, 1);   // straight after the barrier: nothing but MFMAs between the release and the pipe's next work
+            SB();
+            // stage t+4 goes into the buffer of stage t, all of this wave's pieces at once.  Same-box A/B, ms per 2^19
+            // candidates: here 23.6; before the product above (the pipe idles while every wave issues DMA) 24.5; one piece
+            // after each of the remaining products 24.9; the two waves of a SIMD at different times (w: here, w + 4: two
+            // products later) 24.4
             if (pj < nJ) stage_issue(kLoopDma);
             else if (ahead > 0) --ahead;
             SB();
-            if (has_next) lds_b(nxt, 2);
-            SB();
-            CMM4(1, 1);
-            SB();
-            if (has_next) lds_b(nxt, 1);
+            // (after the last stage these fetch a buffer nobody fills any more: harmless, and unconditional loads let the
+            //  compiler count lgkmcnt instead of draining it at the loop head)
+            lds_b(nxt, 2);
+            lds_b(nxt, 1);
             SB();
             CMM4(0, 0);
             SB();
-            if (has_next) lds_a(nxt, 0);
+            lds_a(nxt, 0);
             SB();
             CMM4(1, 0);
             SB();
-            if (has_next) lds_a(nxt, 1);
+            lds_a(nxt, 1);
             SB();
             CMM4(2, 0);
             SB();
-            if (has_next) { lds_a(nxt, 2); lds_b(nxt, 0); }
+            lds_a(nxt, 2);
+            lds_b(nxt, 0);
             SB();
             cur = nxt;
         }
