@@ -44,6 +44,9 @@ __device__ __forceinline__ double gpbo_acquisition(int kind, double mu, double s
 }
 
 // launchers implemented in the individual .hip files (host side, enqueue only)
+int gpbo_kstar_mu_rows(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
+                       const double *ls_host, const double *alpha, double diag_add, int64_t cand_base, double *KsT,
+                       int64_t ldk, double *mu_part, int64_t store_rows, void *stream);
 int gpbo_kstar_mu_mixed(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
                         const double *ls_host, const double *alpha, double diag_add, int64_t cand_base, float *KsT,
                         int64_t ldk, double *mu_part, void *stream);
@@ -59,7 +62,8 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                                  const double *ls_host, const double *U, const double *alpha, double prior_var,
                                  int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset,
                                  int64_t chunk, double *mu_out, double *sigma_out, double *acq_out, gpbo_result *result,
-                                 void *work, int64_t work_bytes, gpbo_profile *prof, int split_max, void *stream);
+                                 void *work, int64_t work_bytes, gpbo_profile *prof, int split_max, int64_t n_prefix,
+                                 void *stream);
 #define GPBO_RESCORE_SPLIT_MAX 64
 int gpbo_potrf_batched(double *Ab, int64_t Ne, int nbf, int batch, double *dinv, int32_t *info, hipStream_t st);
 int gpbo_gemm_launch_tri(int transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,

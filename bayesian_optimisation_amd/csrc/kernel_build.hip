@@ -134,7 +134,10 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
                                                        const double *__restrict__ Xsc, int N, LsArgs ls,
                                                        const double *__restrict__ alpha, double diag_add,
                                                        int64_t cand_base, TK *__restrict__ KsT, int64_t ldk,
-                                                       double *__restrict__ mu_part) {
+                                                       double *__restrict__ mu_part,
+                                                       int store_rows /* rows n >= store_rows are not stored (multiple of 64):
+                                                                         the prefix-bound screen needs the mean of all N
+                                                                         observations but K*^T of the first few only */) {
     __shared__ double tab[32];
     if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
     const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
         nan_b = nan_b || (xb[k] != xb[k]);
     }
     TK *out = KsT + (int64_t)n0 * ldk + c0;
+    const bool do_store = n0 < store_rows;   // workgroup-uniform
     int nend = n0 + KS_SLICE;
     if (nend > N) nend = N;  // observations beyond N are padding: exact zeros, written below
     // two observations per trip: four independent distance/exp chains per thread (the loop is bound by the
@@ -187,8 +191,10 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
         mua = fma(k10, a1, mua);
         mub = fma(k11, a1, mub);
         if (VARIANT != 1) {
-            store_pair<NT>(out, k00, k01);
-            store_pair<NT>(out + ldk, k10, k11);
+            if (do_store) {
+                store_pair<NT>(out, k00, k01);
+                store_pair<NT>(out + ldk, k10, k11);
+            }
         } else {
             mua += (k00 + k10) * 1e-300;
             mub += (k01 + k11) * 1e-300;
@@ -212,12 +218,12 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
         const double an = alpha[n];
         mua = fma(ka, an, mua);
         mub = fma(kb, an, mub);
-        store_pair<NT>(out, ka, kb);
+        if (do_store) store_pair<NT>(out, ka, kb);
         out += ldk;
         ++n;
     }
     for (n = (nend > n0 ? nend : n0); n < n0 + KS_SLICE; ++n) {
-        store_pair<NT>(out, 0.0, 0.0);
+        if (do_store) store_pair<NT>(out, 0.0, 0.0);
         out += ldk;
     }
     d2_t m = {nan_a ? __builtin_nan("") : mua, nan_b ? __builtin_nan("") : mub};
@@ -313,7 +319,16 @@ extern "C" int gpbo_scale_points_f64(const double *X, int64_t N, int64_t Np, int
 extern "C" int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
                                  const double *ls_host, const double *alpha, double diag_add, int64_t cand_base,
                                  double *KsT, int64_t ldk, double *mu_part, void *stream) {
+    return gpbo_kstar_mu_rows(Xs, Mc, Xsc, N, Np, d, ls_host, alpha, diag_add, cand_base, KsT, ldk, mu_part, Np, stream);
+}
+
+// store_rows: only rows n < store_rows of K*^T are written (a multiple of 64; Np = everything); the mean partials always
+// cover all N observations.
+int gpbo_kstar_mu_rows(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
+                       const double *ls_host, const double *alpha, double diag_add, int64_t cand_base, double *KsT,
+                       int64_t ldk, double *mu_part, int64_t store_rows, void *stream) {
     if (!Xs || !Xsc || !alpha || !KsT || !mu_part) return GPBO_ERR_ARG;
+    if (store_rows < 0 || store_rows > Np || store_rows % KS_SLICE) return GPBO_ERR_ARG;
     if (Mc < 1 || N < 1 || Np < N || Np % 128 != 0 || ldk % GPBO_CHUNK_GRANULE != 0 || Mc > ldk)
         return GPBO_ERR_ARG;
     LsArgs ls;
@@ -328,10 +343,10 @@ extern "C" int gpbo_kstar_mu_f64(const double *Xs, int64_t Mc, const double *Xsc
 #else
     constexpr int variant = 0;
 #endif
-    const bool nt = (int64_t)sizeof(double) * Np * ldk > ((int64_t)1 << 30);  // slab beyond what the Infinity Cache keeps
+    const bool nt = (int64_t)sizeof(double) * store_rows * ldk > ((int64_t)1 << 30);  // slab beyond what the Infinity Cache keeps
 #define KSTAR_LAUNCH1(DD, V, H, NTF)                                                                                  \
     hipLaunchKernelGGL((kstar_mu_kernel<DD, V, H, double, NTF>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, Xsc, (int)N, \
-                       ls, alpha, diag_add, cand_base, KsT, ldk, mu_part)
+                       ls, alpha, diag_add, cand_base, KsT, ldk, mu_part, (int)store_rows)
 #define KSTAR_LAUNCH(DD, V, H) \
     do { if (nt) KSTAR_LAUNCH1(DD, V, H, true); else KSTAR_LAUNCH1(DD, V, H, false); } while (0)
 #ifdef GPBO_DIAGNOSTICS
@@ -368,13 +383,13 @@ int gpbo_kstar_mu_mixed(const double *Xs, int64_t Mc, const double *Xsc, int64_t
 #define CALL(DD)                                                                                                     \
     if (diag_add != 0.0)                                                                                             \
         hipLaunchKernelGGL((kstar_mu_kernel<DD, 0, true, float, false>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc,  \
-                           Xsc, (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part);                          \
+                           Xsc, (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part, (int)Np);                 \
     else if (nt)                                                                                                     \
         hipLaunchKernelGGL((kstar_mu_kernel<DD, 0, false, float, true>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc,  \
-                           Xsc, (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part);                          \
+                           Xsc, (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part, (int)Np);                 \
     else                                                                                                             \
         hipLaunchKernelGGL((kstar_mu_kernel<DD, 0, false, float, false>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, \
-                           Xsc, (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part)
+                           Xsc, (int)N, ls, alpha, diag_add, cand_base, KsT, ldk, mu_part, (int)Np)
     GPBO_DISPATCH_D(d, CALL)
 #undef CALL
     GPBO_CHECK_LAUNCH();

@@ -99,6 +99,49 @@ __global__ __launch_bounds__(SB) void screen_select_kernel(const double *__restr
     }
 }
 
+// Prefix-bound screen: survivors of a threshold on the UPPER bounds ub_c >= acq64_c (gpbo_posterior_prefix_f64), plus
+// every NaN (the fp64 pass must see and count it) and the strided sample.  `slack` absorbs the rounding of the two
+// different summation orders (the bound comes from the fused kernel, the exact value from the column-split launch).
+__global__ __launch_bounds__(SB) void bound_select_kernel(const double *__restrict__ ub, int64_t M, double thr, double slack,
+                                                          int64_t stride, int64_t *__restrict__ list, int64_t cap,
+                                                          unsigned long long *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t step = (int64_t)gridDim.x * SB;
+    const int64_t cmax = (M + step - 1) / step * step;  // whole waves stay in the loop together (ballot)
+    for (int64_t c = (int64_t)blockIdx.x * SB + threadIdx.x; c < cmax; c += step) {
+        bool keep = false;
+        if (c < M) keep = !(ub[c] + slack < thr) || (c % stride) == 0;  // !(x < thr): also true for NaN
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(m));
+            base = __shfl(base, 0);
+            if (keep) {
+                const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if ((int64_t)pos < cap) list[pos] = c;
+            }
+        }
+    }
+}
+
+// per-workgroup maximum of the bounds (NaNs skipped); screen_max_kernel finishes it
+__global__ __launch_bounds__(SB) void bound_max_kernel(const double *__restrict__ ub, int64_t M, double *__restrict__ part) {
+    __shared__ double s_val[SB / 64];
+    double best = -std::numeric_limits<double>::infinity();
+    for (int64_t c = (int64_t)blockIdx.x * SB + threadIdx.x; c < M; c += (int64_t)gridDim.x * SB) {
+        const double v = ub[c];
+        if (v > best) best = v;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) best = fmax(best, __shfl_xor(best, off));
+    if ((threadIdx.x & 63) == 0) s_val[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < SB / 64; ++w) best = fmax(best, s_val[w]);
+        part[blockIdx.x] = best;
+    }
+}
+
 __global__ __launch_bounds__(SB) void gather_rows_kernel(const double *__restrict__ Xs, int d, const int64_t *__restrict__ list,
                                                          int64_t K, double *__restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * SB + threadIdx.x;
@@ -130,8 +173,10 @@ __global__ __launch_bounds__(SB) void rescore_finish_kernel(const double *__rest
         const int64_t c = list[i];
         if (a != a) ++nans;
         else if (gpbo_better(a, idx_offset + c, bv, bi)) { bv = a; bi = idx_offset + c; }
-        const double e = fabs(sg * sg - fabs(var32[c]));
-        if (e > err) err = e;  // NaN never raises err; NaNs are reported through the count
+        if (var32) {
+            const double e = fabs(sg * sg - fabs(var32[c]));
+            if (e > err) err = e;  // NaN never raises err; NaNs are reported through the count
+        }
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -251,7 +296,7 @@ extern "C" int gpbo_rescore_f64(const double *Xs, int64_t M, const double *mu, c
         if (chunk > kpad) chunk = kpad;
         int rc = gpbo_posterior_acq_f64_split(rows, (int64_t)K, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1,
                                               0.0, 0, chunk, mu64, sig64, acq64, &out->res, post, L.post_bytes, nullptr,
-                                              GPBO_RESCORE_SPLIT_MAX, stream);
+                                              GPBO_RESCORE_SPLIT_MAX, 0, stream);
         if (rc != GPBO_OK) return rc;
         hipLaunchKernelGGL(rescore_finish_kernel, dim3(1), dim3(SB), 0, st, acq64, sig64, list, (int64_t)K, var32, idx_offset,
                            out);
@@ -269,6 +314,143 @@ extern "C" int gpbo_rescore_f64(const double *Xs, int64_t M, const double *mu, c
             return GPBO_OK;
         }
         tau = fmax(8.0 * h.err_max, 4.0 * tau);
+    }
+    stt.fallback = 1;
+    *stats_host = stt;
+    return GPBO_OK;
+}
+
+// Exact arg-max behind the prefix bound (the first pass: gpbo_posterior_prefix_f64, which leaves ub_c >= acq64_c for every
+// candidate).  Branch and bound, everything in fp64:
+//   round 0   the strided sample (and every NaN) goes through the fp64 kernels: its best value is a LOWER bound of the maximum;
+//   round r   every candidate whose upper bound reaches the best exact value seen so far survives; if the survivors fit `cap`
+//             they (and the sample) are re-scored and the maximum and its LOWEST index are taken over those fp64 values - a
+//             pruned candidate has acq64 <= ub < an exact value, so it is neither the maximum nor tied with it; otherwise the
+//             first `refine` survivors are re-scored to raise the threshold and the selection is repeated (at most 3 times).
+// When the survivors still do not fit (a flat mean, thousands of ties, an exploration weight that dwarfs the mean) the caller
+// is told to run the plain pass (stats->fallback).  stats: tau = the last threshold, err_max unused.
+extern "C" int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *ub, const double *X, int64_t N, int64_t Np,
+                                     int32_t d, const double *ls_host, const double *U, const double *alpha,
+                                     double prior_var, int32_t acq_kind, double p0, double p1, int64_t idx_offset,
+                                     int64_t sample_stride, int64_t cap, int64_t chunk64, gpbo_result *result,
+                                     gpbo_screen_stats *stats_host, void *work, int64_t work_bytes, void *stream) {
+    if (!Xs || !ub || !X || !U || !alpha || !result || !stats_host || !work) return GPBO_ERR_ARG;
+    if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || d < 1 || d > GPBO_MAX_D || cap < 1 || sample_stride < 1) return GPBO_ERR_ARG;
+    if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
+    if (acq_kind == GPBO_ACQ_LCB && !(p0 >= 0.0)) return GPBO_ERR_ARG;   // the bound needs an acquisition that increases with sigma
+    if (gpbo_posterior_workspace_bytes(Np, chunk64, cap) < 0 || ((uintptr_t)work & 255)) return GPBO_ERR_ARG;
+    const RescoreLayout L = rescore_layout(Np, cap, chunk64);
+    if (work_bytes < L.total) return GPBO_ERR_WORKSPACE;
+    hipStream_t st = gpbo_stream(stream);
+    char *w = reinterpret_cast<char *>(work);
+    unsigned long long *count = reinterpret_cast<unsigned long long *>(w + L.count_off);
+    RescoreOut *out = reinterpret_cast<RescoreOut *>(w + L.out_off);
+    int64_t *list = reinterpret_cast<int64_t *>(w + L.list_off);
+    double *rows = reinterpret_cast<double *>(w + L.rows_off);
+    double *mu64 = reinterpret_cast<double *>(w + L.mu_off);
+    double *sig64 = reinterpret_cast<double *>(w + L.sig_off);
+    double *acq64 = reinterpret_cast<double *>(w + L.acq_off);
+    void *post = w + L.post_off;
+    int64_t nblk = (M + SB - 1) / SB;
+    if (nblk > SCREEN_BLOCKS) nblk = SCREEN_BLOCKS;
+    const double inf = std::numeric_limits<double>::infinity();
+    gpbo_screen_stats stt = {0, 0, 0, 0, 0.0, 0.0};
+
+    // exact fp64 values of the first K entries of `list`; their arg-max (lowest original index) lands in *out
+    auto exact = [&](int64_t K, RescoreOut *h) -> int {
+        const int64_t tot = K * d;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((tot + SB - 1) / SB)), dim3(SB), 0, st, Xs, (int)d, list, K, rows);
+        GPBO_CHECK_LAUNCH();
+        int64_t chunk = chunk64;
+        const int64_t kpad = (K + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
+        if (chunk > kpad) chunk = kpad;
+        int rc = gpbo_posterior_acq_f64_split(rows, K, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1, 0.0, 0,
+                                              chunk, mu64, sig64, acq64, &out->res, post, L.post_bytes, nullptr,
+                                              GPBO_RESCORE_SPLIT_MAX, 0, stream);
+        if (rc != GPBO_OK) return rc;
+        hipLaunchKernelGGL(rescore_finish_kernel, dim3(1), dim3(SB), 0, st, acq64, sig64, list, K, (const double *)nullptr,
+                           idx_offset, out);
+        GPBO_CHECK_LAUNCH();
+        if (hipMemcpyAsync(h, out, sizeof(*h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
+        stt.rescored += K;
+        ++stt.rounds;   // = launches of the fp64 kernels on gathered rows
+        return GPBO_OK;
+    };
+    auto select = [&](double thr, unsigned long long *K) -> int {
+        if (hipMemsetAsync(count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
+        const double slack = (thr == inf) ? 0.0 : 1e-10 * fmax(1.0, fabs(thr));
+        hipLaunchKernelGGL(bound_select_kernel, dim3((unsigned)nblk), dim3(SB), 0, st, ub, M, thr, slack, sample_stride, list, cap,
+                           count);
+        GPBO_CHECK_LAUNCH();
+        if (hipMemcpyAsync(K, count, sizeof(*K), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
+        return GPBO_OK;
+    };
+
+    RescoreOut h;
+    unsigned long long K = 0;
+    int rc = select(inf, &K);   // the sample and the NaNs
+    if (rc != GPBO_OK) return rc;
+    stt.survivors = (int64_t)K;
+    if ((int64_t)K > cap) { stt.fallback = 1; *stats_host = stt; return GPBO_OK; }
+    rc = exact((int64_t)K, &h);
+    if (rc != GPBO_OK) return rc;
+    double thr = h.res.best_val;   // -inf when every sampled acquisition is NaN: everything survives
+    // A sample's best value is far below the maximum (the 99.9th percentile of the acquisition), and every candidate whose
+    // bound lies above it would be re-scored.  The candidates with the LARGEST bounds are the likely winners: bisect for a
+    // level that keeps about a thousand of them, re-score those, and let their best exact value be the threshold.
+    {
+        double *part = reinterpret_cast<double *>(w + L.part_off);
+        double *Ldev = reinterpret_cast<double *>(w + L.L_off);
+        hipLaunchKernelGGL(bound_max_kernel, dim3((unsigned)nblk), dim3(SB), 0, st, ub, M, part);
+        hipLaunchKernelGGL(screen_max_kernel, dim3(1), dim3(SB), 0, st, part, (int)nblk, Ldev, count);
+        GPBO_CHECK_LAUNCH();
+        double ub_max = 0.0;
+        if (hipMemcpyAsync(&ub_max, Ldev, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
+        const int64_t want_hi = cap < 4096 ? cap : 4096, want_lo = want_hi / 8;
+        if (thr > -inf && ub_max > thr && ub_max < inf) {
+            double lo = thr, hi = ub_max, level = thr;
+            bool found = false;
+            for (int it = 0; it < 24 && !found; ++it) {
+                const double mid = 0.5 * (lo + hi);
+                if (!(mid > lo) || !(mid < hi)) break;
+                rc = select(mid, &K);   // (list positions beyond cap are not written; the count is exact)
+                if (rc != GPBO_OK) return rc;
+                // the strided sample is always in the list: count it out
+                const int64_t above = (int64_t)K - (M + sample_stride - 1) / sample_stride;
+                if (above > want_hi) lo = mid;
+                else if (above < want_lo) hi = mid;
+                else { level = mid; found = true; }
+            }
+            if (found && (int64_t)K <= cap) {   // the list of the last select() is the one of `level`
+                rc = exact((int64_t)K, &h);
+                if (rc != GPBO_OK) return rc;
+                if (h.res.best_val > thr) thr = h.res.best_val;
+            }
+        }
+    }
+    const int64_t refine = cap < 4096 ? cap : 4096;
+    for (int round = 1; round <= 4; ++round) {
+        stt.tau = thr;
+        rc = select(thr, &K);
+        if (rc != GPBO_OK) return rc;
+        stt.survivors = (int64_t)K;
+        if ((int64_t)K <= cap) {
+            rc = exact((int64_t)K, &h);
+            if (rc != GPBO_OK) return rc;
+            if (hipMemcpyAsync(result, &out->res, sizeof(gpbo_result), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return GPBO_ERR_LAUNCH;
+            *stats_host = stt;
+            return GPBO_OK;
+        }
+        if (round == 4) break;
+        rc = exact(refine, &h);   // some of the survivors: a better lower bound of the maximum
+        if (rc != GPBO_OK) return rc;
+        if (!(h.res.best_val > thr)) break;   // no progress: the bound does not separate these candidates
+        thr = h.res.best_val;
     }
     stt.fallback = 1;
     *stats_host = stt;

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
     double *__restrict__ vbuf /* optional [chunk x Np]: V = K* U itself, for the joint (qEI) posterior */,
     double *__restrict__ ss_part /* column-split launches (gridDim.y = S > 1): [S x ldk] partial |v|^2, no epilogue */,
     int xg /* > 1: one-dimensional launch, the xg column groups of a candidate tile 8 linear ids apart (same XCD) */,
-    int ntile) {
+    int ntile, int ncb /* > 0: only the first ncb column blocks of V (the prefix-bound screen: |v|^2 over the first
+                          128 ncb observations is a LOWER bound of |v|^2, the variance from it an upper bound) */) {
     __shared__ double smem[3 * STAGE];
     // Column split (few candidates, e.g. the re-scoring behind a screen): workgroup (x, s) of S takes the column
     // blocks s, 2S-1-s, 2S+s, 4S-1-s, ... (boustrophedon rounds: block jb costs jb+1 k tiles, so pairing a cheap
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
         for (int j = 0; j < 4; ++j) ss[i][j] = 0.0;
     }
 
-    const int nJ = Np / BN;
+    const int nJ = ncb > 0 ? ncb : Np / BN;
     // staging iterator: tile (pj, pk) goes to stage pbuf; pa / pb are its global bases
     int pr = 0, pj = jb_of(0), pk = 0, pbuf = 0;
     const double *pa = a_base, *pb = U + (int64_t)pj * BN;
@@ -707,7 +708,24 @@ extern "C" int gpbo_posterior_acq_f64(const double *Xs, int64_t M, const double 
                                       void *stream) {
     return gpbo_posterior_acq_f64_split(Xs, M, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1, diag_add,
                                         idx_offset, chunk, mu_out, sigma_out, acq_out, result, work, work_bytes, prof, 1,
-                                        stream);
+                                        0, stream);
+}
+
+// The prefix-bound screen's first pass (rescore.hip, gpbo_bound_select_f64): the mean over all N observations, the
+// variance product over the FIRST n_prefix columns of V only.  |v_c|^2 summed over a prefix of its components is a lower
+// bound of the whole sum, so sigma_out / acq_out hold UPPER bounds of the fp64 path's values (both acquisitions increase
+// with sigma; LCB only for explore >= 0).  K*^T is stored for the first n_prefix observations only.
+extern "C" int gpbo_posterior_prefix_f64(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                                         const double *ls_host, const double *U, const double *alpha, double prior_var,
+                                         int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk,
+                                         int64_t n_prefix, double *mu_out, double *sigma_ub_out, double *acq_ub_out,
+                                         gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof,
+                                         void *stream) {
+    if (n_prefix < BN || n_prefix % BN || n_prefix > Np) return GPBO_ERR_ARG;
+    if (acq_kind == GPBO_ACQ_LCB && !(p0 >= 0.0)) return GPBO_ERR_ARG;
+    return gpbo_posterior_acq_f64_split(Xs, M, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1, 0.0,
+                                        idx_offset, chunk, mu_out, sigma_ub_out, acq_ub_out, result, work, work_bytes,
+                                        prof, 1, n_prefix, stream);
 }
 
 int64_t gpbo_posterior_workspace_bytes_split(int64_t Np, int64_t chunk, int64_t M, int split_max) {
@@ -724,8 +742,10 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                                  const double *ls_host, const double *U, const double *alpha, double prior_var,
                                  int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset,
                                  int64_t chunk, double *mu_out, double *sigma_out, double *acq_out, gpbo_result *result,
-                                 void *work, int64_t work_bytes, gpbo_profile *prof, int split_max, void *stream) {
+                                 void *work, int64_t work_bytes, gpbo_profile *prof, int split_max,
+                                 int64_t n_prefix /* 0: everything; else see gpbo_posterior_prefix_f64 */, void *stream) {
     if (!Xs || !X || !U || !alpha || !result || !work) return GPBO_ERR_ARG;
+    if (n_prefix < 0 || n_prefix > Np || n_prefix % BN || (n_prefix && (split_max != 1 || diag_add != 0.0))) return GPBO_ERR_ARG;
     if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || Np > (1 << 20)) return GPBO_ERR_ARG;
     if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
     if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
@@ -785,8 +805,8 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
         } else if (prof && prof->count < prof->capacity) {
             prof->kmode[prof->count] = 0;
         }
-        int rc = gpbo_kstar_mu_f64(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT[b], chunk,
-                                   mu_part[b], ks);
+        int rc = gpbo_kstar_mu_rows(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT[b], chunk,
+                                    mu_part[b], n_prefix ? n_prefix : Np, ks);
         if (rc != GPBO_OK) return rc;
         if (hp && hipEventRecord(hp->kdone[b], ks) != hipSuccess) return GPBO_ERR_LAUNCH;
         return GPBO_OK;
@@ -815,12 +835,12 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
         // on the problem (N, candidates of the CALL), never on the chunking, so results stay chunk-size invariant bit for
         // bit.  GPBO_F64_GROUPS=1 switches it off (A/B runs).
         static const int xg_env = getenv("GPBO_F64_GROUPS") ? atoi(getenv("GPBO_F64_GROUPS")) : 8;
-        if (xg_env > 1 && S == 1 && M >= 32768 && Np / BN >= 2 * xg_env && xg_env <= 16) {
+        if (xg_env > 1 && S == 1 && M >= 32768 && Np / BN >= 2 * xg_env && xg_env <= 16 && n_prefix == 0) {
             const int64_t grid1 = (nblk + 7) / 8 * 8 * xg_env;
             hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)grid1), dim3(NW * 64), 0, st, KsT[b], chunk, U, (int)Np,
                                mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                                (double *)nullptr, (double *)nullptr, (double *)nullptr, part_val + nparts,
-                               part_idx + nparts, nan_count, (double *)nullptr, ss_part, xg_env, (int)nblk);
+                               part_idx + nparts, nan_count, (double *)nullptr, ss_part, xg_env, (int)nblk, 0);
             hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, xg_env, chunk, mu_part[b],
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                                mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
@@ -830,7 +850,7 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
             hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk, (unsigned)S), dim3(NW * 64), 0, st, KsT[b], chunk, U,
                                (int)Np, mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1,
                                idx_offset + s, (double *)nullptr, (double *)nullptr, (double *)nullptr, part_val + nparts,
-                               part_idx + nparts, nan_count, (double *)nullptr, ss_part, 1, (int)nblk);
+                               part_idx + nparts, nan_count, (double *)nullptr, ss_part, 1, (int)nblk, 0);
             hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, S, chunk, mu_part[b],
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                                mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
@@ -843,7 +863,7 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                        mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                              \
                        acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count,                     \
                        (V == 6 && c == nchunks - 1 && nchunks > 1) ? KsT[(c + 1) & 1] : (double *)nullptr, (double *)nullptr, 1, \
-                       (int)nblk)
+                       (int)nblk, (int)(n_prefix / BN))
 #ifdef GPBO_DIAGNOSTICS
         if (variant == 1) GPBO_SIGMA_LAUNCH(1);
         else if (variant == 2) GPBO_SIGMA_LAUNCH(2);
@@ -955,7 +975,7 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
             hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)grid1), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0,
                                (double *)nullptr, (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb, ss_part,
-                               xg_env, (int)nblk);
+                               xg_env, (int)nblk, 0);
             hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, xg_env, chunk, mu_part,
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
                                (double *)nullptr, (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch);
@@ -963,7 +983,7 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
             hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
                                (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb, (double *)nullptr, 1,
-                               (int)nblk);
+                               (int)nblk, 0);
         }
         GPBO_CHECK_LAUNCH();
         const int64_t nbatch = Mc / QQ;

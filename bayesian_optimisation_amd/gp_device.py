@@ -497,6 +497,85 @@ class DeviceGP:
         v, i, n = self.read_result(res)
         return ScoreResult(v, i, n, mu, sigma, acq)
 
+    # -- prefix-bound screen: exact branch and bound, all fp64 ---------------------------------------------------
+    BOUND_PREFIX_FRACTION = 8   # first pass over the first Np / 8 observations' columns (1/64 of the variance product)
+
+    def score_async_bound(self, Xs, acquisition: str = "lcb", explore: float = 4.0, f_best: Optional[float] = None,
+                          xi: float = 0.0, dense: bool = False, idx_offset: int = 0, diag_add: float = 0.0,
+                          prior_var: float = PRIOR_VAR, prefix: Optional[int] = None):
+        """The selected point WITHOUT the variance of every candidate - exact, all fp64.  The squared norm of the first J
+        components of v_c = U^T k_c is the variance reduction from the first J observations alone, so
+        sqrt(prior_var - |v_c[:J]|^2) >= cov_func_c and (both acquisitions increase with sigma) an UPPER bound of the
+        acquisition follows at (J / N)^2 of the cost.  Candidates whose bound is below the best exact value of a sample
+        cannot be the maximum nor tie with it; the others go through the fp64 kernels, which decide
+        (gpbo_posterior_prefix_f64 + gpbo_bound_select_f64).  The mean is still computed for every candidate.
+        Falls back to score_async when the bound cannot be used (dense outputs wanted, LCB with a negative weight, the
+        N == M diagonal quirk, fewer than 3 column blocks) or does not separate the candidates (flat mean, ties).
+        Synchronises; `last_screen` keeps the statistics."""
+        torch = self.torch
+        Xsd = self._dev(Xs)
+        if Xsd.dim() != 2 or int(Xsd.shape[1]) != self.d:
+            raise ValueError("Xs must be (M, d) with the same d as X")
+        M = int(Xsd.shape[0])
+        if acquisition == "lcb":
+            kind, p0, p1 = _lib.ACQ_LCB, float(explore), 0.0
+        elif acquisition == "ei":
+            if f_best is None:
+                raise ValueError("EI needs f_best (the incumbent minimum)")
+            kind, p0, p1 = _lib.ACQ_EI, float(f_best), float(xi)
+        else:
+            raise ValueError(f"unknown acquisition {acquisition!r}")
+        J = int(prefix) if prefix else max(128, (self.Np // self.BOUND_PREFIX_FRACTION) // 128 * 128)
+        reason = None
+        if dense:
+            reason = "dense outputs"
+        elif diag_add != 0.0:
+            reason = "diag_add"
+        elif kind == _lib.ACQ_LCB and not p0 >= 0.0:
+            reason = "negative explore weight"
+        elif J % 128 or J < 128 or 2 * J > self.Np:
+            reason = "too few column blocks"
+        if reason:
+            self.last_screen = dict(mode="bound", fallback=True, reason=reason)
+            return self.score_async(Xsd, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var)
+        with torch.cuda.device(self.device):
+            chunk, wbytes = self._ensure_post_workspace(M)
+            if getattr(self, "_bound_ub", None) is None or self._bound_ub.numel() < M:
+                self._bound_ub = torch.empty(M, dtype=torch.float64, device=self.device)
+            lsp = self.ls_h.ctypes.data_as(C.c_void_p)
+            st = self.lib.gpbo_posterior_prefix_f64(
+                self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d, lsp, self._ptr(self.U),
+                self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), chunk, J, None, None,
+                self._ptr(self._bound_ub), self._ptr(self._result), self._ptr(self._work_post), wbytes,
+                self._profile if self.profile_active else None, self._stream())
+            _lib.check(st, "gpbo_posterior_prefix_f64")
+            cap = self.screen_cap if self.screen_cap else max(4096, min(M, max(M // 16, 1 << 16)))
+            chunk64 = self.SCREEN_CHUNK64
+            rbytes = int(self.lib.gpbo_rescore_workspace_bytes(self.Np, cap, chunk64))
+            if rbytes < 0:
+                raise _lib.GpboError("gpbo_rescore_workspace_bytes: invalid sizes")
+            if getattr(self, "_work_rescore", None) is None or self._work_rescore.numel() * 8 < rbytes:
+                self._work_rescore = torch.empty((rbytes + 7) // 8, dtype=torch.float64, device=self.device)
+            stats = _lib.ScreenStats()
+            stride = max(1, M // self.SCREEN_SAMPLE)
+            st = self.lib.gpbo_bound_select_f64(
+                self._ptr(Xsd), M, self._ptr(self._bound_ub), self._ptr(self.X), self.N, self.Np, self.d, lsp,
+                self._ptr(self.U), self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), stride, cap,
+                chunk64, self._ptr(self._result), C.byref(stats), self._ptr(self._work_rescore), rbytes, self._stream())
+            _lib.check(st, "gpbo_bound_select_f64")
+            self.last_screen = dict(mode="bound", prefix=J, survivors=int(stats.survivors), rescored=int(stats.rescored),
+                                    rounds=int(stats.rounds), fallback=bool(stats.fallback), threshold=float(stats.tau),
+                                    candidates=M)
+        self._keep = Xsd
+        if stats.fallback:
+            return self.score_async(Xsd, acquisition, explore, f_best, xi, False, idx_offset, 0.0, prior_var)
+        return self._result, None, None, None
+
+    def score_bound(self, Xs, **kw) -> ScoreResult:
+        res, mu, sigma, acq = self.score_async_bound(Xs, **kw)
+        v, i, n = self.read_result(res)
+        return ScoreResult(v, i, n, mu, sigma, acq)
+
     # -- q = 8 Monte-Carlo Expected Improvement (BASELINE config 5) ---------------------------------------
     def score_qei_async(self, Xs, Z, f_best: float, xi: float = 0.0, dense: bool = False, batch_offset: int = 0,
                         prior_var: float = PRIOR_VAR):

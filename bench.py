@@ -70,7 +70,7 @@ def parse_args(argv=None):
                     help="rehearsal only: initialise the process group and run the exchange step even at N=1")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher check (no GPU): every rank joins the process group, rank 0 prints n_gpus / ranks_seen")
-    ap.add_argument("--dtype", choices=["f64", "f32", "i8", "i8c"], default="f64",
+    ap.add_argument("--dtype", choices=["f64", "f32", "i8", "i8c", "f64b"], default="f64",
                     help="f32: fp64 factorisation, fp32 screening of all candidates + fp64 re-scoring of the survivors "
                          "(BASELINE configs[3] shape); i8: the same with the variance product from int8 slices on the "
                          "integer matrix cores (|dsigma| ~ 1e-10)")
@@ -194,8 +194,9 @@ def main():
     f32 = args.dtype == "f32"
     i8c = args.dtype == "i8c"
     i8 = args.dtype == "i8" or i8c
+    bnd = args.dtype == "f64b"   # fp64 throughout, prefix-bound screen (branch and bound) in front of the fp64 decision
     qei = args.acq == "qei"
-    if qei and (f32 or i8 or args.m_per_gpu % 8):
+    if qei and (f32 or i8 or bnd or args.m_per_gpu % 8):
         sys.exit("bench.py: --acq qei needs fp64 and a multiple of 8 candidates per GPU")
     M_total = args.m_per_gpu * world
     lo, hi = D.shard_bounds(M_total, world, rank)
@@ -220,6 +221,8 @@ def main():
             return g.score_qei_async(P, Zd, f_best=f_best, xi=0.0, batch_offset=off // 8)
         if f32:
             return g.score_async_f32(P, idx_offset=off, **acq_kw)
+        if bnd:
+            return g.score_async_bound(P, idx_offset=off, **acq_kw)
         if i8c:
             return g.score_async_i8c(P, idx_offset=off, **acq_kw)
         if i8:
@@ -271,6 +274,9 @@ def main():
         k_avg_ms = k_ms / max(k_launches, 1)
         cand_per_launch = k_cands / max(k_launches, 1)
         flop_per_cand = float(N) * N + 2.0 * N           # triangular product N^2 + |v|^2 2N  
+        if bnd:   # the first pass multiplies the first J columns of V only (the re-scoring launches are not bracketed)
+            Jp = float((gp.last_screen or {}).get("prefix", N))
+            flop_per_cand = Jp * Jp + 2.0 * Jp
         achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
         # HBM bytes of one launch from the committed rocprofv3 --pmc passes of this same command line (profiles/):
         # counters cannot be read from inside the run, so the figure is replayed for the shape it was collected on
@@ -303,6 +309,8 @@ def main():
         if ks_launches:
             ks_avg = ks_ms / ks_launches
             bytes_per_cand = {"f32": 4.0, "i8": 5.0, "i8c": 3.0}.get(args.dtype, 8.0) * N + 8.0 * d
+            if bnd:   # K*^T is stored for the first J observations only: the kernel is fp64-VALU-bound, not HBM-bound
+                bytes_per_cand = 8.0 * float((gp.last_screen or {}).get("prefix", N)) + 8.0 * d
             gbs = bytes_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e9
             kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(gbs / HBM_PEAK_GBS, 4),
@@ -372,6 +380,24 @@ def main():
                 note="screen = 6 int8 slice products (three leading digits of K* and U, |dsigma^2| ~ 2e-4, tolerance checked "
                      "per call); every candidate whose interval reaches the best lower bound is re-scored by the fp64 "
                      "kernels, which decide: same selected point; --dtype i8c times it as the main workload")
+        if args.dtype == "f64" and not qei:
+            # ... and with NO approximation at all: branch and bound on the variance reduction of the first N/8 observations
+            kwb = dict(idx_offset=lo, **acq_kw)
+            gp.score_async_bound(Xsd, **kwb)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for _ in range(reps2):
+                gp.factorise(Xd, yd, ls, check=False)
+                gp.score_async_bound(Xsd, **kwb)
+                v, i, n, info = D.allreduce_status(gp.status)
+            ms = (time.perf_counter() - t) / reps2 * 1e3
+            res["prefix_bound_screen_same_workload"] = dict(
+                value=(hi - lo) / (ms * 1e-3), unit="candidates/s", ms_per_step=ms, argmax_index=i,
+                argmax_matches_fp64=bool(i == best[1]), steps=reps2, screen=gp.last_screen,
+                note="fp64 throughout, exact: the mean of every candidate, an UPPER bound of its acquisition from |v|^2 over the "
+                     "first N/8 components (1/64 of the variance product), the fp64 kernels on every candidate whose bound "
+                     "reaches the best exact value seen; pruned candidates provably cannot be the maximum nor tie with it; "
+                     "--dtype f64b times it as the main workload")
         g1 = os.path.join(REPO, "tests", "golden", "g1_m32.npz")
         if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb") and os.path.exists(g1):
             # BASELINE configs[0] (d=2, N=32, M=32x32 grid, 50x50 ARD search - the sizes the reference's DAG runs): the
@@ -429,6 +455,8 @@ def main():
                 (8192, 16, "f32", "lcb"): "configs[3] (per-GPU shard)",
                 (4096, 8, "i8", "lcb"): "configs[2] (per-GPU shard), int8-sliced variance screen",
                 (4096, 8, "i8c", "lcb"): "configs[2] (per-GPU shard), coarse int8 variance screen",
+                (4096, 8, "f64b", "lcb"): "configs[2] (per-GPU shard), prefix-bound screen",
+                (4096, 8, "f64b", "ei"): "configs[2] (per-GPU shard), EI, prefix-bound screen",
                 (2048, 8, "f64", "qei"): "configs[4] (per-GPU shard)"}.get((N, d, args.dtype, args.acq), "custom")
     acq_txt = {"lcb": "LCB(explore=4) arg-max", "ei": "Expected Improvement (f_best=min y, xi=0) arg-max",
                "qei": "q=8 Monte-Carlo qEI (512 fixed base samples) arg-max over batches"}[args.acq]
@@ -439,10 +467,10 @@ def main():
             "metric": "candidate acquisitions/sec", "value": value, "unit": "candidates/s", "n_gpus": world,
             "ranks_seen": ranks_seen,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64" if bnd else args.dtype, "data": "synthetic",
             "config": {"workload": (f"{cfg_name}: d={d}, N={N} Sobol observations, M={mtxt} "
                                     f"Sobol candidates per GPU, ARD-SE GP, {acq_txt}, "
-                                    f"{ {'f32': 'fp64 factorisation + fp32 screen + fp64 re-score of the survivors', 'i8': 'fp64 factorisation and means + int8-sliced variance screen + fp64 re-score of the survivors', 'i8c': 'fp64 factorisation and means + coarse int8 variance screen (three digits per operand, six slice products) + fp64 re-score of the survivors'}.get(args.dtype, 'fp64') }; "
+                                    f"{ {'f32': 'fp64 factorisation + fp32 screen + fp64 re-score of the survivors', 'i8': 'fp64 factorisation and means + int8-sliced variance screen + fp64 re-score of the survivors', 'i8c': 'fp64 factorisation and means + coarse int8 variance screen (three digits per operand, six slice products) + fp64 re-score of the survivors', 'f64b': 'fp64 throughout: mean of every candidate, UPPER bound of its acquisition from the variance reduction of the first N/8 observations, fp64 re-score of every candidate whose bound reaches the best exact value (branch and bound, exact)'}.get(args.dtype, 'fp64') }; "
                                     f"step = factorise + score all candidates + reduce"),
                        "candidates_total": M_total, "parallelism": f"candidate-sharded x{world}"},
             "ms_per_step_scoring_only": ms_score,
@@ -452,11 +480,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not qei:
             cb, idx_cpu, ns = cpu_baseline(X, y, Xs_local, ls, args.acq, args.cpu_seconds, args.cpu_sample, f_best,
                                            "f32" if f32 else "f64")
-            r = {"f32": gp.score_f32, "i8": gp.score_i8, "i8c": gp.score_i8c}.get(args.dtype, gp.score)(Xsd[:ns], **acq_kw)
+            r = {"f32": gp.score_f32, "i8": gp.score_i8, "i8c": gp.score_i8c, "f64b": gp.score_bound}.get(
+                args.dtype, gp.score)(Xsd[:ns], **acq_kw)
             cb["argmax_match_on_sample"] = bool(r.best_idx == idx_cpu)
             out["cpu_baseline"] = cb
-        if f32 or i8:
-            out["screen"] = gp.last_screen   # survivors of the fp32 screen, tolerance and its check, fallback flag
+        if f32 or i8 or bnd:
+            out["screen"] = gp.last_screen   # survivors of the screen, tolerance / threshold and its check, fallback flag
         if world == 1 and not args.no_also:
             out["also"] = also()
         print(json.dumps(out), flush=True)

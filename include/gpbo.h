@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPBO_VERSION 121 /* 0.2.0: fp32 screen + fp64 re-score (gpbo_rescore_f64), gpbo_posterior_acq_f32 changed */
+#define GPBO_VERSION 122 /* 0.2.0: fp32 screen + fp64 re-score (gpbo_rescore_f64), gpbo_posterior_acq_f32 changed */
 
 #define GPBO_OK 0
 #define GPBO_ERR_ARG (-1)      /* null pointer, bad size/alignment, unsupported d */
@@ -199,6 +199,28 @@ int gpbo_rescore_f64(const double *Xs, int64_t M, const double *mu, const double
                      double prior_var, int32_t acq_kind, double p0, double p1, int64_t idx_offset, double tau0,
                      int64_t sample_stride, int64_t cap, int64_t chunk64, gpbo_result *result,
                      gpbo_screen_stats *stats_host, void *work, int64_t work_bytes, void *stream);
+
+/* Prefix-bound screen: exact branch and bound, everything in fp64 (csrc/sigma_acq.hip, csrc/rescore.hip).
+ * |U^T k_c|^2 summed over the FIRST n_prefix components is a lower bound of the whole sum - it is the variance reduction
+ * from the first n_prefix observations alone - so  sigma_ub = sqrt(|prior_var - partial|) >= cov_func_c  and, both
+ * acquisitions being increasing in sigma (LCB for explore >= 0), acq_ub_c >= acq_func_eval_c (point_selector.py:98,204).
+ * gpbo_posterior_prefix_f64: one pass over all candidates - the mean over all N observations (exactly the fp64 path's),
+ * the variance product over the first n_prefix columns only ((n_prefix / Np)^2 of the work; n_prefix a multiple of 128).
+ * Same workspace as gpbo_posterior_acq_f64; `result` receives the arg-max of the BOUNDS (not the answer).
+ * gpbo_bound_select_f64: the strided sample goes through the fp64 kernels (a lower bound of the maximum), every
+ * candidate whose bound reaches it survives and is re-scored by the fp64 kernels, which decide (maximum, lowest index,
+ * NaN count as the plain pass); too many survivors -> stats->fallback = 1 and the caller runs gpbo_posterior_acq_f64.
+ * work: gpbo_rescore_workspace_bytes(Np, cap, chunk64).  This call synchronises the stream. */
+int gpbo_posterior_prefix_f64(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
+                              const double *ls_host, const double *U, const double *alpha, double prior_var,
+                              int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk, int64_t n_prefix,
+                              double *mu_out, double *sigma_ub_out, double *acq_ub_out, gpbo_result *result, void *work,
+                              int64_t work_bytes, gpbo_profile *prof /* or NULL */, void *stream);
+int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *acq_ub, const double *X, int64_t N, int64_t Np,
+                          int32_t d, const double *ls_host, const double *U, const double *alpha, double prior_var,
+                          int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t sample_stride, int64_t cap,
+                          int64_t chunk64, gpbo_result *result, gpbo_screen_stats *stats_host, void *work,
+                          int64_t work_bytes, void *stream);
 
 /* int8-sliced variance screen (Ozaki-style splitting on the integer matrix cores, csrc/ozaki.hip): same role and
  * outputs as gpbo_posterior_acq_f32 - mean exactly the fp64 path's, variance from 20 exact int8 slice products

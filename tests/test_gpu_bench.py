@@ -18,7 +18,7 @@ def _bench(*flags):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["f64", "i8", "i8c"])
+@pytest.mark.parametrize("dtype", ["f64", "i8", "i8c", "f64b"])
 def test_two_self_launched_ranks_pick_the_point_one_rank_picks_over_the_same_candidates(dtype):
     common = ["--n-obs", "384", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--dtype", dtype]
     two = _bench("--gpus", "2", "--backend", "gloo", "--all-on-device", "0", "--m-per-gpu", "65536", *common)
@@ -45,6 +45,9 @@ def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
     c8 = line["also"]["int8_coarse_screen_same_workload"]
     assert c8["argmax_matches_fp64"] is True and not c8["screen"]["fallback"] and c8["value"] > 2.0 * i8["value"]
     assert c8["screen"]["mode"] == "i8c" and 4.0 * c8["screen"]["err_max"] <= c8["screen"]["tau"]
+    pb = line["also"]["prefix_bound_screen_same_workload"]
+    assert pb["argmax_matches_fp64"] is True and not pb["screen"]["fallback"] and pb["value"] > 5.0 * line["value"]
+    assert pb["screen"]["mode"] == "bound" and pb["screen"]["rescored"] < (1 << 21) // 16
 
 
 @pytest.mark.gpu
@@ -62,3 +65,13 @@ def test_coarse_int8_screen_as_the_main_workload():
     assert line["dtype"] == "i8c" and line["roofline"]["kernel"] == "sigma_i8c_kernel" and 0.05 < line["roofline"]["frac"] <= 1.0
     assert line["roofline"]["unit"].startswith("TOP/s") and line["cpu_baseline"]["argmax_match_on_sample"] is True
     assert line["screen"]["mode"] == "i8c" and not line["screen"]["fallback"]
+
+
+@pytest.mark.gpu
+def test_prefix_bound_screen_as_the_main_workload():
+    line = _bench("--dtype", "f64b", "--n-obs", "1024", "--m-per-gpu", "262144", "--steps", "2", "--warmup", "1",
+                  "--cpu-seconds", "3", "--no-also")
+    assert line["dtype"] == "f64" and "prefix-bound" in line["config"]["workload"] or "bound" in line["config"]["workload"]
+    assert line["roofline"]["kernel"] == "sigma_acq_kernel" and 0.05 < line["roofline"]["frac"] <= 1.0
+    assert line["cpu_baseline"]["argmax_match_on_sample"] is True
+    assert line["screen"]["mode"] == "bound" and not line["screen"]["fallback"]

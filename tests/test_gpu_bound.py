@@ -1,0 +1,148 @@
+"""Prefix-bound screen (DeviceGP.score_bound: gpbo_posterior_prefix_f64 + gpbo_bound_select_f64): branch and bound on the
+variance reduction of the first J observations - everything in fp64, no tolerance anywhere.
+
+|U^T k_c|^2 over the first J components is a lower bound of the whole sum, so the acquisition computed from it is an UPPER
+bound of acq_func_eval_c (point_selector.py:98,204: both acquisitions increase with sigma); candidates whose bound is below
+an exact value cannot be the maximum nor tie with it.  The bar here is the plain fp64 pass itself: same index (the LOWEST
+among ties, point_selector.py:207), same NaN count, value equal up to the rounding of the column-split launch that
+re-scores the survivors (1e-12 relative, as for the other screens), and the oracle's first arg-max."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from bayesian_optimisation_amd import DeviceGP, _lib
+from bayesian_optimisation_amd.synthetic import make_problem
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _first_argmax(a):
+    return int(np.flatnonzero(a == a.max())[0])
+
+
+def _same(r, r64, scale=1.0):
+    assert r.best_idx == r64.best_idx and r.nan_count == r64.nan_count
+    assert abs(r.best_val - r64.best_val) <= 1e-12 * max(scale, abs(r64.best_val))
+
+
+@pytest.mark.parametrize("N,M,d,chunk", [(256, 2048, 8, 1024), (300, 7001, 3, 2048), (700, 5000, 8, 2048),
+                                         (2048, 40000, 8, 4096), (1000, 60000, 16, 8192), (2500, 70000, 8, 1 << 15)])
+def test_bound_screen_selects_the_fp64_point(N, M, d, chunk):
+    X, y, Xs, ls = make_problem(N, M, d)
+    gp = DeviceGP(chunk=chunk).factorise(X, y, ls)
+    mu_o, sig_o = O.posterior_chol(X, y, Xs, ls)
+    ys = max(1.0, float(np.abs(y).max()))
+    for kw, acq_o in ((dict(acquisition="lcb", explore=4.0), O.lcb(mu_o, sig_o, 4)),
+                      (dict(acquisition="lcb", explore=0.0), O.lcb(mu_o, sig_o, 0)),
+                      (dict(acquisition="lcb", explore=15.0), O.lcb(mu_o, sig_o, 15)),
+                      (dict(acquisition="ei", f_best=float(y.min()), xi=0.0),
+                       O.expected_improvement(mu_o, sig_o, float(y.min()), 0.0))):
+        r = gp.score_bound(Xs, idx_offset=11, **kw)
+        st = dict(gp.last_screen)
+        r64 = gp.score(Xs, idx_offset=11, **kw)
+        _same(r, r64, ys)
+        top2 = np.sort(acq_o)[-2:]
+        if top2[1] - top2[0] > 1e-7 * ys:
+            assert r.best_idx == 11 + _first_argmax(acq_o), kw
+        assert st["mode"] == "bound" and st["prefix"] % 128 == 0 and 2 * st["prefix"] <= gp.Np
+        if M >= 40000 and kw.get("explore", 4.0) <= 4.0:   # the bound prunes: a few thousand rows meet the fp64 kernels again
+            assert not st["fallback"] and st["rescored"] < M // 4, st
+
+
+def test_bound_is_an_upper_bound_of_the_fp64_acquisition_for_every_candidate():
+    """The first pass alone (C ABI): mean bit-identical to the plain pass, sigma_ub >= sigma, acq_ub >= acq, for every prefix."""
+    import torch
+
+    X, y, Xs, ls = make_problem(1500, 9000, 8)
+    gp = DeviceGP(chunk=4096).factorise(X, y, ls)
+    full = gp.score(Xs, dense=True)
+    mu, sig, acq = (t.cpu().numpy() for t in (full.mu, full.sigma, full.acq))
+    Xd = gp._dev(Xs)
+    M = Xd.shape[0]
+    chunk, wbytes = gp._ensure_post_workspace(M)
+    lsp = gp.ls_h.ctypes.data_as(C.c_void_p)
+    prev = None
+    for J in (128, 512, 1024, gp.Np):
+        o = [torch.empty(M, dtype=torch.float64, device=gp.device) for _ in range(3)]
+        st = gp.lib.gpbo_posterior_prefix_f64(gp._ptr(Xd), M, gp._ptr(gp.X), gp.N, gp.Np, gp.d, lsp, gp._ptr(gp.U),
+                                              gp._ptr(gp.alpha), 1.000101, _lib.ACQ_LCB, 4.0, 0.0, 0, chunk, J, gp._ptr(o[0]),
+                                              gp._ptr(o[1]), gp._ptr(o[2]), gp._ptr(gp._result), gp._ptr(gp._work_post),
+                                              wbytes, None, gp._stream())
+        assert st == 0
+        m, s, a = (t.cpu().numpy() for t in o)
+        assert np.array_equal(m, mu)
+        assert np.all(s >= sig - 1e-13) and np.all(a >= acq - 1e-12)
+        if prev is not None:
+            assert np.all(s <= prev + 1e-13)   # more observations, tighter bound
+        prev = s
+    assert np.max(np.abs(prev - sig)) <= 1e-12   # the whole prefix is the plain pass
+    # argument checks: prefix not a multiple of 128, LCB with a negative weight (the bound would point the wrong way)
+    bad = [dict(J=100, p0=4.0), dict(J=256, p0=-1.0), dict(J=gp.Np + 128, p0=4.0)]
+    for b in bad:
+        st = gp.lib.gpbo_posterior_prefix_f64(gp._ptr(Xd), M, gp._ptr(gp.X), gp.N, gp.Np, gp.d, lsp, gp._ptr(gp.U),
+                                              gp._ptr(gp.alpha), 1.000101, _lib.ACQ_LCB, b["p0"], 0.0, 0, chunk, b["J"], None,
+                                              None, gp._ptr(o[2]), gp._ptr(gp._result), gp._ptr(gp._work_post), wbytes, None,
+                                              gp._stream())
+        assert st == -1   # GPBO_ERR_ARG
+
+
+def test_ties_nan_and_chunk_invariance():
+    X, y, Xs, ls = make_problem(600, 20000, 6)
+    gp = DeviceGP(chunk=4096).factorise(X, y, ls)
+    best = gp.score(Xs).best_idx
+    # copies of the winning row: the LOWEST index among exact ties wins (point_selector.py:207)
+    Xt = Xs.copy()
+    for i in (19990, 7, 12345):
+        Xt[i] = Xs[best]
+    r, r64 = gp.score_bound(Xt), gp.score(Xt)
+    assert r64.best_idx == min(7, best) and r.best_idx == r64.best_idx and r.best_val == pytest.approx(r64.best_val, rel=1e-13)
+    # NaN candidates are counted and never selected
+    Xn = Xs.copy()
+    Xn[3, 0] = np.nan
+    Xn[15000, 2] = np.nan
+    r, r64 = gp.score_bound(Xn), gp.score(Xn)
+    assert r.nan_count == r64.nan_count == 2 and r.best_idx == r64.best_idx
+    # chunking and the prefix length change the work, never the answer
+    ref = gp.score(Xs)
+    for chunk, prefix in ((1024, None), (8192, 128), (4096, 256)):
+        g = DeviceGP(chunk=chunk).factorise(X, y, ls)
+        _same(g.score_bound(Xs, prefix=prefix), ref)
+
+
+def test_weak_bounds_end_in_the_plain_pass_or_many_survivors_never_in_a_wrong_point():
+    """(a) a flat objective: the mean separates nothing; (b) observations sorted along one axis: the prefix knows one corner of
+    the domain only; (c) 2,500 exact ties; (d) dense outputs, a negative weight, too few column blocks: not this route."""
+    X, y, Xs, ls = make_problem(900, 30000, 5)
+    gp = DeviceGP(chunk=8192)
+    gp.factorise(X, np.full_like(y, 0.3) + 1e-9 * y, ls)
+    _same(gp.score_bound(Xs), gp.score(Xs))
+    order = np.argsort(X[:, 0])
+    gp.factorise(X[order], y[order], ls)
+    _same(gp.score_bound(Xs), gp.score(Xs))
+    _same(gp.score_bound(Xs, acquisition="ei", f_best=float(y.min())), gp.score(Xs, acquisition="ei", f_best=float(y.min())))
+    gp.factorise(X, y, ls)
+    Xt = np.repeat(Xs[:1], 2500, axis=0)
+    r = gp.score_bound(Xt)
+    assert r.best_idx == 0
+    r = gp.score_bound(Xs, dense=True)
+    assert gp.last_screen["fallback"] and r.mu is not None and r.best_idx == gp.score(Xs).best_idx
+    r = gp.score_bound(Xs, explore=-2.0)
+    assert gp.last_screen["fallback"] and r.best_idx == gp.score(Xs, explore=-2.0).best_idx
+    Xa, ya, Xsa, lsa = make_problem(100, 3000, 4)
+    g2 = DeviceGP(chunk=1024).factorise(Xa, ya, lsa)
+    r = g2.score_bound(Xsa)
+    assert g2.last_screen["fallback"] and r.best_idx == g2.score(Xsa).best_idx
+
+
+@pytest.mark.parametrize("name", ["g5_d8_n512_m4096", "g5_d8_n2048_m4096", "g6_d16_n256_m2048"])
+def test_bound_screen_selects_the_reference_point(golden, name):
+    """Vectors produced by the reference itself (tests/golden/make_golden.py)."""
+    g = golden(name)
+    X, y, Xs, ls = make_problem(int(g["N"]), int(g["M"]), int(g["d"]))
+    gp = DeviceGP(chunk=2048).factorise(X, y, g["kernel_params"])
+    r = gp.score_bound(Xs)
+    if g["top2_gap"] > 1e-7 * max(1.0, np.abs(y).max()):
+        assert r.best_idx == _first_argmax(g["acq_func_eval"])
+    assert abs(r.best_val - g["acq_func_eval"].max()) <= 1e-8 * max(1.0, np.abs(y).max())

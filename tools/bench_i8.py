@@ -40,7 +40,7 @@ def i8raw(P, entry="gpbo_posterior_acq_i8"):
 
 for name in modes:
     fn = {"i8": gp.score_i8, "f64": gp.score, "i8raw": i8raw, "i8c": gp.score_i8c,
-          "i8craw": lambda P: i8raw(P, "gpbo_posterior_acq_i8c")}[name]
+          "i8craw": lambda P: i8raw(P, "gpbo_posterior_acq_i8c"), "bound": gp.score_bound}[name]
     fn(Xd)
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(reps):

@@ -1,0 +1,35 @@
+# prefix-bound screen (DeviceGP.score_bound): the selected point against the plain fp64 pass on assorted problems, then
+# timing at the headline shape.  usage: python tools/bound_check.py [time]
+import sys, time
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import numpy as np, torch
+from bayesian_optimisation_amd import DeviceGP
+from bayesian_optimisation_amd.synthetic import make_problem
+
+for N, M, d, chunk in [(256, 2048, 8, 1024), (700, 5000, 8, 2048), (2048, 40000, 8, 4096), (1000, 60000, 16, 8192),
+                       (2500, 70000, 8, 1 << 15), (4096, 1 << 17, 8, 1 << 16)]:
+    X, y, Xs, ls = make_problem(N, M, d)
+    gp = DeviceGP(chunk=chunk).factorise(X, y, ls)
+    for kw in (dict(acquisition="lcb"), dict(acquisition="lcb", explore=1.0), dict(acquisition="lcb", explore=12.0),
+               dict(acquisition="ei", f_best=float(y.min()))):
+        r = gp.score_bound(Xs, idx_offset=3, **kw)
+        scr = dict(gp.last_screen)
+        r64 = gp.score(Xs, idx_offset=3, **kw)
+        print(N, M, d, kw.get("acquisition"), kw.get("explore", ""), "idx", r.best_idx == r64.best_idx,
+              "dval %.2g" % abs(r.best_val - r64.best_val), "nan", r.nan_count == r64.nan_count, scr, flush=True)
+
+if len(sys.argv) > 1:
+    N, M, d = 4096, 1 << 21, 8
+    X, y, Xs, ls = make_problem(N, M, d)
+    gp = DeviceGP().factorise(X, y, ls)
+    Xd = gp._dev(Xs)
+    for name, fn in [("bound", gp.score_bound), ("bound J=256", lambda P: gp.score_bound(P, prefix=256)),
+                     ("bound J=1024", lambda P: gp.score_bound(P, prefix=1024)), ("i8c", gp.score_i8c), ("f64", gp.score)]:
+        fn(Xd)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        reps = 1 if name == "f64" else 3
+        for _ in range(reps):
+            r = fn(Xd)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
+        print(name, "%.1f ms per 2^21" % (dt * 1e3), "%.4g cand/s" % (M / dt), r.best_idx, r.best_val,
+              gp.last_screen if name != "f64" else "", flush=True)
