@@ -70,7 +70,7 @@ SIGNATURES = {
     "gpbo_posterior_prefix_f64": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _i32, _f64, _f64, _i64, _i64,
                                             _i64, _p, _p, _p, _p, _p, _i64, _p, _p]),
     "gpbo_bound_select_f64": (C.c_int, [_p, _i64, _p, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _i32, _f64, _f64, _i64,
-                                        _i64, _i64, _i64, _p, _p, _p, _i64, _p]),
+                                        _i64, _i64, _i64, _i64, _p, _p, _p, _i64, _p]),
     "gpbo_rescore_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gpbo_rescore_f64": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _i32, _f64, _f64, _i64,
                                    _f64, _i64, _i64, _i64, _p, _p, _p, _i64, _p]),

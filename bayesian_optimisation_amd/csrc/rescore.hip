@@ -142,6 +142,26 @@ __global__ __launch_bounds__(SB) void bound_max_kernel(const double *__restrict_
     }
 }
 
+// second level of the prefix bound: of the K listed candidates keep those whose TIGHTER bound (a longer prefix) still reaches
+// the threshold; the kept ones keep their order (ascending original index is not needed: the arg-max is taken by index)
+__global__ __launch_bounds__(SB) void bound_refine_kernel(const double *__restrict__ ub2, const int64_t *__restrict__ list,
+                                                          int64_t K, double thr, double slack, int64_t *__restrict__ list_out,
+                                                          unsigned long long *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t step = (int64_t)gridDim.x * SB;
+    const int64_t imax = (K + step - 1) / step * step;
+    for (int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x; i < imax; i += step) {
+        const bool keep = i < K && !(ub2[i] + slack < thr);
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(m));
+            base = __shfl(base, 0);
+            if (keep) list_out[base + __popcll(m & ((1ull << lane) - 1ull))] = list[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(SB) void gather_rows_kernel(const double *__restrict__ Xs, int d, const int64_t *__restrict__ list,
                                                          int64_t K, double *__restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * SB + threadIdx.x;
@@ -332,9 +352,11 @@ extern "C" int gpbo_rescore_f64(const double *Xs, int64_t M, const double *mu, c
 extern "C" int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *ub, const double *X, int64_t N, int64_t Np,
                                      int32_t d, const double *ls_host, const double *U, const double *alpha,
                                      double prior_var, int32_t acq_kind, double p0, double p1, int64_t idx_offset,
-                                     int64_t sample_stride, int64_t cap, int64_t chunk64, gpbo_result *result,
-                                     gpbo_screen_stats *stats_host, void *work, int64_t work_bytes, void *stream) {
+                                     int64_t sample_stride, int64_t cap, int64_t chunk64, int64_t n_prefix2,
+                                     gpbo_result *result, gpbo_screen_stats *stats_host, void *work, int64_t work_bytes,
+                                     void *stream) {
     if (!Xs || !ub || !X || !U || !alpha || !result || !stats_host || !work) return GPBO_ERR_ARG;
+    if (n_prefix2 < 0 || n_prefix2 > Np || n_prefix2 % 128) return GPBO_ERR_ARG;
     if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || d < 1 || d > GPBO_MAX_D || cap < 1 || sample_stride < 1) return GPBO_ERR_ARG;
     if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
     if (acq_kind == GPBO_ACQ_LCB && !(p0 >= 0.0)) return GPBO_ERR_ARG;   // the bound needs an acquisition that increases with sigma
@@ -439,6 +461,37 @@ extern "C" int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *
         if (rc != GPBO_OK) return rc;
         stt.survivors = (int64_t)K;
         if ((int64_t)K <= cap) {
+            if (n_prefix2 > 0 && (int64_t)K > 4 * refine) {
+                // second level: a longer prefix for the survivors only (tighter bounds at (n_prefix2 / Np)^2 of the
+                // exact cost); what still reaches the threshold goes to the fp64 kernels
+                const int64_t tot = (int64_t)K * d;
+                hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((tot + SB - 1) / SB)), dim3(SB), 0, st, Xs, (int)d, list,
+                                   (int64_t)K, rows);
+                GPBO_CHECK_LAUNCH();
+                int64_t chunk = chunk64;
+                const int64_t kpad = ((int64_t)K + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
+                if (chunk > kpad) chunk = kpad;
+                rc = gpbo_posterior_acq_f64_split(rows, (int64_t)K, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1,
+                                                  0.0, 0, chunk, nullptr, nullptr, acq64, &out->res, post, L.post_bytes, nullptr,
+                                                  GPBO_RESCORE_SPLIT_MAX, n_prefix2, stream);
+                if (rc != GPBO_OK) return rc;
+                int64_t *list2 = reinterpret_cast<int64_t *>(mu64);   // (cap x 8 bytes, not used by the call above)
+                if (hipMemsetAsync(count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
+                int64_t rblk = ((int64_t)K + SB - 1) / SB;
+                if (rblk > SCREEN_BLOCKS) rblk = SCREEN_BLOCKS;
+                hipLaunchKernelGGL(bound_refine_kernel, dim3((unsigned)rblk), dim3(SB), 0, st, acq64, list, (int64_t)K, thr,
+                                   1e-10 * fmax(1.0, fabs(thr)), list2, count);
+                GPBO_CHECK_LAUNCH();
+                unsigned long long K2 = 0;
+                if (hipMemcpyAsync(&K2, count, sizeof(K2), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess)
+                    return GPBO_ERR_LAUNCH;
+                if (K2 > K) return GPBO_ERR_LAUNCH;
+                if (hipMemcpyAsync(list, list2, sizeof(int64_t) * K2, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return GPBO_ERR_LAUNCH;
+                K = K2;   // (never empty: the candidate that set the threshold has ub2 >= its exact value)
+                if (K == 0) return GPBO_ERR_LAUNCH;
+            }
             rc = exact((int64_t)K, &h);
             if (rc != GPBO_OK) return rc;
             if (hipMemcpyAsync(result, &out->res, sizeof(gpbo_result), hipMemcpyDeviceToDevice, st) != hipSuccess)

@@ -745,7 +745,7 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                                  void *work, int64_t work_bytes, gpbo_profile *prof, int split_max,
                                  int64_t n_prefix /* 0: everything; else see gpbo_posterior_prefix_f64 */, void *stream) {
     if (!Xs || !X || !U || !alpha || !result || !work) return GPBO_ERR_ARG;
-    if (n_prefix < 0 || n_prefix > Np || n_prefix % BN || (n_prefix && (split_max != 1 || diag_add != 0.0))) return GPBO_ERR_ARG;
+    if (n_prefix < 0 || n_prefix > Np || n_prefix % BN || (n_prefix && diag_add != 0.0)) return GPBO_ERR_ARG;
     if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || Np > (1 << 20)) return GPBO_ERR_ARG;
     if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
     if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
@@ -829,7 +829,7 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
         const bool rec = prof && prof->count < prof->capacity;
         if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
-        const int S = split_factor(nblk, Np / BN, split_max);
+        const int S = split_factor(nblk, (n_prefix ? n_prefix : Np) / BN, split_max);
         // Column groups on one XCD for large calls (see the kernel): measured on MI355X at N = 4096, 2^21 candidates,
         // same box: 543 -> 509 ms per step with 8 groups (16: 512), the variance launches 32.9 -> 30.7 ms.  The rule depends
         // on the problem (N, candidates of the CALL), never on the chunking, so results stay chunk-size invariant bit for
@@ -850,7 +850,7 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
             hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk, (unsigned)S), dim3(NW * 64), 0, st, KsT[b], chunk, U,
                                (int)Np, mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1,
                                idx_offset + s, (double *)nullptr, (double *)nullptr, (double *)nullptr, part_val + nparts,
-                               part_idx + nparts, nan_count, (double *)nullptr, ss_part, 1, (int)nblk, 0);
+                               part_idx + nparts, nan_count, (double *)nullptr, ss_part, 1, (int)nblk, (int)(n_prefix / BN));
             hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, S, chunk, mu_part[b],
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                                mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,

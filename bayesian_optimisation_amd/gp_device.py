@@ -498,11 +498,12 @@ class DeviceGP:
         return ScoreResult(v, i, n, mu, sigma, acq)
 
     # -- prefix-bound screen: exact branch and bound, all fp64 ---------------------------------------------------
-    BOUND_PREFIX_FRACTION = 8   # first pass over the first Np / 8 observations' columns (1/64 of the variance product)
+    BOUND_PREFIX_FRACTION = 16  # first pass over the first Np / 16 observations' columns (1/256 of the variance product);
+                                # survivors get a second bound from four times as many before the fp64 kernels see them
 
     def score_async_bound(self, Xs, acquisition: str = "lcb", explore: float = 4.0, f_best: Optional[float] = None,
                           xi: float = 0.0, dense: bool = False, idx_offset: int = 0, diag_add: float = 0.0,
-                          prior_var: float = PRIOR_VAR, prefix: Optional[int] = None):
+                          prior_var: float = PRIOR_VAR, prefix: Optional[int] = None, prefix2: Optional[int] = None):
         """The selected point WITHOUT the variance of every candidate - exact, all fp64.  The squared norm of the first J
         components of v_c = U^T k_c is the variance reduction from the first J observations alone, so
         sqrt(prior_var - |v_c[:J]|^2) >= cov_func_c and (both acquisitions increase with sigma) an UPPER bound of the
@@ -526,6 +527,7 @@ class DeviceGP:
         else:
             raise ValueError(f"unknown acquisition {acquisition!r}")
         J = int(prefix) if prefix else max(128, (self.Np // self.BOUND_PREFIX_FRACTION) // 128 * 128)
+        J2 = int(prefix2) if prefix2 is not None else (4 * J if 8 * J <= self.Np else 0)   # second level: survivors only
         reason = None
         if dense:
             reason = "dense outputs"
@@ -561,9 +563,10 @@ class DeviceGP:
             st = self.lib.gpbo_bound_select_f64(
                 self._ptr(Xsd), M, self._ptr(self._bound_ub), self._ptr(self.X), self.N, self.Np, self.d, lsp,
                 self._ptr(self.U), self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), stride, cap,
-                chunk64, self._ptr(self._result), C.byref(stats), self._ptr(self._work_rescore), rbytes, self._stream())
+                chunk64, J2, self._ptr(self._result), C.byref(stats), self._ptr(self._work_rescore), rbytes,
+                self._stream())
             _lib.check(st, "gpbo_bound_select_f64")
-            self.last_screen = dict(mode="bound", prefix=J, survivors=int(stats.survivors), rescored=int(stats.rescored),
+            self.last_screen = dict(mode="bound", prefix=J, prefix2=J2, survivors=int(stats.survivors), rescored=int(stats.rescored),
                                     rounds=int(stats.rounds), fallback=bool(stats.fallback), threshold=float(stats.tau),
                                     candidates=M)
         self._keep = Xsd

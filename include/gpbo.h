@@ -219,8 +219,9 @@ int gpbo_posterior_prefix_f64(const double *Xs, int64_t M, const double *X, int6
 int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *acq_ub, const double *X, int64_t N, int64_t Np,
                           int32_t d, const double *ls_host, const double *U, const double *alpha, double prior_var,
                           int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t sample_stride, int64_t cap,
-                          int64_t chunk64, gpbo_result *result, gpbo_screen_stats *stats_host, void *work,
-                          int64_t work_bytes, void *stream);
+                          int64_t chunk64, int64_t n_prefix2 /* 0, or a longer prefix (multiple of 128) that tightens the
+                          bounds of the survivors before they are re-scored */, gpbo_result *result,
+                          gpbo_screen_stats *stats_host, void *work, int64_t work_bytes, void *stream);
 
 /* int8-sliced variance screen (Ozaki-style splitting on the integer matrix cores, csrc/ozaki.hip): same role and
  * outputs as gpbo_posterior_acq_f32 - mean exactly the fp64 path's, variance from 20 exact int8 slice products

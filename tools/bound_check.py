@@ -18,13 +18,18 @@ for N, M, d, chunk in [(256, 2048, 8, 1024), (700, 5000, 8, 2048), (2048, 40000,
         print(N, M, d, kw.get("acquisition"), kw.get("explore", ""), "idx", r.best_idx == r64.best_idx,
               "dval %.2g" % abs(r.best_val - r64.best_val), "nan", r.nan_count == r64.nan_count, scr, flush=True)
 
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] != 'timeonly' or len(sys.argv) > 1:
     N, M, d = 4096, 1 << 21, 8
     X, y, Xs, ls = make_problem(N, M, d)
     gp = DeviceGP().factorise(X, y, ls)
     Xd = gp._dev(Xs)
-    for name, fn in [("bound", gp.score_bound), ("bound J=256", lambda P: gp.score_bound(P, prefix=256)),
-                     ("bound J=1024", lambda P: gp.score_bound(P, prefix=1024)), ("i8c", gp.score_i8c), ("f64", gp.score)]:
+    for name, fn in [("bound", gp.score_bound), ("bound J=512 one level", lambda P: gp.score_bound(P, prefix=512, prefix2=0)),
+                     ("bound J=256 one level", lambda P: gp.score_bound(P, prefix=256, prefix2=0)),
+                     ("bound 128/512", lambda P: gp.score_bound(P, prefix=128, prefix2=512)),
+                     ("bound 256/1536", lambda P: gp.score_bound(P, prefix=256, prefix2=1536)),
+                     ("bound 384/1536", lambda P: gp.score_bound(P, prefix=384, prefix2=1536)),
+                     ("bound 256/1024", lambda P: gp.score_bound(P, prefix=256, prefix2=1024)), ("bound again", gp.score_bound),
+                     ("i8c", gp.score_i8c), ("f64", gp.score)]:
         fn(Xd)
         torch.cuda.synchronize(); t = time.perf_counter()
         reps = 1 if name == "f64" else 3
