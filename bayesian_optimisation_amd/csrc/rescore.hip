@@ -124,21 +124,44 @@ __global__ __launch_bounds__(SB) void bound_select_kernel(const double *__restri
     }
 }
 
-// per-workgroup maximum of the bounds (NaNs skipped); screen_max_kernel finishes it
-__global__ __launch_bounds__(SB) void bound_max_kernel(const double *__restrict__ ub, int64_t M, double *__restrict__ part) {
-    __shared__ double s_val[SB / 64];
-    double best = -std::numeric_limits<double>::infinity();
+// largest and smallest finite-or-infinite bound (NaNs skipped): part[0 .. n) maxima, part[n .. 2n) minima per workgroup
+__global__ __launch_bounds__(SB) void bound_minmax_kernel(const double *__restrict__ ub, int64_t M, double *__restrict__ part) {
+    __shared__ double s_hi[SB / 64], s_lo[SB / 64];
+    double hi = -std::numeric_limits<double>::infinity(), lo = std::numeric_limits<double>::infinity();
     for (int64_t c = (int64_t)blockIdx.x * SB + threadIdx.x; c < M; c += (int64_t)gridDim.x * SB) {
         const double v = ub[c];
-        if (v > best) best = v;
+        if (v > hi) hi = v;
+        if (v < lo) lo = v;
     }
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) best = fmax(best, __shfl_xor(best, off));
-    if ((threadIdx.x & 63) == 0) s_val[threadIdx.x >> 6] = best;
+    for (int off = 1; off < 64; off <<= 1) {
+        hi = fmax(hi, __shfl_xor(hi, off));
+        lo = fmin(lo, __shfl_xor(lo, off));
+    }
+    if ((threadIdx.x & 63) == 0) { s_hi[threadIdx.x >> 6] = hi; s_lo[threadIdx.x >> 6] = lo; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < SB / 64; ++w) best = fmax(best, s_val[w]);
-        part[blockIdx.x] = best;
+        for (int w = 1; w < SB / 64; ++w) { hi = fmax(hi, s_hi[w]); lo = fmin(lo, s_lo[w]); }
+        part[blockIdx.x] = hi;
+        part[gridDim.x + blockIdx.x] = lo;
+    }
+}
+
+__global__ __launch_bounds__(SB) void bound_minmax_finish_kernel(const double *__restrict__ part, int n, double *__restrict__ out2) {
+    __shared__ double s_hi[SB / 64], s_lo[SB / 64];
+    double hi = -std::numeric_limits<double>::infinity(), lo = std::numeric_limits<double>::infinity();
+    for (int i = threadIdx.x; i < n; i += SB) { hi = fmax(hi, part[i]); lo = fmin(lo, part[n + i]); }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        hi = fmax(hi, __shfl_xor(hi, off));
+        lo = fmin(lo, __shfl_xor(lo, off));
+    }
+    if ((threadIdx.x & 63) == 0) { s_hi[threadIdx.x >> 6] = hi; s_lo[threadIdx.x >> 6] = lo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < SB / 64; ++w) { hi = fmax(hi, s_hi[w]); lo = fmin(lo, s_lo[w]); }
+        out2[0] = hi;
+        out2[1] = lo;
     }
 }
 
@@ -399,11 +422,11 @@ extern "C" int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *
         ++stt.rounds;   // = launches of the fp64 kernels on gathered rows
         return GPBO_OK;
     };
-    auto select = [&](double thr, unsigned long long *K) -> int {
+    const int64_t no_sample = std::numeric_limits<int64_t>::max();
+    auto select = [&](double thr, int64_t stride, unsigned long long *K) -> int {
         if (hipMemsetAsync(count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
         const double slack = (thr == inf) ? 0.0 : 1e-10 * fmax(1.0, fabs(thr));
-        hipLaunchKernelGGL(bound_select_kernel, dim3((unsigned)nblk), dim3(SB), 0, st, ub, M, thr, slack, sample_stride, list, cap,
-                           count);
+        hipLaunchKernelGGL(bound_select_kernel, dim3((unsigned)nblk), dim3(SB), 0, st, ub, M, thr, slack, stride, list, cap, count);
         GPBO_CHECK_LAUNCH();
         if (hipMemcpyAsync(K, count, sizeof(*K), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
@@ -412,52 +435,55 @@ extern "C" int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *
 
     RescoreOut h;
     unsigned long long K = 0;
-    int rc = select(inf, &K);   // the sample and the NaNs
-    if (rc != GPBO_OK) return rc;
-    stt.survivors = (int64_t)K;
-    if ((int64_t)K > cap) { stt.fallback = 1; *stats_host = stt; return GPBO_OK; }
-    rc = exact((int64_t)K, &h);
-    if (rc != GPBO_OK) return rc;
-    double thr = h.res.best_val;   // -inf when every sampled acquisition is NaN: everything survives
-    // A sample's best value is far below the maximum (the 99.9th percentile of the acquisition), and every candidate whose
-    // bound lies above it would be re-scored.  The candidates with the LARGEST bounds are the likely winners: bisect for a
-    // level that keeps about a thousand of them, re-score those, and let their best exact value be the threshold.
+    int rc;
+    double thr = -inf;
+    // A lower bound of the maximum.  The candidates with the LARGEST bounds are the likely winners: bisect for a level that
+    // keeps a few thousand of them (every select is one pass over the bounds), re-score those: their best exact value is
+    // the threshold - on the benchmark problem it IS the maximum.
     {
         double *part = reinterpret_cast<double *>(w + L.part_off);
         double *Ldev = reinterpret_cast<double *>(w + L.L_off);
-        hipLaunchKernelGGL(bound_max_kernel, dim3((unsigned)nblk), dim3(SB), 0, st, ub, M, part);
-        hipLaunchKernelGGL(screen_max_kernel, dim3(1), dim3(SB), 0, st, part, (int)nblk, Ldev, count);
+        const int mblk = (int)(nblk > SCREEN_BLOCKS / 2 ? SCREEN_BLOCKS / 2 : nblk);
+        hipLaunchKernelGGL(bound_minmax_kernel, dim3((unsigned)mblk), dim3(SB), 0, st, ub, M, part);
+        hipLaunchKernelGGL(bound_minmax_finish_kernel, dim3(1), dim3(SB), 0, st, part, mblk, Ldev);
         GPBO_CHECK_LAUNCH();
-        double ub_max = 0.0;
-        if (hipMemcpyAsync(&ub_max, Ldev, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess)
+        double mm[2] = {0.0, 0.0};
+        if (hipMemcpyAsync(mm, Ldev, sizeof(mm), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
         const int64_t want_hi = cap < 4096 ? cap : 4096, want_lo = want_hi / 8;
-        if (thr > -inf && ub_max > thr && ub_max < inf) {
-            double lo = thr, hi = ub_max, level = thr;
+        if (mm[0] > mm[1] && mm[0] < inf && mm[1] > -inf) {
+            double lo = mm[1], hi = mm[0];
             bool found = false;
-            for (int it = 0; it < 24 && !found; ++it) {
+            for (int it = 0; it < 30 && !found; ++it) {
                 const double mid = 0.5 * (lo + hi);
                 if (!(mid > lo) || !(mid < hi)) break;
-                rc = select(mid, &K);   // (list positions beyond cap are not written; the count is exact)
+                rc = select(mid, no_sample, &K);   // (list positions beyond cap are not written; the count is exact)
                 if (rc != GPBO_OK) return rc;
-                // the strided sample is always in the list: count it out
-                const int64_t above = (int64_t)K - (M + sample_stride - 1) / sample_stride;
-                if (above > want_hi) lo = mid;
-                else if (above < want_lo) hi = mid;
-                else { level = mid; found = true; }
+                if ((int64_t)K > want_hi) lo = mid;
+                else if ((int64_t)K < want_lo) hi = mid;
+                else found = true;
             }
-            if (found && (int64_t)K <= cap) {   // the list of the last select() is the one of `level`
+            if (found) {   // the list of the last select() is the one of this level (NaN bounds included)
                 rc = exact((int64_t)K, &h);
                 if (rc != GPBO_OK) return rc;
-                if (h.res.best_val > thr) thr = h.res.best_val;
+                thr = h.res.best_val;
             }
         }
+    }
+    if (!(thr > -inf)) {
+        // no such level (e.g. thousands of equal bounds): the strided sample (and every NaN) gives the first threshold
+        rc = select(inf, sample_stride, &K);
+        if (rc != GPBO_OK) return rc;
+        stt.survivors = (int64_t)K;
+        if ((int64_t)K > cap) { stt.fallback = 1; *stats_host = stt; return GPBO_OK; }
+        rc = exact((int64_t)K, &h);
+        if (rc != GPBO_OK) return rc;
+        thr = h.res.best_val;   // -inf when every sampled acquisition is NaN: everything survives
     }
     const int64_t refine = cap < 4096 ? cap : 4096;
     for (int round = 1; round <= 4; ++round) {
         stt.tau = thr;
-        rc = select(thr, &K);
+        rc = select(thr, no_sample, &K);
         if (rc != GPBO_OK) return rc;
         stt.survivors = (int64_t)K;
         if ((int64_t)K <= cap) {

@@ -381,7 +381,7 @@ def main():
                      "per call); every candidate whose interval reaches the best lower bound is re-scored by the fp64 "
                      "kernels, which decide: same selected point; --dtype i8c times it as the main workload")
         if args.dtype == "f64" and not qei:
-            # ... and with NO approximation at all: branch and bound on the variance reduction of the first N/8 observations
+            # ... and with NO approximation at all: branch and bound on the variance reduction of the first N/16 observations
             kwb = dict(idx_offset=lo, **acq_kw)
             gp.score_async_bound(Xsd, **kwb)
             torch.cuda.synchronize(dev)
@@ -395,8 +395,9 @@ def main():
                 value=(hi - lo) / (ms * 1e-3), unit="candidates/s", ms_per_step=ms, argmax_index=i,
                 argmax_matches_fp64=bool(i == best[1]), steps=reps2, screen=gp.last_screen,
                 note="fp64 throughout, exact: the mean of every candidate, an UPPER bound of its acquisition from |v|^2 over the "
-                     "first N/8 components (1/64 of the variance product), the fp64 kernels on every candidate whose bound "
-                     "reaches the best exact value seen; pruned candidates provably cannot be the maximum nor tie with it; "
+                     "first N/16 components (1/256 of the variance product; N/4 for the survivors), the fp64 kernels on every "
+                     "candidate whose bound reaches the best exact value seen; pruned candidates provably cannot be the "
+                     "maximum nor tie with it; "
                      "--dtype f64b times it as the main workload")
         g1 = os.path.join(REPO, "tests", "golden", "g1_m32.npz")
         if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb") and os.path.exists(g1):
@@ -470,7 +471,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64" if bnd else args.dtype, "data": "synthetic",
             "config": {"workload": (f"{cfg_name}: d={d}, N={N} Sobol observations, M={mtxt} "
                                     f"Sobol candidates per GPU, ARD-SE GP, {acq_txt}, "
-                                    f"{ {'f32': 'fp64 factorisation + fp32 screen + fp64 re-score of the survivors', 'i8': 'fp64 factorisation and means + int8-sliced variance screen + fp64 re-score of the survivors', 'i8c': 'fp64 factorisation and means + coarse int8 variance screen (three digits per operand, six slice products) + fp64 re-score of the survivors', 'f64b': 'fp64 throughout: mean of every candidate, UPPER bound of its acquisition from the variance reduction of the first N/8 observations, fp64 re-score of every candidate whose bound reaches the best exact value (branch and bound, exact)'}.get(args.dtype, 'fp64') }; "
+                                    f"{ {'f32': 'fp64 factorisation + fp32 screen + fp64 re-score of the survivors', 'i8': 'fp64 factorisation and means + int8-sliced variance screen + fp64 re-score of the survivors', 'i8c': 'fp64 factorisation and means + coarse int8 variance screen (three digits per operand, six slice products) + fp64 re-score of the survivors', 'f64b': 'fp64 throughout: mean of every candidate, UPPER bound of its acquisition from the variance reduction of the first N/16 observations (N/4 for the survivors), fp64 re-score of every candidate whose bound reaches the best exact value (branch and bound, exact)'}.get(args.dtype, 'fp64') }; "
                                     f"step = factorise + score all candidates + reduce"),
                        "candidates_total": M_total, "parallelism": f"candidate-sharded x{world}"},
             "ms_per_step_scoring_only": ms_score,
