@@ -82,6 +82,21 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
     double *dmu = dense ? A.alloc<double>(M) : nullptr;
     double *dsig = dense ? A.alloc<double>(M) : nullptr;
     double *dacq = dense ? A.alloc<double>(M) : nullptr;
+    // A caller that asks for the next point only (no dense arrays) gets it by branch and bound on the exact prefix bound
+    // (same point, same NaN count, the plain pass when the bound does not separate the candidates); the same
+    // rule and the same prefix lengths as DeviceGP.score_bound.
+    const bool bound_route = !dense && diag_add == 0.0 && M >= 32768 && Np >= 1024 &&
+                             (acq_kind == GPBO_ACQ_EI || p0 >= 0.0);
+    const int64_t J1 = (Np / 16) / 128 * 128 < 128 ? 128 : (Np / 16) / 128 * 128, J2 = (8 * J1 <= Np) ? 4 * J1 : 0;
+    int64_t bcap = M / 16;   // most survivors the fp64 kernels re-score before the plain pass takes over
+    if (bcap < 65536) bcap = 65536;
+    if (bcap > M) bcap = M;
+    if (bcap < 4096) bcap = 4096;
+    const int64_t bchunk = 1 << 14;
+    const int64_t wresc = bound_route ? gpbo_rescore_workspace_bytes(Np, bcap, bchunk) : 0;
+    if (wresc < 0) return GPBO_ERR_ARG;
+    double *dub = bound_route ? A.alloc<double>(M) : nullptr;
+    char *dresc = bound_route ? A.alloc<char>(wresc + 256) : nullptr;
     if (!A.ok) return GPBO_ERR_WORKSPACE;
     void *st = reinterpret_cast<void *>(A.stream);
 
@@ -104,9 +119,25 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
         return A.sync() ? GPBO_OK : GPBO_ERR_LAUNCH;
     }
     const double prior_var = (1.0 + jitter1) + jitter2;  // diagonal of cov_pred as the reference rounds it
-    rc = gpbo_posterior_acq_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, diag_add, 0, chunk,
-                                dmu, dsig, dacq, dres, dwork, wpost, nullptr, st);
-    if (rc != GPBO_OK) return rc;
+    bool decided = false;
+    if (bound_route) {
+        rc = gpbo_posterior_prefix_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, chunk, J1, nullptr,
+                                       nullptr, dub, dres, dwork, wpost, nullptr, st);
+        if (rc != GPBO_OK) return rc;
+        gpbo_screen_stats stats;
+        char *wr = reinterpret_cast<char *>(((uintptr_t)dresc + 255) & ~(uintptr_t)255);
+        int64_t stride = M / 1024;
+        if (stride < 1) stride = 1;
+        rc = gpbo_bound_select_f64(dXs, M, dub, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, stride, bcap,
+                                   bchunk, J2, dres, &stats, wr, wresc, st);
+        if (rc != GPBO_OK) return rc;
+        decided = !stats.fallback;
+    }
+    if (!decided) {
+        rc = gpbo_posterior_acq_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, diag_add, 0, chunk,
+                                    dmu, dsig, dacq, dres, dwork, wpost, nullptr, st);
+        if (rc != GPBO_OK) return rc;
+    }
     bool okc = A.d2h(result, dres, sizeof(gpbo_result));
     if (mu_out) okc = okc && A.d2h(mu_out, dmu, sizeof(double) * M);
     if (sigma_out) okc = okc && A.d2h(sigma_out, dsig, sizeof(double) * M);

@@ -270,6 +270,9 @@ int gpbo_acq_argmax_f64(const double *mu, const double *sigma, int64_t M, int32_
  * gpbo_nlml_grid_host_f64 = tune_kernel()'s float32 likelihood grid (point_selector.py:104-163): ls_cells [G x d]
  *   host, out [G] host float32; any N (the in-LDS kernel up to gpbo_nlml_grid_max_n(), one factorisation per cell
  *   beyond). */
+/* (When mu_out, sigma_out and acq_out are all NULL, M >= 32768, N > 896 and the acquisition increases with sigma, the next
+ * point is found by branch and bound on the exact prefix bound - gpbo_posterior_prefix_f64 / gpbo_bound_select_f64 below -
+ * instead of computing every variance: same index and NaN count, the value within 1e-12 relative of the plain pass.) */
 int gpbo_select_next_host_f64(const double *X_host, const double *y_host, int64_t N, int32_t d, const double *ls_host,
                               double jitter1, double jitter2, const double *Xs_host, int64_t M, int32_t acq_kind,
                               double p0, double p1, double diag_add, int64_t chunk, double *mu_out_host,

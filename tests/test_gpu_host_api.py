@@ -55,6 +55,25 @@ def test_host_call_is_bitwise_the_device_pointer_path(N, M, d):
     assert np.array_equal(e["acq"], qe.acq.cpu().numpy()) and e["best_idx"] == qe.best_idx
 
 
+def test_host_call_without_dense_outputs_takes_the_exact_prefix_bound_and_returns_the_same_point():
+    """A plain-C caller that asks for the next point only (mu / sigma / acq pointers NULL): from 32,768 candidates and
+    N >= 897 the entry point runs the branch and bound of DESIGN 4d - same index, same NaN count, value equal up to the
+    rounding of the column-split re-scoring launch."""
+    X, y, Xs, ls = make_problem(1300, 50000, 6)
+    Xs = Xs.copy()
+    Xs[41, 3] = np.nan
+    for kw in (dict(acquisition="lcb", explore=4.0), dict(acquisition="ei", f_best=float(y.min()), xi=0.0)):
+        full = H.select_next(X, y, ls, Xs, dense=True, **kw)
+        only = H.select_next(X, y, ls, Xs, dense=False, **kw)
+        assert only["mu"] is None and only["info"] == 0
+        assert only["best_idx"] == full["best_idx"] and only["nan_count"] == full["nan_count"] == 1
+        assert abs(only["best_val"] - full["best_val"]) <= 1e-12 * max(1.0, abs(full["best_val"]))
+    # a negative weight cannot use the bound: the plain pass answers, bit for bit
+    full = H.select_next(X, y, ls, Xs, dense=True, explore=-1.5)
+    only = H.select_next(X, y, ls, Xs, dense=False, explore=-1.5)
+    assert (only["best_idx"], only["best_val"]) == (full["best_idx"], full["best_val"])
+
+
 @pytest.mark.parametrize("name", ["g1_m32", "g1_m50", "g4_ard_n2", "g2_n1_tr", "g2_n5_a", "g2_n20_tr", "g3_n1_2d"])
 def test_host_class_full_path_with_ard_vs_reference_golden(golden, name):
     g = golden(name)
