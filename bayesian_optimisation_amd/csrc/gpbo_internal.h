@@ -44,6 +44,8 @@ __device__ __forceinline__ double gpbo_acquisition(int kind, double mu, double s
 }
 
 // launchers implemented in the individual .hip files (host side, enqueue only)
+// prefix bound: variance floor / pad (see sigma_acq_kernel's epilogue)
+#define GPBO_BOUND_VAR_PAD 1e-9
 int gpbo_kstar_mu_rows(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
                        const double *ls_host, const double *alpha, double diag_add, int64_t cand_base, double *KsT,
                        int64_t ldk, double *mu_part, int64_t store_rows, void *stream);

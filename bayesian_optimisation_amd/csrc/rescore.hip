@@ -102,26 +102,33 @@ __global__ __launch_bounds__(SB) void screen_select_kernel(const double *__restr
 // Prefix-bound screen: survivors of a threshold on the UPPER bounds ub_c >= acq64_c (gpbo_posterior_prefix_f64), plus
 // every NaN (the fp64 pass must see and count it) and the strided sample.  `slack` absorbs the rounding of the two
 // different summation orders (the bound comes from the fused kernel, the exact value from the column-split launch).
+// One atomic per WORKGROUP: each thread counts its survivors first, the workgroup reserves a range of the list, a second
+// sweep writes them (one atomic per wave with a survivor took 170-400 us on 2^21 bounds when thousands survive).
+// list == nullptr: count only (the bisection probes).
 __global__ __launch_bounds__(SB) void bound_select_kernel(const double *__restrict__ ub, int64_t M, double thr, double slack,
                                                           int64_t stride, int64_t *__restrict__ list, int64_t cap,
                                                           unsigned long long *__restrict__ count) {
-    const int lane = threadIdx.x & 63;
+    __shared__ unsigned s_cnt[SB];
+    __shared__ unsigned long long s_base;
     const int64_t step = (int64_t)gridDim.x * SB;
-    const int64_t cmax = (M + step - 1) / step * step;  // whole waves stay in the loop together (ballot)
-    for (int64_t c = (int64_t)blockIdx.x * SB + threadIdx.x; c < cmax; c += step) {
-        bool keep = false;
-        if (c < M) keep = !(ub[c] + slack < thr) || (c % stride) == 0;  // !(x < thr): also true for NaN
-        const unsigned long long m = __ballot(keep);
-        if (m) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(m));
-            base = __shfl(base, 0);
-            if (keep) {
-                const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                if ((int64_t)pos < cap) list[pos] = c;
-            }
-        }
+    unsigned mine = 0;
+    for (int64_t c = (int64_t)blockIdx.x * SB + threadIdx.x; c < M; c += step)
+        mine += (!(ub[c] + slack < thr) || (c % stride) == 0) ? 1u : 0u;   // !(x < thr): also true for NaN
+    s_cnt[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int t = 0; t < SB; ++t) { const unsigned v = s_cnt[t]; s_cnt[t] = tot; tot += v; }   // exclusive scan
+        s_base = tot ? atomicAdd(count, (unsigned long long)tot) : 0ull;
     }
+    __syncthreads();
+    if (!list || !mine) return;
+    unsigned long long pos = s_base + s_cnt[threadIdx.x];
+    for (int64_t c = (int64_t)blockIdx.x * SB + threadIdx.x; c < M; c += step)
+        if (!(ub[c] + slack < thr) || (c % stride) == 0) {
+            if ((int64_t)pos < cap) list[pos] = c;
+            ++pos;
+        }
 }
 
 // largest and smallest finite-or-infinite bound (NaNs skipped): part[0 .. n) maxima, part[n .. 2n) minima per workgroup
@@ -423,10 +430,11 @@ extern "C" int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *
         return GPBO_OK;
     };
     const int64_t no_sample = std::numeric_limits<int64_t>::max();
-    auto select = [&](double thr, int64_t stride, unsigned long long *K) -> int {
+    auto select = [&](double thr, int64_t stride, unsigned long long *K, bool count_only = false) -> int {
         if (hipMemsetAsync(count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
         const double slack = (thr == inf) ? 0.0 : 1e-10 * fmax(1.0, fabs(thr));
-        hipLaunchKernelGGL(bound_select_kernel, dim3((unsigned)nblk), dim3(SB), 0, st, ub, M, thr, slack, stride, list, cap, count);
+        hipLaunchKernelGGL(bound_select_kernel, dim3((unsigned)nblk), dim3(SB), 0, st, ub, M, thr, slack, stride,
+                           count_only ? (int64_t *)nullptr : list, cap, count);
         GPBO_CHECK_LAUNCH();
         if (hipMemcpyAsync(K, count, sizeof(*K), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
@@ -452,18 +460,20 @@ extern "C" int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *
             return GPBO_ERR_LAUNCH;
         const int64_t want_hi = cap < 4096 ? cap : 4096, want_lo = want_hi / 8;
         if (mm[0] > mm[1] && mm[0] < inf && mm[1] > -inf) {
-            double lo = mm[1], hi = mm[0];
+            double lo = mm[1], hi = mm[0], level = mm[0];
             bool found = false;
             for (int it = 0; it < 30 && !found; ++it) {
                 const double mid = 0.5 * (lo + hi);
                 if (!(mid > lo) || !(mid < hi)) break;
-                rc = select(mid, no_sample, &K);   // (list positions beyond cap are not written; the count is exact)
+                rc = select(mid, no_sample, &K, true);   // count only
                 if (rc != GPBO_OK) return rc;
                 if ((int64_t)K > want_hi) lo = mid;
                 else if ((int64_t)K < want_lo) hi = mid;
-                else found = true;
+                else { found = true; level = mid; }
             }
-            if (found) {   // the list of the last select() is the one of this level (NaN bounds included)
+            if (found) {   // list the candidates of this level (NaN bounds included) and re-score them
+                rc = select(level, no_sample, &K);
+                if (rc != GPBO_OK) return rc;
                 rc = exact((int64_t)K, &h);
                 if (rc != GPBO_OK) return rc;
                 thr = h.res.best_val;

@@ -305,7 +305,11 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
         for (int q = 1; q < WQ; ++q) ssq += red[q * BM + tid];
         double mu = 0.0;
         for (int s = 0; s < nsl; ++s) mu += mu_part[(int64_t)s * ldk + c];
-        const double var = prior_var - ssq;
+        double var = prior_var - ssq;
+        // prefix bound (ncb > 0): the plain pass takes sqrt(|var|), and a variance that rounding has pushed a hair below
+        // zero (a candidate on top of an observation) can have a LARGER magnitude than the prefix's: clamp and pad, so that
+        // the bound holds whenever the plain variance is above -1e-9 (observed: 1e-13)
+        if (ncb > 0) var = fmax(var, 0.0) + GPBO_BOUND_VAR_PAD;
         const double sigma = sqrt(fabs(var));  // abs, then sqrt: point_selector.py:98
         const double acq = acquisition(acq_kind, mu, sigma, p0, p1);
         if (valid) {
@@ -376,7 +380,8 @@ __global__ __launch_bounds__(256) void split_finish_kernel(const double *__restr
                                                            double *__restrict__ sigma_out, double *__restrict__ acq_out,
                                                            double *__restrict__ var_out,
                                                            double *__restrict__ part_val, int64_t *__restrict__ part_idx,
-                                                           unsigned long long *__restrict__ nan_count) {
+                                                           unsigned long long *__restrict__ nan_count,
+                                                           double var_pad /* > 0: prefix bound, see sigma_acq_kernel */) {
     __shared__ double s_val[4];
     __shared__ int64_t s_idx[4];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -385,7 +390,8 @@ __global__ __launch_bounds__(256) void split_finish_kernel(const double *__restr
     double ssq = 0.0, mu = 0.0;
     for (int q = 0; q < S; ++q) ssq += ss_part[(int64_t)q * ldk + c];
     for (int q = 0; q < nsl; ++q) mu += mu_part[(int64_t)q * ldk + c];
-    const double var = prior_var - ssq;
+    double var = prior_var - ssq;
+    if (var_pad > 0.0) var = fmax(var, 0.0) + var_pad;
     const double sigma = sqrt(fabs(var));
     const double acq = acquisition(acq_kind, mu, sigma, p0, p1);
     if (valid) {
@@ -682,7 +688,7 @@ int gpbo_launch_split_finish(const double *ss_part, int S, int64_t ldk, const do
                              unsigned long long *nan_count, hipStream_t st) {
     const int64_t nb = (Mc + 255) / 256;
     hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, ss_part, S, ldk, mu_part, nsl, Mc, prior_var,
-                       acq_kind, p0, p1, idx_base, mu_out, sigma_out, acq_out, var_out, part_val, part_idx, nan_count);
+                       acq_kind, p0, p1, idx_base, mu_out, sigma_out, acq_out, var_out, part_val, part_idx, nan_count, 0.0);
     GPBO_CHECK_LAUNCH();
     return GPBO_OK;
 }
@@ -845,7 +851,7 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                                mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
                                acq_out ? acq_out + s : nullptr, (double *)nullptr, part_val + nparts, part_idx + nparts,
-                               nan_count);
+                               nan_count, n_prefix ? GPBO_BOUND_VAR_PAD : 0.0);
         } else if (S > 1) {
             hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk, (unsigned)S), dim3(NW * 64), 0, st, KsT[b], chunk, U,
                                (int)Np, mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1,
@@ -855,7 +861,7 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                                mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
                                acq_out ? acq_out + s : nullptr, (double *)nullptr, part_val + nparts, part_idx + nparts,
-                               nan_count);
+                               nan_count, n_prefix ? GPBO_BOUND_VAR_PAD : 0.0);
         } else {
 #define GPBO_SIGMA_LAUNCH(V)                                                                                        \
     hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT[b], chunk, U, (int)Np,          \
@@ -978,7 +984,7 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
                                xg_env, (int)nblk, 0);
             hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, xg_env, chunk, mu_part,
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
-                               (double *)nullptr, (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch);
+                               (double *)nullptr, (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, 0.0);
         } else {
             hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,

@@ -8,7 +8,7 @@ import numpy as np, torch
 from bayesian_optimisation_amd import DeviceGP, _lib
 from bayesian_optimisation_amd.gp_device import PRIOR_VAR
 from bayesian_optimisation_amd.synthetic import make_problem
-N, M, d = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 1 << 19, 8
+N, M, d = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(__import__("os").environ.get("BENCH_M", 1 << 19)), 8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["i8", "f64"]
 X, y, Xs, ls = make_problem(N, M, d)
