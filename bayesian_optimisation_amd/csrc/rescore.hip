@@ -445,35 +445,128 @@ extern "C" int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *
     unsigned long long K = 0;
     int rc;
     double thr = -inf;
+    double *part = reinterpret_cast<double *>(w + L.part_off);
+    double *Ldev = reinterpret_cast<double *>(w + L.L_off);
+    // smallest and largest value of n bounds (NaNs skipped)
+    auto minmax = [&](const double *v, int64_t n, double *mm) -> int {
+        int64_t blk = (n + SB - 1) / SB;
+        if (blk > SCREEN_BLOCKS / 2) blk = SCREEN_BLOCKS / 2;
+        hipLaunchKernelGGL(bound_minmax_kernel, dim3((unsigned)blk), dim3(SB), 0, st, v, n, part);
+        hipLaunchKernelGGL(bound_minmax_finish_kernel, dim3(1), dim3(SB), 0, st, part, (int)blk, Ldev);
+        GPBO_CHECK_LAUNCH();
+        if (hipMemcpyAsync(mm, Ldev, 2 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return GPBO_ERR_LAUNCH;
+        return GPBO_OK;
+    };
+    // a level between mm[1] and mm[0] that `counter(level)` candidates reach, want_lo <= count <= want_hi
+    auto bisect = [&](const double *mm, int64_t want_lo, int64_t want_hi, auto &&counter, double *level) -> int {
+        *level = inf;   // "none found"
+        if (!(mm[0] > mm[1]) || !(mm[0] < inf) || !(mm[1] > -inf)) return GPBO_OK;
+        double lo = mm[1], hi = mm[0];
+        for (int it = 0; it < 30; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (!(mid > lo) || !(mid < hi)) break;
+            unsigned long long c = 0;
+            int r = counter(mid, &c);
+            if (r != GPBO_OK) return r;
+            if ((int64_t)c > want_hi) lo = mid;
+            else if ((int64_t)c < want_lo) hi = mid;
+            else { *level = mid; break; }
+        }
+        return GPBO_OK;
+    };
+    auto count_ub = [&](double level, unsigned long long *c) -> int { return select(level, no_sample, c, true); };
+    const int64_t want_hi = cap < 4096 ? cap : 4096, want_lo = want_hi / 8;
+    double mm[2] = {0.0, 0.0};
+    rc = minmax(ub, M, mm);
+    if (rc != GPBO_OK) return rc;
+
+    // ---- the usual case in one sweep: second-level bounds BEFORE any fp64 row, one fp64 launch --------------------------
+    // The K1 candidates with the largest first-level bounds (a few times more than can survive) get the second-level
+    // bound; the few hundred with the largest SECOND-level bounds are re-scored: t = their best exact value.  If t is at
+    // least both levels, nobody else can reach it: outside the K1, ub1 < level1 <= t; inside, ub2 < level2 <= t.  Done.
+    // Anything else (levels not found, t below a level) leaves t as a valid threshold for the general loop below.
+    if (n_prefix2 > 0) {
+        int64_t k1 = M / 64;
+        if (k1 < 2048) k1 = 2048;
+        if (k1 > cap / 2) k1 = cap / 2;
+        double level1 = inf;
+        rc = bisect(mm, k1 - k1 / 3, k1 + k1 / 2, count_ub, &level1);
+        if (rc != GPBO_OK) return rc;
+        if (level1 < inf) {
+            rc = select(level1, no_sample, &K);
+            if (rc != GPBO_OK) return rc;
+            const int64_t K1 = (int64_t)K;
+            if (K1 >= 1 && K1 <= cap) {
+                const int64_t tot = K1 * d;
+                hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((tot + SB - 1) / SB)), dim3(SB), 0, st, Xs, (int)d, list, K1,
+                                   rows);
+                GPBO_CHECK_LAUNCH();
+                int64_t chunk = chunk64;
+                const int64_t kpad = (K1 + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
+                if (chunk > kpad) chunk = kpad;
+                double *ub2 = sig64;   // (acq64 / mu64 are overwritten by the fp64 launch below; sig64 is too, AFTER ub2's last use)
+                rc = gpbo_posterior_acq_f64_split(rows, K1, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1, 0.0, 0,
+                                                  chunk, nullptr, nullptr, ub2, &out->res, post, L.post_bytes, nullptr,
+                                                  GPBO_RESCORE_SPLIT_MAX, n_prefix2, stream);
+                if (rc != GPBO_OK) return rc;
+                int64_t *list2 = reinterpret_cast<int64_t *>(mu64);
+                int64_t rblk = (K1 + SB - 1) / SB;
+                if (rblk > SCREEN_BLOCKS) rblk = SCREEN_BLOCKS;
+                auto refine_ub2 = [&](double level, unsigned long long *c) -> int {   // list2 <- {i : ub2_i >= level}
+                    if (hipMemsetAsync(count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
+                    hipLaunchKernelGGL(bound_refine_kernel, dim3((unsigned)rblk), dim3(SB), 0, st, ub2, list, K1, level,
+                                       1e-10 * fmax(1.0, fabs(level)), list2, count);
+                    GPBO_CHECK_LAUNCH();
+                    if (hipMemcpyAsync(c, count, sizeof(*c), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess)
+                        return GPBO_ERR_LAUNCH;
+                    return GPBO_OK;
+                };
+                double mm2[2], level2 = inf;
+                rc = minmax(ub2, K1, mm2);
+                if (rc != GPBO_OK) return rc;
+                const int64_t t_hi = K1 < 1024 ? K1 : 1024;
+                rc = bisect(mm2, t_hi / 4, t_hi, refine_ub2, &level2);
+                if (rc != GPBO_OK) return rc;
+                if (level2 < inf) {
+                    unsigned long long KT = 0;
+                    rc = refine_ub2(level2, &KT);   // (the probe that found the level left exactly this list; kept explicit)
+                    if (rc != GPBO_OK) return rc;
+                    if (KT >= 1 && (int64_t)KT <= cap) {
+                        // (the K1 list is not needed again: a miss goes to the general loop, which selects afresh)
+                        if (hipMemcpyAsync(list, list2, sizeof(int64_t) * KT, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                            return GPBO_ERR_LAUNCH;
+                        rc = exact((int64_t)KT, &h);
+                        if (rc != GPBO_OK) return rc;
+                        thr = h.res.best_val;
+                        stt.survivors = K1;
+                        stt.tau = thr;
+                        if (thr >= level1 && thr >= level2) {
+                            if (hipMemcpyAsync(result, &out->res, sizeof(gpbo_result), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                                return GPBO_ERR_LAUNCH;
+                            *stats_host = stt;
+                            return GPBO_OK;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- general route ---------------------------------------------------------------------------------------------------
     // A lower bound of the maximum.  The candidates with the LARGEST bounds are the likely winners: bisect for a level that
     // keeps a few thousand of them (every select is one pass over the bounds), re-score those: their best exact value is
     // the threshold - on the benchmark problem it IS the maximum.
-    {
-        double *part = reinterpret_cast<double *>(w + L.part_off);
-        double *Ldev = reinterpret_cast<double *>(w + L.L_off);
-        const int mblk = (int)(nblk > SCREEN_BLOCKS / 2 ? SCREEN_BLOCKS / 2 : nblk);
-        hipLaunchKernelGGL(bound_minmax_kernel, dim3((unsigned)mblk), dim3(SB), 0, st, ub, M, part);
-        hipLaunchKernelGGL(bound_minmax_finish_kernel, dim3(1), dim3(SB), 0, st, part, mblk, Ldev);
-        GPBO_CHECK_LAUNCH();
-        double mm[2] = {0.0, 0.0};
-        if (hipMemcpyAsync(mm, Ldev, sizeof(mm), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-            return GPBO_ERR_LAUNCH;
-        const int64_t want_hi = cap < 4096 ? cap : 4096, want_lo = want_hi / 8;
-        if (mm[0] > mm[1] && mm[0] < inf && mm[1] > -inf) {
-            double lo = mm[1], hi = mm[0], level = mm[0];
-            bool found = false;
-            for (int it = 0; it < 30 && !found; ++it) {
-                const double mid = 0.5 * (lo + hi);
-                if (!(mid > lo) || !(mid < hi)) break;
-                rc = select(mid, no_sample, &K, true);   // count only
-                if (rc != GPBO_OK) return rc;
-                if ((int64_t)K > want_hi) lo = mid;
-                else if ((int64_t)K < want_lo) hi = mid;
-                else { found = true; level = mid; }
-            }
-            if (found) {   // list the candidates of this level (NaN bounds included) and re-score them
-                rc = select(level, no_sample, &K);
-                if (rc != GPBO_OK) return rc;
+    if (!(thr > -inf)) {
+        double level = inf;
+        rc = bisect(mm, want_lo, want_hi, count_ub, &level);
+        if (rc != GPBO_OK) return rc;
+        if (level < inf) {   // list the candidates of this level (NaN bounds included) and re-score them
+            rc = select(level, no_sample, &K);
+            if (rc != GPBO_OK) return rc;
+            if ((int64_t)K >= 1 && (int64_t)K <= cap) {
                 rc = exact((int64_t)K, &h);
                 if (rc != GPBO_OK) return rc;
                 thr = h.res.best_val;
