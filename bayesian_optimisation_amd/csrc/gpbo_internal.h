@@ -45,7 +45,15 @@ __device__ __forceinline__ double gpbo_acquisition(int kind, double mu, double s
 
 // launchers implemented in the individual .hip files (host side, enqueue only)
 // prefix bound: variance floor / pad (see sigma_acq_kernel's epilogue)
-#define GPBO_BOUND_VAR_PAD 1e-9
+#define GPBO_BOUND_VAR_PAD 1e-8
+// K(X*,X) with the distances on the matrix cores (kstar_mfma.hip): prefix-bound route only
+int64_t gpbo_kstar_mfma_prep_bytes(int64_t Np);
+int gpbo_kstar_mfma_slice(int64_t Np);
+int gpbo_kstar_mfma_prep(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host, const double *alpha,
+                         void *prep_buf, void *stream);
+int gpbo_kstar_mu_mfma(const double *Xs, int64_t Mc, int64_t N, int64_t Np, int32_t d, const double *ls_host,
+                       const double *alpha, const void *prep_buf, double *KsT, int64_t ldk, double *mu_part,
+                       int64_t store_rows, void *stream);
 int gpbo_kstar_mu_rows(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
                        const double *ls_host, const double *alpha, double diag_add, int64_t cand_base, double *KsT,
                        int64_t ldk, double *mu_part, int64_t store_rows, void *stream);

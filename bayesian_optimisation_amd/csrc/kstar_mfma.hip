@@ -1,0 +1,313 @@
+// K(X*,X) entries and the mean with the pair distances on the fp64 matrix cores - for the PREFIX-BOUND route only
+// (sigma_acq.hip: gpbo_posterior_prefix_f64), where the first pass needs a BOUND, not the reference's bits.
+//
+//     t_ci = |a_c - b_i|^2 = |a_c|^2 + |b_i|^2 - 2 a_c . b_i,        k_ci = exp(-t_ci)           (point_selector.py:180-189)
+// with a = (x* - m) / (ls sqrt 2), b = (x - m) / (ls sqrt 2), m = the mean of the scaled observations (centring keeps the
+// norms, hence the cancellation, small).  The expanded form is ONE inner product of length d + 2,
+//     t_ci = (b_i1 .. b_id, 1, |b_i|^2) . (-2 a_c1 .. -2 a_cd, |a_c|^2, 1),
+// i.e. ceil((d + 2) / 4) v_mfma_f64_16x16x4_f64 per 16 x 16 block of pairs instead of 2 d fp64 VALU instructions per pair;
+// what stays on the VALU is exp(-t) and the mean's multiply-add (25 of the 36 instructions of kstar_mu_kernel).
+// Measured (MI355X, N = 4096, 2^21 candidates, whole bound route, same box): 14.8-15.0 ms against 15.7 ms with the
+// difference-form kernel, i.e. 0.56 against 0.61 ms per 2^17 x 4096 entries - less than the instruction count promises:
+// the four exp chains of a tile are issued one after the other, and neither operands from LDS instead of L2, nor
+// branch-free stores, nor three-address FMAs spelled in asm moved it (14.7-15.0 ms all).
+//
+// Accuracy - why this is NOT the fp64 path's kernel.  The difference form's error in t is relative (t 1e-16); the expanded
+// form's is ABSOLUTE: every one of the d + 2 fused steps rounds at the size of the partial sum, <= 2 (|a|^2 + |b|^2), so
+//     |dt_ci| <= gamma (|a_c|^2 + |b_i|^2),   gamma = 2 (2 (d + 2) + 8) 2^-53   (inputs' own roundings included, x2 to spare)
+// and since |dk| <= k |dt| and k <= 1, the mean  mu_c = sum_i k_ci alpha_i  is off by at most
+//     slack_c = gamma (|a_c|^2 S0 + S1),      S0 = sum_i |alpha_i|,   S1 = sum_i |alpha_i| |b_i|^2
+// (N = 4096 benchmark problem: S0 = 7.8e4, slack ~ 1e-9; the 5e-15 entry bound of tests/test_kstar_mu cannot be met).
+// The prefix-bound route only needs mu from BELOW (both acquisitions decrease with the mean): this kernel reports
+// mu_c - slack_c, so the upper bound it feeds stays an upper bound; the entries it stores (first `store_rows` observations)
+// feed |v[:J]|^2, whose error (<= 3e-10) is inside the variance pad GPBO_BOUND_VAR_PAD.  The candidates that survive
+// are re-scored by the difference-form kernel (kernel_build.hip) - the answer never contains a number from this file.
+//
+// Layout.  Workgroup = 4 waves, wave = 64 candidates (4 MFMA column tiles) x one slice of 64 observations (4 row tiles):
+// output register r of lane (l15, l4) is the pair (observation 16 ot + l4 + 4 r, candidate 16 tc + l15), so a lane keeps
+// the mean of ITS candidate over its rows and the four lanes of a candidate are added once at the end; K*^T rows are
+// stored as 128-byte segments (16 candidates).  mu_part is [Np / slice][ldk] with slice = gpbo_kstar_mfma_slice(Np)
+// observations per workgroup (kstar_mu_kernel's layout with a coarser slice).
+#include "gpbo_internal.h"
+
+#include <type_traits>
+
+namespace {
+
+constexpr int KP_MAX = 20;                 // d + 2 <= 18, padded to a multiple of 4
+constexpr int KS = GPBO_KS_SLICE;          // observations per slice (64)
+constexpr int OB_MAX = 256;                // observations per workgroup (LDS: 256 x 21 doubles)
+constexpr double PAD_ROW_NORM = 1e300;     // |b|^2 of padding rows i >= N: t = 1e300, k = 0 exactly
+
+struct ObsPrep {
+    double m[GPBO_MAX_D];   // centre (scaled coordinates)
+    double S0, S1;
+};
+
+struct IscArgs {
+    double isc[GPBO_MAX_D];  // 1 / (ls_k sqrt 2)
+};
+
+__device__ const double kExp2TabM[32] = {
+    1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237,
+    1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775,
+    1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332,
+    1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832,
+    1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228,
+    1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965,
+    1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072,
+    1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002};
+
+// exp(-t), t >= 0: the algorithm of kernel_build.hip's exp_neg (2^(n/32) table x degree-6 polynomial)
+__device__ __forceinline__ double exp_neg_m(double t, const double *tab) {
+    const double u = -t;
+    const double z = fma(u, 46.16624130844683, 6755399441055744.0);
+    const int ni = __double2loint(z);
+    const double fn = z - 6755399441055744.0;
+    double r = fma(fn, -0.02166084939249829, u);
+    r = fma(fn, -7.247021293269686e-19, r);
+    const double T = tab[ni & 31];
+    double q = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    q = fma(r, q, 1.0 / 24.0);
+    q = fma(r, q, 1.0 / 6.0);
+    q = fma(r, q, 0.5);
+    q = fma(r, q, 1.0);
+    const double v = fma(T * r, q, T);
+    const double s = __hiloint2double(__double2hiint(v) + ((ni >> 5) << 20), __double2loint(v));
+    return (t <= 708.0) ? s : 0.0;
+}
+
+// One workgroup: centre, rows (b_1 .. b_d, 1, |b|^2, 0 ..) of the observations, S0, S1.  N x d is small (4096 x 8).
+__global__ __launch_bounds__(1024) void obs_prep_kernel(const double *__restrict__ X, int N, int Np, int d, IscArgs ls,
+                                                        const double *__restrict__ alpha, int KP, double *__restrict__ Bp,
+                                                        ObsPrep *__restrict__ prep) {
+    __shared__ double red[1024];
+    __shared__ double m_s[GPBO_MAX_D];
+    const int t = threadIdx.x;
+    for (int k = 0; k < d; ++k) {
+        double s = 0.0;
+        for (int i = t; i < N; i += 1024) s += X[(int64_t)i * d + k] * ls.isc[k];
+        red[t] = s;
+        __syncthreads();
+        for (int h = 512; h > 0; h >>= 1) {
+            if (t < h) red[t] += red[t + h];
+            __syncthreads();
+        }
+        if (t == 0) m_s[k] = red[0] / (double)N;
+        __syncthreads();
+    }
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = t; i < Np; i += 1024) {
+        double *row = Bp + (int64_t)i * KP;
+        if (i < N) {
+            double nb = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double b = fma(X[(int64_t)i * d + k], ls.isc[k], -m_s[k]);
+                row[k] = b;
+                nb = fma(b, b, nb);
+            }
+            row[d] = 1.0;
+            row[d + 1] = nb;
+            for (int k = d + 2; k < KP; ++k) row[k] = 0.0;
+            const double aa = fabs(alpha[i]);
+            s0 += aa;
+            s1 = fma(aa, nb, s1);
+        } else {
+            for (int k = 0; k < KP; ++k) row[k] = 0.0;
+            row[d + 1] = PAD_ROW_NORM;
+        }
+    }
+    red[t] = s0;
+    __syncthreads();
+    for (int h = 512; h > 0; h >>= 1) {
+        if (t < h) red[t] += red[t + h];
+        __syncthreads();
+    }
+    const double S0 = red[0];
+    __syncthreads();
+    red[t] = s1;
+    __syncthreads();
+    for (int h = 512; h > 0; h >>= 1) {
+        if (t < h) red[t] += red[t + h];
+        __syncthreads();
+    }
+    if (t == 0) {
+        for (int k = 0; k < GPBO_MAX_D; ++k) prep->m[k] = k < d ? m_s[k] : 0.0;
+        prep->S0 = S0;
+        prep->S1 = red[0];
+    }
+}
+
+template <int KQ /* (d + 2 padded) / 4 */>
+__global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__restrict__ Xs, int64_t Mc, int d, IscArgs ls,
+                                                            const double *__restrict__ Bp, const ObsPrep *__restrict__ prep,
+                                                            const double *__restrict__ alpha, int N, double gamma,
+                                                            double *__restrict__ KsT, int64_t ldk,
+                                                            double *__restrict__ mu_part, int store_rows,
+                                                            int OB /* observations per workgroup = per mean partial */) {
+    constexpr int KP = 4 * KQ;
+    constexpr int NC = 4;   // candidate tiles per wave
+    constexpr int LDB = KP + 1;   // LDS row stride of the observation rows (odd: the 16 rows of a tile land on different banks)
+    __shared__ double tab[32];
+    __shared__ double Bs[OB_MAX * LDB];
+    __shared__ double As[OB_MAX];   // alpha of the workgroup's observations (0 beyond N: those rows give k = 0 anyway)
+    if (threadIdx.x < 32) tab[threadIdx.x] = kExp2TabM[threadIdx.x];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t cbase = (int64_t)blockIdx.x * 256 + wid * 64;
+    const int n0 = blockIdx.y * OB;
+    // the workgroup's observation rows, once: the MFMA operands then come from LDS (a global load per operand and tile left
+    // every wave waiting on L2 at the top of every tile)
+    for (int e = threadIdx.x; e < OB * KP; e += 256) {
+        const int row = e / KP, k = e - row * KP;
+        Bs[row * LDB + k] = Bp[(int64_t)(n0 + row) * KP + k];
+    }
+    for (int e = threadIdx.x; e < OB; e += 256) As[e] = (n0 + e < N) ? alpha[n0 + e] : 0.0;
+    // candidate operands: element e = 4 q + l4 of (-2 a_1 .. -2 a_d, |a|^2, 1, 0 ..) for candidate cbase + 16 tc + l15
+    double bop[NC][KQ], slack[NC];
+    bool isnan_c[NC];
+#pragma unroll
+    for (int tc = 0; tc < NC; ++tc) {
+        const int64_t c = cbase + 16 * tc + l15;
+        double na = 0.0;
+        double sel[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) sel[q] = 0.0;
+        bool bad = false;
+        for (int k = 0; k < d; ++k) {
+            const double x = (c < Mc) ? Xs[c * d + k] : 0.0;
+            bad = bad || (x != x);
+            const double a = fma(x, ls.isc[k], -prep->m[k]);
+            na = fma(a, a, na);
+#pragma unroll
+            for (int q = 0; q < KQ; ++q)
+                if (4 * q + l4 == k) sel[q] = -2.0 * a;
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            if (4 * q + l4 == d) sel[q] = na;
+            if (4 * q + l4 == d + 1) sel[q] = 1.0;
+            bop[tc][q] = sel[q];
+        }
+        slack[tc] = gamma * fma(na, prep->S0, prep->S1);
+        isnan_c[tc] = bad;
+    }
+    __syncthreads();
+
+    double mu[NC];
+#pragma unroll
+    for (int tc = 0; tc < NC; ++tc) mu[tc] = 0.0;
+
+    // one tile of 16 observations against the wave's 64 candidates; STORE: this tile's K*^T rows are kept
+    auto tile = [&](int ot, auto store_c) {
+        constexpr bool STORE = decltype(store_c)::value;
+        const int r0 = n0 + 16 * ot;
+        // observation operand: element 4 q + l4 of row r0 + l15
+        double aop[KQ];
+        const double *brow = Bs + (16 * ot + l15) * LDB + l4;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) aop[q] = brow[4 * q];
+        double al[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) al[r] = As[16 * ot + l4 + 4 * r];
+#pragma unroll
+        for (int tc = 0; tc < NC; ++tc) {
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) acc = mfma_f64_16x16x4(aop[q], bop[tc][q], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double t = fmax(acc[r], 0.0);   // (a rounding can leave a tiny negative distance)
+                const double k = exp_neg_m(t, tab);
+                mu[tc] = fma(k, al[r], mu[tc]);
+                if (STORE) KsT[(int64_t)(r0 + l4 + 4 * r) * ldk + cbase + 16 * tc + l15] = k;
+            }
+        }
+    };
+    int ot_store = (store_rows - n0) / 16;   // store_rows and n0 are multiples of 64
+    if (ot_store < 0) ot_store = 0;
+    if (ot_store > OB / 16) ot_store = OB / 16;
+    int ot = 0;
+#pragma unroll 1
+    for (; ot < ot_store; ++ot) tile(ot, std::true_type{});
+#pragma unroll 1
+    for (; ot < OB / 16; ++ot) tile(ot, std::false_type{});
+#pragma unroll
+    for (int tc = 0; tc < NC; ++tc) {
+        double v = mu[tc];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (l4 == 0) {
+            if (blockIdx.y == 0) v -= slack[tc];   // the mean from BELOW: see the header
+            mu_part[(int64_t)blockIdx.y * ldk + cbase + 16 * tc + l15] = isnan_c[tc] ? __builtin_nan("") : v;
+        }
+    }
+}
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+// observations per workgroup = per partial of the mean (mu_part has Np / slice rows): the candidate operands of a wave
+// (its share of the prologue) are then used for 256 observations where Np allows, not for 64
+int gpbo_kstar_mfma_slice(int64_t Np) { return (Np % 256 == 0) ? 256 : 128; }
+
+int64_t gpbo_kstar_mfma_prep_bytes(int64_t Np) {
+    return align_up((int64_t)sizeof(double) * Np * KP_MAX, 256) + align_up((int64_t)sizeof(ObsPrep), 256);
+}
+
+// once per call: centred observation rows, S0, S1 (alpha: the factorisation's, padded with zeros to Np)
+int gpbo_kstar_mfma_prep(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host, const double *alpha,
+                         void *prep_buf, void *stream) {
+    if (!X || !ls_host || !alpha || !prep_buf || N < 1 || Np < N || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
+    IscArgs ls;
+    for (int k = 0; k < GPBO_MAX_D; ++k) ls.isc[k] = 0.0;
+    for (int k = 0; k < d; ++k) {
+        if (!(ls_host[k] > 0.0)) return GPBO_ERR_ARG;
+        ls.isc[k] = 1.0 / (ls_host[k] * 1.4142135623730950488);
+    }
+    const int KP = (d + 2 + 3) / 4 * 4;
+    double *Bp = reinterpret_cast<double *>(prep_buf);
+    ObsPrep *prep = reinterpret_cast<ObsPrep *>(reinterpret_cast<char *>(prep_buf) +
+                                                align_up((int64_t)sizeof(double) * Np * KP_MAX, 256));
+    hipLaunchKernelGGL(obs_prep_kernel, dim3(1), dim3(1024), 0, gpbo_stream(stream), X, (int)N, (int)Np, (int)d, ls, alpha, KP,
+                       Bp, prep);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
+// K*^T rows n < store_rows (a multiple of 64) and the mean partials of all observations for Mc candidates: the interface of
+// gpbo_kstar_mu_rows, the mean reported from BELOW by the error bound of the expanded distance (see the header).
+int gpbo_kstar_mu_mfma(const double *Xs, int64_t Mc, int64_t N, int64_t Np, int32_t d, const double *ls_host,
+                       const double *alpha, const void *prep_buf, double *KsT, int64_t ldk, double *mu_part,
+                       int64_t store_rows, void *stream) {
+    if (!Xs || !ls_host || !alpha || !prep_buf || !KsT || !mu_part) return GPBO_ERR_ARG;
+    if (Mc < 1 || N < 1 || Np < N || Np % 128 || ldk % GPBO_CHUNK_GRANULE || Mc > ldk || d < 1 || d > GPBO_MAX_D)
+        return GPBO_ERR_ARG;
+    if (store_rows < 0 || store_rows > Np || store_rows % KS) return GPBO_ERR_ARG;
+    IscArgs ls;
+    for (int k = 0; k < GPBO_MAX_D; ++k) ls.isc[k] = 0.0;
+    for (int k = 0; k < d; ++k) ls.isc[k] = 1.0 / (ls_host[k] * 1.4142135623730950488);
+    const int KQ = (d + 2 + 3) / 4;
+    const double gamma = 2.0 * (2.0 * (d + 2) + 8.0) * 1.1102230246251565e-16;   // 2^-53
+    const double *Bp = reinterpret_cast<const double *>(prep_buf);
+    const ObsPrep *prep = reinterpret_cast<const ObsPrep *>(reinterpret_cast<const char *>(prep_buf) +
+                                                            align_up((int64_t)sizeof(double) * Np * KP_MAX, 256));
+    const int64_t used = (Mc + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
+    const int OB = gpbo_kstar_mfma_slice(Np);
+    dim3 grid((unsigned)(used / 256), (unsigned)(Np / OB));
+#define GPBO_KM_LAUNCH(Q)                                                                                              \
+    hipLaunchKernelGGL((kstar_mu_mfma_kernel<Q>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, (int)d, ls, Bp, prep, alpha, \
+                       (int)N, gamma, KsT, ldk, mu_part, (int)store_rows, OB)
+    switch (KQ) {
+        case 1: GPBO_KM_LAUNCH(1); break;
+        case 2: GPBO_KM_LAUNCH(2); break;
+        case 3: GPBO_KM_LAUNCH(3); break;
+        case 4: GPBO_KM_LAUNCH(4); break;
+        case 5: GPBO_KM_LAUNCH(5); break;
+        default: return GPBO_ERR_ARG;
+    }
+#undef GPBO_KM_LAUNCH
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}

@@ -488,7 +488,7 @@ Helper *helper_for_current_device() {
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct PosteriorLayout {
-    int64_t kst_off[2], mup_off[2], xsc_off, pval_off, pidx_off, nan_off, ssp_off, total, nparts_cap;
+    int64_t kst_off[2], mup_off[2], xsc_off, prep_off, pval_off, pidx_off, nan_off, ssp_off, total, nparts_cap;
 };
 
 // number of column-split workgroups per candidate tile for a launch of nblk tiles (1 = the plain kernel)
@@ -514,6 +514,7 @@ PosteriorLayout posterior_layout(int64_t Np, int64_t chunk, int64_t M, int split
     }
     if (nbuf == 1) { L.kst_off[1] = L.kst_off[0]; L.mup_off[1] = L.mup_off[0]; }
     L.xsc_off = off; off += align_up((int64_t)sizeof(double) * Np * GPBO_MAX_D, 256);
+    L.prep_off = off; off += align_up(gpbo_kstar_mfma_prep_bytes(Np), 256);   // prefix-bound route (kstar_mfma.hip)
     L.pval_off = off; off += align_up((int64_t)sizeof(double) * L.nparts_cap, 256);
     L.pidx_off = off; off += align_up((int64_t)sizeof(int64_t) * L.nparts_cap, 256);
     L.nan_off = off; off += 256;
@@ -772,6 +773,15 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
         int rc0 = gpbo_scale_points_launch(X, N, Np, d, ls_host, Xsc, nan_count, stream);
         if (rc0 != GPBO_OK) return rc0;
     }
+    // prefix-bound route: K(X*,X) with the pair distances on the matrix cores and the mean reported from below by its error
+    // bound (kstar_mfma.hip; GPBO_PREFIX_VALU=1: the difference-form kernel instead, for A/B runs)
+    static const bool prefix_valu = getenv("GPBO_PREFIX_VALU") && atoi(getenv("GPBO_PREFIX_VALU"));
+    const bool kstar_mfma = n_prefix > 0 && !prefix_valu;
+    void *prep_buf = w + L.prep_off;
+    if (kstar_mfma) {
+        int rc0 = gpbo_kstar_mfma_prep(X, N, Np, d, ls_host, alpha, prep_buf, stream);
+        if (rc0 != GPBO_OK) return rc0;
+    }
 
     // Timing-only variants of the variance kernel (wrong results; tools/tile_stamps.py uses 6) exist only in a
     // diagnostics build (GPBO_DIAG=1 build.sh): the shipped library has no switch into them.
@@ -793,6 +803,8 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
         if (hipEventRecord(hp->fork, st) != hipSuccess || hipStreamWaitEvent(ks, hp->fork, 0) != hipSuccess)
             return GPBO_ERR_LAUNCH;
     }
+    // partials of the mean per candidate: 64-observation slices, coarser ones from the matrix-core K(X*,X) kernel
+    const int nsl = kstar_mfma ? (int)(Np / gpbo_kstar_mfma_slice(Np)) : (int)(Np / GPBO_KS_SLICE);
     bool prev_recorded = false;  // the previous chunk's variance launch has an end event in the slot before
     auto launch_kstar = [&](int64_t c) -> int {
         const int64_t s = c * chunk;
@@ -811,8 +823,10 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
         } else if (prof && prof->count < prof->capacity) {
             prof->kmode[prof->count] = 0;
         }
-        int rc = gpbo_kstar_mu_rows(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT[b], chunk,
-                                    mu_part[b], n_prefix ? n_prefix : Np, ks);
+        int rc = kstar_mfma ? gpbo_kstar_mu_mfma(Xs + s * d, Mc, N, Np, d, ls_host, alpha, prep_buf, KsT[b], chunk, mu_part[b],
+                                                 n_prefix, ks)
+                            : gpbo_kstar_mu_rows(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, diag_add, idx_offset + s,
+                                                 KsT[b], chunk, mu_part[b], n_prefix ? n_prefix : Np, ks);
         if (rc != GPBO_OK) return rc;
         if (hp && hipEventRecord(hp->kdone[b], ks) != hipSuccess) return GPBO_ERR_LAUNCH;
         return GPBO_OK;
@@ -844,28 +858,28 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
         if (xg_env > 1 && S == 1 && M >= 32768 && Np / BN >= 2 * xg_env && xg_env <= 16 && n_prefix == 0) {
             const int64_t grid1 = (nblk + 7) / 8 * 8 * xg_env;
             hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)grid1), dim3(NW * 64), 0, st, KsT[b], chunk, U, (int)Np,
-                               mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
+                               mu_part[b], nsl, Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                                (double *)nullptr, (double *)nullptr, (double *)nullptr, part_val + nparts,
                                part_idx + nparts, nan_count, (double *)nullptr, ss_part, xg_env, (int)nblk, 0);
             hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, xg_env, chunk, mu_part[b],
-                               (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
+                               nsl, Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                                mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
                                acq_out ? acq_out + s : nullptr, (double *)nullptr, part_val + nparts, part_idx + nparts,
                                nan_count, n_prefix ? GPBO_BOUND_VAR_PAD : 0.0);
         } else if (S > 1) {
             hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk, (unsigned)S), dim3(NW * 64), 0, st, KsT[b], chunk, U,
-                               (int)Np, mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1,
+                               (int)Np, mu_part[b], nsl, Mc, prior_var, (int)acq_kind, p0, p1,
                                idx_offset + s, (double *)nullptr, (double *)nullptr, (double *)nullptr, part_val + nparts,
                                part_idx + nparts, nan_count, (double *)nullptr, ss_part, 1, (int)nblk, (int)(n_prefix / BN));
             hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, S, chunk, mu_part[b],
-                               (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
+                               nsl, Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,
                                mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,
                                acq_out ? acq_out + s : nullptr, (double *)nullptr, part_val + nparts, part_idx + nparts,
                                nan_count, n_prefix ? GPBO_BOUND_VAR_PAD : 0.0);
         } else {
 #define GPBO_SIGMA_LAUNCH(V)                                                                                        \
     hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT[b], chunk, U, (int)Np,          \
-                       mu_part[b], (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,               \
+                       mu_part[b], nsl, Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,               \
                        mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                              \
                        acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count,                     \
                        (V == 6 && c == nchunks - 1 && nchunks > 1) ? KsT[(c + 1) & 1] : (double *)nullptr, (double *)nullptr, 1, \

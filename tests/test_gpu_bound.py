@@ -74,12 +74,14 @@ def test_bound_is_an_upper_bound_of_the_fp64_acquisition_for_every_candidate():
                                               wbytes, None, gp._stream())
         assert st == 0
         m, s, a = (t.cpu().numpy() for t in o)
-        assert np.array_equal(m, mu)
-        assert np.all(s >= sig) and np.all(a >= acq)   # (the bound's variance is clamped at 0 and padded by 1e-9)
+        # the first pass takes the pair distances from the matrix cores (kstar_mfma.hip) and reports the mean from BELOW by
+        # its error bound (~1e-9 here): never above the plain pass's mean, never far below
+        assert np.all(m <= mu) and np.max(mu - m) <= 1e-7
+        assert np.all(s >= sig) and np.all(a >= acq)   # (the bound's variance is clamped at 0 and padded by 1e-8)
         if prev is not None:
             assert np.all(s <= prev + 1e-13)   # more observations, tighter bound
         prev = s
-    assert np.max(np.abs(prev ** 2 - sig ** 2)) <= 2e-9   # the whole prefix is the plain pass, up to the pad
+    assert np.max(np.abs(prev ** 2 - sig ** 2)) <= 2e-8   # the whole prefix is the plain pass, up to the pad
     # argument checks: prefix not a multiple of 128, LCB with a negative weight (the bound would point the wrong way)
     bad = [dict(J=100, p0=4.0), dict(J=256, p0=-1.0), dict(J=gp.Np + 128, p0=4.0)]
     for b in bad:
