@@ -92,6 +92,36 @@ def test_bound_is_an_upper_bound_of_the_fp64_acquisition_for_every_candidate():
         assert st == -1   # GPBO_ERR_ARG
 
 
+@pytest.mark.parametrize("d", [1, 2, 6, 7, 14, 15, 16])
+def test_first_pass_kernel_for_every_operand_length(d):
+    """The first pass builds K(X*,X) from ONE inner product of length d + 2 per pair on the fp64 matrix cores
+    (csrc/kstar_mfma.hip: 1 .. 5 MFMAs of depth 4).  With the whole prefix the pass is the plain pass up to the expanded
+    form's error: the mean from below by at most its bound, sigma above by at most the variance pad."""
+    import torch
+
+    X, y, Xs, ls = make_problem(700, 5000, d)
+    Xs = Xs.copy()
+    Xs[17, 0] = np.nan
+    gp = DeviceGP(chunk=2048).factorise(X, y, ls)
+    full = gp.score(Xs, dense=True)
+    mu, sig = full.mu.cpu().numpy(), full.sigma.cpu().numpy()
+    Xd = gp._dev(Xs)
+    M = Xd.shape[0]
+    chunk, wbytes = gp._ensure_post_workspace(M)
+    o = [torch.empty(M, dtype=torch.float64, device=gp.device) for _ in range(3)]
+    st = gp.lib.gpbo_posterior_prefix_f64(gp._ptr(Xd), M, gp._ptr(gp.X), gp.N, gp.Np, gp.d, gp.ls_h.ctypes.data_as(C.c_void_p),
+                                          gp._ptr(gp.U), gp._ptr(gp.alpha), 1.000101, _lib.ACQ_LCB, 4.0, 0.0, 0, chunk, gp.Np,
+                                          gp._ptr(o[0]), gp._ptr(o[1]), gp._ptr(o[2]), gp._ptr(gp._result), gp._ptr(gp._work_post),
+                                          wbytes, None, gp._stream())
+    assert st == 0
+    m, s = o[0].cpu().numpy(), o[1].cpu().numpy()
+    ok = np.ones(M, bool)
+    ok[17] = False
+    assert np.isnan(m[17]) and np.isnan(mu[17])
+    assert np.all(m[ok] <= mu[ok]) and np.max(mu[ok] - m[ok]) <= 1e-7 * max(1.0, np.abs(y).max())
+    assert np.all(s[ok] >= sig[ok]) and np.max(s[ok] ** 2 - sig[ok] ** 2) <= 2e-8
+
+
 def test_ties_nan_and_chunk_invariance():
     X, y, Xs, ls = make_problem(600, 20000, 6)
     gp = DeviceGP(chunk=4096).factorise(X, y, ls)
