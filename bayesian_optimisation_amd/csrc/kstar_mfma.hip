@@ -7,10 +7,15 @@
 //     t_ci = (b_i1 .. b_id, 1, |b_i|^2) . (-2 a_c1 .. -2 a_cd, |a_c|^2, 1),
 // i.e. ceil((d + 2) / 4) v_mfma_f64_16x16x4_f64 per 16 x 16 block of pairs instead of 2 d fp64 VALU instructions per pair;
 // what stays on the VALU is exp(-t) and the mean's multiply-add (25 of the 36 instructions of kstar_mu_kernel).
-// Measured (MI355X, N = 4096, 2^21 candidates, whole bound route, same box): 14.8-15.0 ms against 15.7 ms with the
-// difference-form kernel, i.e. 0.56 against 0.61 ms per 2^17 x 4096 entries - less than the instruction count promises:
-// the four exp chains of a tile are issued one after the other, and neither operands from LDS instead of L2, nor
-// branch-free stores, nor three-address FMAs spelled in asm moved it (14.7-15.0 ms all).
+// Measured (MI355X, N = 4096, rocprofv3 kernel trace): 0.57-0.61 ms per 2^17 x 4096 entries - the SAME as the difference-form
+// kernel without its stores (0.61 ms).  Why: v_mfma_f64_16x16x4_f64 occupies a SIMD for 64 cycles (1,024 multiply-adds at
+// the 16 per cycle that make 78.6 TFLOP/s), fp64 MFMA and fp64 VALU do not execute side by side on gfx950 (DESIGN 4, round 1:
+// K(X*,X) overlapped with the variance kernel gained nothing), so the three MFMAs of a 16 x 16 tile cost 0.75 cycles per
+// pair and SIMD against 1.0 for the sixteen VALU instructions they replace: 2.3 cycles per pair instead of 2.25 + 0.0 - a
+// wash, whatever the issue order (operands from LDS instead of L2, branch-free stores, three-address FMAs in asm, the four
+// exp chains of a tile in lock step: 14.7-15.0 ms per 2^21 candidates for the whole route, all of them).  What the route
+// did gain with this kernel (15.7 -> 14.9 ms) comes from its coarser partials of the mean: 16 instead of 64 per candidate
+// for the first-pass variance launches to add up (0.21 -> 0.18 ms each).
 //
 // Accuracy - why this is NOT the fp64 path's kernel.  The difference form's error in t is relative (t 1e-16); the expanded
 // form's is ABSOLUTE: every one of the d + 2 fused steps rounds at the size of the partial sum, <= 2 (|a|^2 + |b|^2), so
