@@ -29,7 +29,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
         k = k.split("(")[0].split("<")[0]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-keep = ("sigma_acq_kernel", "kstar_mu_kernel", "sigma_acq_f32_kernel", "sigma_i8_kernel", "sigma_i8c_kernel", "kstar_slices_kernel",
+keep = ("sigma_acq_kernel", "kstar_mu_kernel", "sigma_acq_f32_kernel", "sigma_i8_kernel", "sigma_i8c_kernel", "kstar_slices_kernel", "kstar_mu_mfma_kernel", "bound_select_kernel",
         "split_finish_kernel", "u_slices_kernel", "u_colscale_kernel", "potrf_diag_kernel", "gemm_f64_kernel", "kxx_kernel", "utv_kernel",
         "uv_kernel")
 with open(os.path.join(here, f"{out}_pmc_summary.csv"), "w") as fo:
