@@ -315,7 +315,8 @@ def main():
             kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(gbs / HBM_PEAK_GBS, 4),
                                   kernel={"f32": "kstar_mu_kernel<..., float>", "i8": "kstar_slices_kernel<..., 5>",
-                                          "i8c": "kstar_slices_kernel<..., 3>"}.get(args.dtype, "kstar_mu_kernel"),
+                                          "i8c": "kstar_slices_kernel<..., 3>",
+                                          "f64b": "kstar_mu_mfma_kernel"}.get(args.dtype, "kstar_mu_kernel"),
                                   launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
                                   bytes_per_candidate=bytes_per_cand)
 
