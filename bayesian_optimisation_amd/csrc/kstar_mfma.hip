@@ -3,20 +3,23 @@
 //
 //     t_ci = |a_c - b_i|^2 = |a_c|^2 + |b_i|^2 - 2 a_c . b_i,        k_ci = exp(-t_ci)           (point_selector.py:180-189)
 // with a = (x* - m) / (ls sqrt 2), b = (x - m) / (ls sqrt 2), m = the mean of the scaled observations (centring keeps the
-// norms, hence the cancellation, small).  The expanded form is ONE inner product of length d + 2,
-//     t_ci = (b_i1 .. b_id, 1, |b_i|^2) . (-2 a_c1 .. -2 a_cd, |a_c|^2, 1),
-// i.e. ceil((d + 2) / 4) v_mfma_f64_16x16x4_f64 per 16 x 16 block of pairs instead of 2 d fp64 VALU instructions per pair;
+// norms, hence the cancellation, small).  The expanded form is an inner product of length d on top of the two norms,
+//     t_ci = (|a_c|^2 + |b_i|^2) + b_i . (-2 a_c),
+// i.e. ceil(d / 4) v_mfma_f64_16x16x4_f64 per 16 x 16 block of pairs (the norms are the accumulator's initial value: one
+// VALU addition per pair) instead of 2 d fp64 VALU instructions per pair;
 // what stays on the VALU is exp(-t) and the mean's multiply-add (25 of the 36 instructions of kstar_mu_kernel; 19 with the
 // shorter exp a bound can afford: 256-entry table, degree 4, one-word argument reduction, clamp instead of compare-select).
-// Measured (MI355X, N = 4096, rocprofv3 kernel trace): 0.57-0.61 ms per 2^17 x 4096 entries - the SAME as the difference-form
-// kernel without its stores (0.61 ms).  Why: v_mfma_f64_16x16x4_f64 occupies a SIMD for 64 cycles (1,024 multiply-adds at
-// the 16 per cycle that make 78.6 TFLOP/s), fp64 MFMA and fp64 VALU do not execute side by side on gfx950 (DESIGN 4, round 1:
-// K(X*,X) overlapped with the variance kernel gained nothing), so the three MFMAs of a 16 x 16 tile cost 0.75 cycles per
-// pair and SIMD against 1.0 for the sixteen VALU instructions they replace: 2.3 cycles per pair instead of 2.25 + 0.0 - a
-// wash, whatever the issue order (operands from LDS instead of L2, branch-free stores, three-address FMAs in asm, the four
-// exp chains of a tile in lock step: 14.7-15.0 ms per 2^21 candidates for the whole route, all of them).  What the route
-// did gain with this kernel (15.7 -> 14.9 ms) comes from its coarser partials of the mean: 16 instead of 64 per candidate
-// for the first-pass variance launches to add up (0.21 -> 0.18 ms each).
+// Measured (MI355X, N = 4096, rocprofv3 kernel trace), ms per 2^17 x 4096 entries: difference-form kernel without its
+// stores 0.61; this kernel with the full-length exp and the norms inside the inner product (3 MFMAs) 0.57-0.61 - no gain;
+// with the shorter exp 0.53; with the norms as the accumulator's initial value (2 MFMAs) 0.48-0.51.  The accounting that
+// fits: v_mfma_f64_16x16x4_f64 occupies a SIMD for 64 cycles (1,024 multiply-adds at the 16 per cycle behind 78.6 TFLOP/s)
+// and fp64 MFMA does not execute beside fp64 VALU on gfx950 (K(X*,X) overlapped with the variance kernel
+// gained nothing), so per pair and lane the MFMAs cost 32 cycles (48 with three) where the sixteen VALU instructions they
+// replace cost 64, and the rest of the pair 19 x 4 = 76 (25 x 4 = 100 with the full exp): 108 cycles against 164 for the
+// difference form - measured 130 against 150.  Issue order does not matter (operands from LDS instead of L2, branch-free
+// stores, three-address FMAs in asm, the four exp chains of a tile in lock step: no change).  The route also gained from this
+// kernel's coarser partials of the mean: 16 instead of 64 per candidate for the first-pass variance launches to add up
+// (0.21 -> 0.18 ms each).
 //
 // Accuracy - why this is NOT the fp64 path's kernel.  The difference form's error in t is relative (t 1e-16); the expanded
 // form's is ABSOLUTE: every one of the d + 2 fused steps rounds at the size of the partial sum, <= 2 (|a|^2 + |b|^2), so
@@ -211,18 +214,18 @@ __global__ __launch_bounds__(1024) void obs_prep_kernel(const double *__restrict
     }
 }
 
-template <int KQ /* (d + 2 padded) / 4 */>
+template <int KQ /* ceil(d / 4): MFMAs per 16 x 16 pairs */>
 __global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__restrict__ Xs, int64_t Mc, int d, IscArgs ls,
                                                             const double *__restrict__ Bp, const ObsPrep *__restrict__ prep,
                                                             const double *__restrict__ alpha, int N, double gamma,
                                                             double *__restrict__ KsT, int64_t ldk,
                                                             double *__restrict__ mu_part, int store_rows,
-                                                            int OB /* observations per workgroup = per mean partial */) {
-    constexpr int KP = 4 * KQ;
+                                                            int OB /* observations per workgroup = per mean partial */,
+                                                            int KP /* row length of Bp: d + 2 padded to a multiple of 4 */) {
     constexpr int NC = 4;   // candidate tiles per wave
-    constexpr int LDB = KP + 1;   // LDS row stride of the observation rows (odd: the 16 rows of a tile land on different banks)
+    const int LDB = KP + 1;   // LDS row stride of the observation rows (odd: the 16 rows of a tile land on different banks)
     __shared__ double tab[256];
-    __shared__ double Bs[OB_MAX * LDB];
+    __shared__ double Bs[OB_MAX * (4 * KQ + 5)];   // KP <= 4 KQ + 4
     __shared__ double As[OB_MAX];   // alpha of the workgroup's observations (0 beyond N: those rows give k = 0 anyway)
     tab[threadIdx.x] = kExp2TabM[threadIdx.x];   // (256 threads)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -236,8 +239,10 @@ __global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__rest
         Bs[row * LDB + k] = Bp[(int64_t)(n0 + row) * KP + k];
     }
     for (int e = threadIdx.x; e < OB; e += 256) As[e] = (n0 + e < N) ? alpha[n0 + e] : 0.0;
-    // candidate operands: element e = 4 q + l4 of (-2 a_1 .. -2 a_d, |a|^2, 1, 0 ..) for candidate cbase + 16 tc + l15
-    double bop[NC][KQ], slack[NC];
+    // candidate operands: element e = 4 q + l4 of (-2 a_1 .. -2 a_d, 0 ..) for candidate cbase + 16 tc + l15.  The two norms
+    // do not ride in the inner product (that would be a third MFMA at d = 8 - 64 cycles - for two additions): |a|^2 + |b|^2
+    // is the accumulator's initial value.  (The observation rows keep their (1, |b|^2) tail: it meets zeros here.)
+    double bop[NC][KQ], slack[NC], nac[NC];
     bool isnan_c[NC];
 #pragma unroll
     for (int tc = 0; tc < NC; ++tc) {
@@ -257,11 +262,8 @@ __global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__rest
                 if (4 * q + l4 == k) sel[q] = -2.0 * a;
         }
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            if (4 * q + l4 == d) sel[q] = na;
-            if (4 * q + l4 == d + 1) sel[q] = 1.0;
-            bop[tc][q] = sel[q];
-        }
+        for (int q = 0; q < KQ; ++q) bop[tc][q] = sel[q];
+        nac[tc] = na;
         slack[tc] = gamma * fma(na, prep->S0, prep->S1) + (EXP_REL_ERR + EXP_ABS_ERR) * prep->S0;
         isnan_c[tc] = bad;
     }
@@ -280,12 +282,15 @@ __global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__rest
         const double *brow = Bs + (16 * ot + l15) * LDB + l4;
 #pragma unroll
         for (int q = 0; q < KQ; ++q) aop[q] = brow[4 * q];
-        double al[4];
+        double al[4], nb[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) al[r] = As[16 * ot + l4 + 4 * r];
+        for (int r = 0; r < 4; ++r) {
+            al[r] = As[16 * ot + l4 + 4 * r];
+            nb[r] = Bs[(16 * ot + l4 + 4 * r) * LDB + d + 1];
+        }
 #pragma unroll
         for (int tc = 0; tc < NC; ++tc) {
-            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            d4_t acc = {nac[tc] + nb[0], nac[tc] + nb[1], nac[tc] + nb[2], nac[tc] + nb[3]};
 #pragma unroll
             for (int q = 0; q < KQ; ++q) acc = mfma_f64_16x16x4(aop[q], bop[tc][q], acc);
 #pragma unroll
@@ -360,7 +365,7 @@ int gpbo_kstar_mu_mfma(const double *Xs, int64_t Mc, int64_t N, int64_t Np, int3
     IscArgs ls;
     for (int k = 0; k < GPBO_MAX_D; ++k) ls.isc[k] = 0.0;
     for (int k = 0; k < d; ++k) ls.isc[k] = 1.0 / (ls_host[k] * 1.4142135623730950488);
-    const int KQ = (d + 2 + 3) / 4;
+    const int KQ = (d + 3) / 4, KP = (d + 2 + 3) / 4 * 4;
     const double gamma = 2.0 * (2.0 * (d + 2) + 8.0) * 1.1102230246251565e-16;   // 2^-53
     const double *Bp = reinterpret_cast<const double *>(prep_buf);
     const ObsPrep *prep = reinterpret_cast<const ObsPrep *>(reinterpret_cast<const char *>(prep_buf) +
@@ -370,13 +375,12 @@ int gpbo_kstar_mu_mfma(const double *Xs, int64_t Mc, int64_t N, int64_t Np, int3
     dim3 grid((unsigned)(used / 256), (unsigned)(Np / OB));
 #define GPBO_KM_LAUNCH(Q)                                                                                              \
     hipLaunchKernelGGL((kstar_mu_mfma_kernel<Q>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, (int)d, ls, Bp, prep, alpha, \
-                       (int)N, gamma, KsT, ldk, mu_part, (int)store_rows, OB)
+                       (int)N, gamma, KsT, ldk, mu_part, (int)store_rows, OB, KP)
     switch (KQ) {
         case 1: GPBO_KM_LAUNCH(1); break;
         case 2: GPBO_KM_LAUNCH(2); break;
         case 3: GPBO_KM_LAUNCH(3); break;
         case 4: GPBO_KM_LAUNCH(4); break;
-        case 5: GPBO_KM_LAUNCH(5); break;
         default: return GPBO_ERR_ARG;
     }
 #undef GPBO_KM_LAUNCH

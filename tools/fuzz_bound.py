@@ -1,7 +1,10 @@
 """Randomised sweep of the exact prefix bound (DeviceGP.score_bound) against the plain fp64 pass: random sizes, feature
 counts, length scales, objectives (rough / nearly flat), observation orders (random / sorted along an axis / clustered),
 acquisitions (LCB weights 0 .. 30, EI), prefix lengths, duplicated and NaN candidates.  The bar: the same index, the same
-NaN count, the value within 1e-12 relative.  usage: python tools/fuzz_bound.py [seconds] [seed]"""
+NaN count, the value within 1e-9 relative (both values are fp64 kernels' - the fused launch of the plain pass and the
+column-split launch that re-scores the survivors add |v|^2 up in different orders, and sigma^2 = c - |v|^2 cancels: with
+sigma ~ 1e-2 and a weight of 30 the two differ by 4e-12 relative in one of 4,246 cases; 1e-12 holds for weights <= 4).
+usage: python tools/fuzz_bound.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -53,7 +56,7 @@ while time.time() < t_end:
         n_fallback += bool(st.get("fallback"))
         n_pruned += (not st.get("fallback")) and st.get("rescored", M) < M // 4
         if r.best_idx != r64.best_idx or r.nan_count != r64.nan_count or \
-                abs(r.best_val - r64.best_val) > 1e-12 * max(1.0, abs(r64.best_val)):
+                abs(r.best_val - r64.best_val) > 1e-9 * max(1.0, abs(r64.best_val)):
             n_fail += 1
             print("FAIL", tag, (r.best_idx, r.best_val, r.nan_count), (r64.best_idx, r64.best_val, r64.nan_count), st, flush=True)
     except Exception as exc:  # noqa: BLE001
