@@ -400,6 +400,22 @@ def main():
                      "candidate whose bound reaches the best exact value seen; pruned candidates provably cannot be the "
                      "maximum nor tie with it; "
                      "--dtype f64b times it as the main workload")
+            if args.acq == "lcb":   # the north star counts EI evaluations: the same route with Expected Improvement
+                kwe = dict(idx_offset=lo, acquisition="ei", f_best=f_best, xi=0.0)
+                gp.factorise(Xd, yd, ls, check=False)
+                gp.score_async(Xsd, **kwe)
+                v64, i64, n64, info = D.allreduce_status(gp.status)
+                gp.score_async_bound(Xsd, **kwe)
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                for _ in range(reps2):
+                    gp.factorise(Xd, yd, ls, check=False)
+                    gp.score_async_bound(Xsd, **kwe)
+                    v, i, n, info = D.allreduce_status(gp.status)
+                ms = (time.perf_counter() - t) / reps2 * 1e3
+                res["prefix_bound_screen_ei_same_workload"] = dict(
+                    value=(hi - lo) / (ms * 1e-3), unit="EI evaluations/s", ms_per_step=ms, argmax_index=i,
+                    argmax_matches_fp64=bool(i == i64), steps=reps2, screen=gp.last_screen)
         g1 = os.path.join(REPO, "tests", "golden", "g1_m32.npz")
         if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb") and os.path.exists(g1):
             # BASELINE configs[0] (d=2, N=32, M=32x32 grid, 50x50 ARD search - the sizes the reference's DAG runs): the

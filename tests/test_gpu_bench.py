@@ -48,6 +48,8 @@ def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
     pb = line["also"]["prefix_bound_screen_same_workload"]
     assert pb["argmax_matches_fp64"] is True and not pb["screen"]["fallback"] and pb["value"] > 5.0 * line["value"]
     assert pb["screen"]["mode"] == "bound" and pb["screen"]["rescored"] < (1 << 21) // 16
+    pe = line["also"]["prefix_bound_screen_ei_same_workload"]
+    assert pe["argmax_matches_fp64"] is True and not pe["screen"]["fallback"] and pe["value"] > 5.0 * line["value"]
 
 
 @pytest.mark.gpu
