@@ -214,6 +214,8 @@ __global__ __launch_bounds__(1024) void obs_prep_kernel(const double *__restrict
     }
 }
 
+// (MFMA results straight into VGPRs - `-mllvm -amdgpu-mfma-vgpr-form=1`, no v_accvgpr_read per value - was measured too:
+//  13.2-13.4 against 13.3-13.5 ms per 2^21 candidates for the whole route, at 128-130 registers instead of 94: not used.)
 template <int KQ /* ceil(d / 4): MFMAs per 16 x 16 pairs */>
 __global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__restrict__ Xs, int64_t Mc, int d, IscArgs ls,
                                                             const double *__restrict__ Bp, const ObsPrep *__restrict__ prep,
