@@ -18,7 +18,7 @@ for N, M, d, chunk in [(256, 2048, 8, 1024), (700, 5000, 8, 2048), (2048, 40000,
         print(N, M, d, kw.get("acquisition"), kw.get("explore", ""), "idx", r.best_idx == r64.best_idx,
               "dval %.2g" % abs(r.best_val - r64.best_val), "nan", r.nan_count == r64.nan_count, scr, flush=True)
 
-if len(sys.argv) > 1 and sys.argv[1] != 'timeonly' or len(sys.argv) > 1:
+if len(sys.argv) > 1:
     N, M, d = 4096, 1 << 21, 8
     X, y, Xs, ls = make_problem(N, M, d)
     gp = DeviceGP().factorise(X, y, ls)
