@@ -16,7 +16,8 @@ Differences from the reference, all deliberate:
     definite, IndexError when the acquisition contains NaN (the reference's own failure at :207).
   * Extra, not in the reference: `precision="fp32"` / `"i8"` (fp64 factorisation and means; the N^2 variance product
     as an fp32 or int8-sliced SCREEN; the selected point is still decided by the fp64 kernels), `expected_improvement(xi)`,
-    `q_expected_improvement()`, `kernel_params` may be preset (then no
+    `q_expected_improvement()`, `dense_outputs=False` (next point only: the dense attributes stay None and the acquisition
+    calls go through the exact prefix bound), `kernel_params` may be preset (then no
     ARD search runs), optional multi-GPU candidate sharding when torch.distributed is initialised,
     `incremental=True` / `state_path=...` (append new observations to the previous factorisation in O(N^2)
     while the length scales stay the same, within one process or across jobs through a state file).
@@ -48,7 +49,7 @@ def _plot_hooks():
 
 class PointSelector:
     def __init__(self, device=None, verbose: bool = False, shard_candidates: bool = True, precision: str = "fp64",
-                 incremental: bool = False, state_path=None):
+                 incremental: bool = False, state_path=None, dense_outputs: bool = True):
         # attribute protocol of point_selector.py:15-40
         self.feature_domain = None
         self.predicted_pts = None
@@ -75,6 +76,10 @@ class PointSelector:
             raise ValueError("precision must be 'fp64' (reference arithmetic), 'fp32', 'i8' or 'i8c' (fp64 factorisation, "
                              "means and decision; variance product screened in fp32 / in int8 slices / in three int8 digits)")
         self._precision = precision
+        # dense_outputs=False (not in the reference): a caller that needs the next point only.  mean_func / cov_func /
+        # acq_func_eval stay None and the acquisition calls return the same multi-index through the exact prefix bound
+        # (DeviceGP.score_bound: fp64 branch and bound, the full pass when the bound does not separate the candidates).
+        self._dense = bool(dense_outputs)
         self._gp = None
         self._mu_dev = self._sigma_dev = None
         self._cached = None  # (kind, p0, p1) -> (acq ndarray, flat index)
@@ -155,6 +160,17 @@ class PointSelector:
         diag_add = JITTER_KERNEL if Xs.shape == X.shape else 0.0          # :173 shape-coincidence quirk
         world, rank = self._world()
         lo, hi = D.shard_bounds(M, world, rank)
+        if not self._dense:
+            self.mean_func = self.cov_func = self.acq_func_eval = None
+            self._mu_dev = self._sigma_dev = None
+            self._cached = {}
+            self._lo_hi = (lo, hi)
+            self._select_only = (gp._dev(Xs[lo:hi]), diag_add)
+            self._cov = {"cov_pred": None, "cov_meas": None, "cov_meas_pred": None}
+            self._lazy = {"cov_meas": gp.cov_meas_host}
+            self.measured_pts = self.measured_pts.tolist()
+            self.measured_vals = self.measured_vals.tolist()
+            return
         if self._precision in ("fp32", "i8", "i8c"):   # screened variance product (fp32: BASELINE config 4's mode), fp64 decision
             score = {"fp32": gp.score_f32, "i8": gp.score_i8, "i8c": gp.score_i8c}[self._precision]
             res = score(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
@@ -322,7 +338,12 @@ class PointSelector:
     # ------------------------------------------------------------------------------------------
     def _finish(self, key, kind, **kw):
         fd = [int(v) for v in self.feature_domain]
-        if key not in self._cached:
+        if not self._dense:
+            if key not in self._cached:
+                Xd, diag_add = self._select_only
+                res = self._gp.score_bound(Xd, acquisition=kind, idx_offset=self._lo_hi[0], diag_add=diag_add, **kw)
+                self._cached[key] = (None, D.allreduce_argmax(res.best_val, res.best_idx, res.nan_count))
+        elif key not in self._cached:
             lo, hi = self._lo_hi
             res = self._gp.acquisition_on_posterior(self._mu_dev, self._sigma_dev, acquisition=kind,
                                                     idx_offset=lo, **kw)

@@ -180,3 +180,31 @@ def test_bound_screen_selects_the_reference_point(golden, name):
     if g["top2_gap"] > 1e-7 * max(1.0, np.abs(y).max()):
         assert r.best_idx == _first_argmax(g["acq_func_eval"])
     assert abs(r.best_val - g["acq_func_eval"].max()) <= 1e-8 * max(1.0, np.abs(y).max())
+
+
+def test_drop_in_class_without_dense_outputs_returns_the_same_multi_index():
+    """PointSelector(dense_outputs=False): a caller that needs the next point only - the acquisition calls return the multi-index
+    the full class returns, mean_func / cov_func / acq_func_eval stay None."""
+    from bayesian_optimisation_amd import PointSelector
+
+    rng = np.random.default_rng(3)
+    N, d, g = 900, 3, 48
+    X = rng.uniform(0, 1, (N, d))
+    y = np.sin(6 * X[:, 0]) * np.cos(4 * X[:, 1]) + X[:, 2] ** 2 + 0.01 * rng.standard_normal(N)
+    axes = [np.linspace(0, 1, g)] * d
+    Xs = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, d)
+    out = []
+    for dense in (True, False):
+        ps = PointSelector(dense_outputs=dense)
+        ps.name, ps.iteration = "T", 0
+        ps.measured_pts, ps.measured_vals = X, y
+        ps.feature_domain, ps.predicted_pts = [g] * d, Xs
+        ps.set_kernel_params(np.array([0.15, 0.2, 0.4]))
+        ps.update_surrogate()
+        out.append((ps.lower_confidence_bound(), ps.lower_confidence_bound(explore=1.0), ps.expected_improvement(), ps))
+    full, only = out
+    for a, b in zip(full[:3], only[:3]):
+        assert np.array_equal(a, b) and a.dtype == np.int64 and a.shape == (d,)
+    assert only[3].mean_func is None and only[3].cov_func is None and only[3].acq_func_eval is None
+    assert full[3].mean_func.shape == (g, g, g)
+    assert only[3]._gp.last_screen["mode"] == "bound"
