@@ -265,6 +265,9 @@ __global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__rest
         }
 #pragma unroll
         for (int q = 0; q < KQ; ++q) bop[tc][q] = sel[q];
+        // an infinite (or overflowing) coordinate makes the expanded form inf - inf; the difference form handles it (k = 0):
+        // such a candidate is reported like a NaN one here - its bound is NaN, so it always survives to the fp64 kernels
+        bad = bad || !(na < __builtin_inf());
         nac[tc] = na;
         slack[tc] = gamma * fma(na, prep->S0, prep->S1) + (EXP_REL_ERR + EXP_ABS_ERR) * prep->S0;
         isnan_c[tc] = bad;

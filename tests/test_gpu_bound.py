@@ -138,6 +138,15 @@ def test_ties_nan_and_chunk_invariance():
     Xn[15000, 2] = np.nan
     r, r64 = gp.score_bound(Xn), gp.score(Xn)
     assert r.nan_count == r64.nan_count == 2 and r.best_idx == r64.best_idx
+    # infinite candidate coordinates: the plain pass gives k = 0 (mean 0, prior sigma) - a legitimate, possibly winning, value
+    Xi = Xs.copy()
+    Xi[11, 1] = np.inf
+    Xi[4000, 0] = -np.inf
+    Xi[9000, 3] = 1e200
+    r, r64 = gp.score_bound(Xi), gp.score(Xi)
+    assert r.best_idx == r64.best_idx and r.nan_count == r64.nan_count
+    r, r64 = gp.score_bound(Xi, explore=500.0), gp.score(Xi, explore=500.0)   # now the far-away candidates win (sigma = prior)
+    assert r.best_idx == r64.best_idx and r.nan_count == r64.nan_count
     # chunking and the prefix length change the work, never the answer
     ref = gp.score(Xs)
     for chunk, prefix in ((1024, None), (8192, 128), (4096, 256)):
