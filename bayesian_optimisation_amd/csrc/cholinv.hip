@@ -1,0 +1,511 @@
+// Fused Cholesky + inverse factor of cov_meas on the gfx950 fp64 matrix cores.
+//
+// The reference inverts cov_meas with np.linalg.inv (/root/reference/point_selector.py:89) and uses the inverse in the
+// posterior mean and covariance (:90-91).  The variance kernel (sigma_acq.hip) wants U = L^-T.  Round 2 built it in two
+// passes (blocked Cholesky, then a block-recursive triangular inverse whose last level cannot start before the
+// Cholesky has ended) out of ~200 dependent launches per factorisation.  This file replaces both passes by ONE sweep of
+// row operations over the stacked matrix S = [A | W] (cholinv_plan.h): on exit W = L^-1 = U^T.
+//
+// One kernel, three kinds of workgroup (512 threads), mixed inside a launch (cholinv_plan.h decides):
+//   PANEL      64 x 64 diagonal block: Cholesky AND the inverse of its factor in one elimination (registers + LDS +
+//              MFMA), computed redundantly by every workgroup of the block row, then row <- inv(L_jj) * row for the
+//              workgroup's own 64 x 128 tile on the matrix cores.  The critical path of the factorisation.
+//   UPD_SMALL  64 x 64 tile of out -= A^T B, K <= 256: MFMA fragments straight from global memory (k-major operands:
+//              16 lanes read 128 contiguous bytes), no LDS, no barrier - the lowest latency for the updates that sit on
+//              the critical path (the group's own rows, the next group's rows).
+//   UPD_BIG    128 x 128 tile, 16-deep k tiles through a three-stage LDS ring filled by global_load_lds (the loop of
+//              sigma_acq_kernel): the bulk of the flops, run as filler workgroups beside the panels.
+// Dependencies are launch order on one stream; inside a launch no workgroup reads what another one writes
+// (tests/test_cholinv_plan_cpu.py checks that on the plan itself).
+#include "gpbo_internal.h"
+
+#include "cholinv_plan.h"
+
+namespace {
+
+constexpr int NB = 64;
+constexpr int PB = 16;               // inner block of the diagonal elimination
+constexpr int LDM = NB + 2;          // row stride of the elimination matrix in LDS (doubles)
+constexpr int LDT = 128 + 16;        // row stride of a 128-wide k-major operand tile in LDS: lanes l and l+16 of a
+                                     // ds_read_b64 group (k and k+1) land in disjoint banks
+constexpr int BKT = 16;              // k depth of a stage
+constexpr int STAGE_D = 2 * BKT * LDT;                 // doubles per stage: A tile + B tile
+constexpr int PANEL_D = 2 * NB * LDM + NB * LDT;       // elimination matrix [128][LDM] + the row tile [64][LDT]
+constexpr int SMEM_D = (3 * STAGE_D > PANEL_D) ? 3 * STAGE_D : PANEL_D;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+__device__ __forceinline__ void glds16(const double *g, double *l) {
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double rsqrt_refined(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+    double e = fma(-(h * y), y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-(h * y), y, 0.5);
+    return fma(y, e, y);
+}
+
+struct CiArgs {
+    double *S;
+    int64_t ld;
+    int32_t Np;
+    int32_t *info;
+    CiLaunch l;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// UPD_BIG: out[128 x 128] -= sum_k S[k][row0 + m] * S[k][col0 + n], k in [k0, k0 + K)
+// 8 waves as 4 (rows) x 2 (columns): wave tile 32 x 64 = 2 x 4 MFMA tiles; the two waves of a SIMD (w, w + 4) take the
+// even / odd 16-column tiles.  Per 16-deep k tile: 32 KiB by LDS-DMA (each wave two rows of either operand, 1 KiB per
+// instruction), 32 MFMAs per wave; one barrier in the middle of the tile (see sigma_acq_kernel for why there).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int Np, const CiJob &u, int t,
+                                        double *smem) {
+    int row0, col0;
+    ci_big_decode(Np, u.r0, u.wlim, u.t0 + t, &row0, &col0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid & 3, wq = wid >> 2;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    const double *pa = S + (int64_t)u.k0 * ld + row0;
+    const double *pb = S + (int64_t)u.k0 * ld + col0;
+    unsigned voff[2];
+    int lds_off[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        voff[r] = (unsigned)((wid + 8 * r) * (unsigned)ld + lane * 2);
+        lds_off[r] = (wid + 8 * r) * LDT;
+    }
+    const int nk = u.K / BKT;
+    int pk = 0, pbuf = 0;
+    auto stage_next = [&]() {
+        double *St = smem + pbuf * STAGE_D;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) glds16(pa + voff[r], St + lds_off[r]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) glds16(pb + voff[r], St + BKT * LDT + lds_off[r]);
+        pbuf = (pbuf == 2) ? 0 : pbuf + 1;
+        ++pk;
+        pa += (int64_t)BKT * ld;
+        pb += (int64_t)BKT * ld;
+    };
+
+    d4_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    stage_next();
+    if (pk < nk) stage_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    double a0[2], b0[4], a1[2], b1[4];
+    auto lds_frag = [&](double (&af)[2], double (&bf)[4], int buf, int kk) {
+        const double *As = smem + buf * STAGE_D;
+        const double *Bs = As + BKT * LDT;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[mi] = As[(kk + l4) * LDT + wr * 32 + mi * 16 + l15];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[(kk + l4) * LDT + (2 * ni + wq) * 16 + l15];
+    };
+    auto mfma8 = [&](const double (&af)[2], const double (&bf)[4]) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf[ni], acc[mi][ni]);
+    };
+    lds_frag(a0, b0, 0, 0);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nxt = (cur == 2) ? 0 : cur + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a0, b0);
+        lds_frag(a1, b1, cur, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a1, b1);
+        lds_frag(a0, b0, cur, 8);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own share of tile kt+1 has landed
+        __builtin_amdgcn_s_barrier();                      // ... everybody's has; everybody has left tile kt-1
+        if (pk < nk) stage_next();                         // tile kt+2 into the stage tile kt-1 occupied
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a0, b0);
+        lds_frag(a1, b1, cur, 12);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a1, b1);
+        lds_frag(a0, b0, nxt, 0);  // first step of the next tile (stale but in-bounds after the last one)
+        cur = nxt;
+    }
+
+    // out = C - acc on the live part of the tile (masks are uniform per 16 x 16 MFMA tile: boundaries are 64-granular)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int rbase = row0 + wr * 32 + mi * 16;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int cbase = col0 + (2 * ni + wq) * 16;
+            const bool live = rbase < u.r1 && (cbase < Np ? cbase >= (rbase & ~63) : cbase < Np + u.wlim);
+            if (live) {
+                double *cp = S + (int64_t)(rbase + l4) * ld + cbase + l15;
+                double c[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[r] = cp[(int64_t)(4 * r) * ld];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cp[(int64_t)(4 * r) * ld] = c[r] - acc[mi][ni][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// UPD_SMALL: out[64 x 64] -= sum_k S[k][row0 + m] * S[k][col0 + n].  8 waves as 4 (rows) x 2 (columns): wave tile
+// 16 x 32.  Fragments come straight from global memory, 32 k at a time (24 loads in flight per lane), the next 32 k
+// are in flight while the current ones are multiplied.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, int Np, const CiJob &u, int t) {
+    int row0, col0;
+    ci_small_decode(Np, u.r0, u.wlim, u.t0 + t, &row0, &col0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = wid & 3, wcol = wid >> 2;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const double *ap = S + (int64_t)(u.k0 + l4) * ld + row0 + wrow * 16 + l15;
+    const double *bp = S + (int64_t)(u.k0 + l4) * ld + col0 + wcol * 32 + l15;
+    double *cp = S + (int64_t)(row0 + wrow * 16 + l4) * ld + col0 + wcol * 32 + l15;
+    d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+    double c0[4], c1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        c0[r] = cp[(int64_t)(4 * r) * ld];
+        c1[r] = cp[(int64_t)(4 * r) * ld + 16];
+    }
+    constexpr int CH = 8;  // k steps (of 4) per chunk
+    double fa[2][CH], fb0[2][CH], fb1[2][CH];
+    auto load = [&](int set, int kbase) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int64_t o = (int64_t)(kbase + 4 * s) * ld;
+            fa[set][s] = ap[o];
+            fb0[set][s] = bp[o];
+            fb1[set][s] = bp[o + 16];
+        }
+    };
+    auto mult = [&](int set) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            acc0 = mfma_f64_16x16x4(fa[set][s], fb0[set][s], acc0);
+            acc1 = mfma_f64_16x16x4(fa[set][s], fb1[set][s], acc1);
+        }
+    };
+    const int nch = u.K / (4 * CH);
+    load(0, 0);
+    for (int c = 0; c < nch; c += 2) {
+        if (c + 1 < nch) load(1, (c + 1) * 4 * CH);
+        mult(0);
+        if (c + 1 < nch) {
+            if (c + 2 < nch) load(0, (c + 2) * 4 * CH);
+            mult(1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cp[(int64_t)(4 * r) * ld] = c0[r] - acc0[r];
+        cp[(int64_t)(4 * r) * ld + 16] = c1[r] - acc1[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PANEL(j), column tile pt.  The eliminated matrix is the 128 x 64 stack M = [D; I] in LDS (D = the block row's
+// diagonal block, already carrying every earlier contribution): the column operations of the Cholesky, applied to the
+// identity rows as well, leave L^-T in them.  The 64 columns go 16 at a time:
+//   (1) wave 0 eliminates the 16 x 16 diagonal sub-block and the identity rows under it in registers (lane = row,
+//       pivots and multipliers broadcast with v_readlane);
+//   (2) the three non-zero 16 x 16 blocks of the panel are multiplied by the sub-block's L^-T on the matrix cores;
+//   (3) the trailing 16 x 16 blocks are updated on the matrix cores - wave 0 takes the next diagonal sub-block first
+//       and goes straight on to (1) while the other seven waves do the rest.
+// Then the workgroup's own 64 x 128 tile X of the block row becomes inv(L) X (lower-triangular product on the matrix
+// cores, k only up to the diagonal).  The diagonal block itself is left as it is (nothing reads R_jj later, and other
+// workgroups of this launch are still reading D); W's block j receives inv(L).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void panel_body(double *__restrict__ S, int64_t ld, int Np, int j, int pt,
+                                           int32_t *__restrict__ info, double *smem) {
+    double *M = smem;                   // rows 0..63: D -> L (lower);  rows 64..127: I -> L^-T (upper)
+    double *Xs = smem + 2 * NB * LDM;   // [64][LDT]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int c0 = 128 * ((64 * j) / 128 + pt);
+    const double *Dg = S + (int64_t)(64 * j) * ld + 64 * j;
+    const double *Xg = S + (int64_t)(64 * j) * ld + c0;
+    for (int e = tid; e < NB * NB; e += 512) {
+        const int r = e >> 6, c = e & 63;
+        M[r * LDM + c] = (c <= r) ? Dg[(int64_t)r * ld + c] : 0.0;
+        M[(NB + r) * LDM + c] = (c == r) ? 1.0 : 0.0;
+    }
+    for (int e = tid; e < NB * 64; e += 512) {
+        const int r = e >> 6, c2 = (e & 63) * 2;
+        *reinterpret_cast<d2_t *>(&Xs[r * LDT + c2]) = *reinterpret_cast<const d2_t *>(&Xg[(int64_t)r * ld + c2]);
+    }
+    __syncthreads();
+
+    int first_bad = 0;  // 1-based column of the first non-positive / non-finite pivot (wave 0)
+    auto eliminate = [&](int s) {
+        const int l31 = lane & 31;
+        const int prow = (l31 < PB) ? (PB * s + l31) : (NB + PB * s + (l31 - PB));
+        double *row = M + prow * LDM + PB * s;
+        double x[PB];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) x[k] = row[k];
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            const double piv = readlane_f64(x[c], c);
+            const bool ok = (piv > 0.0) && (piv < 1.0e300);
+            first_bad = (!ok && first_bad == 0) ? PB * s + c + 1 : first_bad;
+            x[c] *= rsqrt_refined(piv);
+#pragma unroll
+            for (int k = c + 1; k < PB; ++k) x[k] = fma(-x[c], readlane_f64(x[c], k), x[k]);
+        }
+        if (lane < 2 * PB) {
+#pragma unroll
+            for (int k = 0; k < PB; ++k) row[k] = (lane < PB && k > lane) ? 0.0 : x[k];
+        }
+    };
+    auto panel = [&](int R0, int s) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < PB; kk += 4) {
+            const double a = M[(R0 + l15) * LDM + PB * s + kk + l4];
+            const double b = M[(NB + PB * s + kk + l4) * LDM + PB * s + l15];
+            acc = mfma_f64_16x16x4(a, b, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[(R0 + l4 + 4 * r) * LDM + PB * s + l15] = acc[r];
+    };
+    auto trail = [&](int R0, int c, int s) {
+        d4_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = M[(R0 + l4 + 4 * r) * LDM + PB * c + l15];
+#pragma unroll
+        for (int kk = 0; kk < PB; kk += 4) {
+            const double a = -M[(R0 + l15) * LDM + PB * s + kk + l4];
+            const double b = M[(PB * c + l15) * LDM + PB * s + kk + l4];
+            acc = mfma_f64_16x16x4(a, b, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[(R0 + l4 + 4 * r) * LDM + PB * c + l15] = acc[r];
+    };
+
+    constexpr int NS = NB / PB;  // 4
+    if (w == 0) eliminate(0);
+    __syncthreads();
+    for (int s = 0; s < NS; ++s) {
+        if (w < NS - 1) {  // (2): D row blocks s+1..3 and identity-part row blocks 0..s-1 - always three
+            const int nA = NS - 1 - s;
+            panel(w < nA ? PB * (s + 1 + w) : NB + PB * (w - nA), s);
+        }
+        __syncthreads();
+        if (s == NS - 1) break;
+        if (w == 0) {  // (3)
+            trail(PB * (s + 1), s + 1, s);
+            eliminate(s + 1);
+        } else {
+            int q = 0;
+            for (int c = s + 1; c < NS; ++c) {
+                for (int R = c; R < NS; ++R) {
+                    if (R == s + 1 && c == s + 1) continue;
+                    if (q % 7 == w - 1) trail(PB * R, c, s);
+                    ++q;
+                }
+                for (int m = 0; m <= s; ++m) {
+                    if (q % 7 == w - 1) trail(NB + PB * m, c, s);
+                    ++q;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (pt == 0 && tid == 0 && first_bad) atomicCAS(info, 0, j * NB + first_bad);
+
+    // ---- row <- inv(L) * row for this workgroup's tile.  inv(L)[r][k] = M[64 + k][r], zero for k > r.
+    // wave -> row tiles {p, 3 - p} (balanced: row tile rt needs 4 (rt + 1) k steps) x two 16-column tiles
+    const int p = w & 1, cg = w >> 1;
+    // what each 64-column half of the tile is: 0 = not written, 1 = the scaled row, 2 = W's block j (= inv(L))
+    int what[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int cc = c0 + 64 * h;
+        if (cc < Np) what[h] = (cc >= 64 * j + 64) ? 1 : 0;
+        else what[h] = (cc - Np < 64 * j) ? 1 : (cc - Np == 64 * j ? 2 : 0);
+    }
+    const int myhalf = cg >> 1;  // columns 32 cg .. 32 cg + 31
+    if (what[myhalf] == 1) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int rt = q ? 3 - p : p;
+            d4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+            for (int ks = 0; ks < 4 * (rt + 1); ++ks) {
+                const int k = 4 * ks + l4;
+                const double a = M[(NB + k) * LDM + rt * 16 + l15];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const double b = Xs[k * LDT + (2 * cg + ni) * 16 + l15];
+                    acc[ni] = mfma_f64_16x16x4(a, b, acc[ni]);
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    S[(int64_t)(64 * j + rt * 16 + l4 + 4 * r) * ld + c0 + (2 * cg + ni) * 16 + l15] = acc[ni][r];
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (what[h] == 2) {
+            double *Wg = S + (int64_t)(64 * j) * ld + c0 + 64 * h;
+            for (int e = tid; e < NB * NB; e += 512) {
+                const int r = e >> 6, c = e & 63;
+                Wg[(int64_t)r * ld + c] = (c <= r) ? M[(NB + c) * LDM + r] : 0.0;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void cholinv_kernel(CiArgs a) {
+    __shared__ double smem[SMEM_D];
+    int b = blockIdx.x;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const CiJob &jb = a.l.job[q];
+        if (b < jb.nblk) {
+            if (jb.kind == CI_PANEL) panel_body(a.S, a.ld, a.Np, jb.j, b, a.info, smem);
+            else if (jb.kind == CI_UPD_SMALL) upd_small(a.S, a.ld, a.Np, jb, b);
+            else if (jb.kind == CI_UPD_BIG) upd_big(a.S, a.ld, a.Np, jb, b, smem);
+            return;
+        }
+        b -= jb.nblk;
+    }
+}
+
+// U = W^T restricted to the upper triangle (W = the right half of S, lower triangular): 64x64 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_w_kernel(const double *__restrict__ W, int64_t ldw,
+                                                          double *__restrict__ U, int64_t Np) {
+    __shared__ double tile[NB * (NB + 1)];
+    const int bi = blockIdx.y, bj = blockIdx.x;  // output tile (bi, bj) of U = input tile (bj, bi) of W
+    double *Ub = U + ((int64_t)bi * NB) * Np + (int64_t)bj * NB;
+    if (bj < bi) {
+        for (int e = threadIdx.x; e < NB * NB; e += 256) Ub[(int64_t)(e >> 6) * Np + (e & 63)] = 0.0;
+        return;
+    }
+    const double *Wb = W + ((int64_t)bj * NB) * ldw + (int64_t)bi * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256)
+        tile[(e >> 6) * (NB + 1) + (e & 63)] = Wb[(int64_t)(e >> 6) * ldw + (e & 63)];
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        double v = tile[c * (NB + 1) + r];
+        if (bi == bj && c < r) v = 0.0;
+        Ub[(int64_t)r * Np + c] = v;
+    }
+}
+
+}  // namespace
+
+// S: [Np x ld] row-major, ld >= 2 Np, columns [0, Np) = the symmetric positive definite matrix, [Np, 2 Np) = zeros.
+// On return columns [Np, 2 Np) hold inv(L) (lower triangular); the upper block triangle of [0, Np) holds L^T except its
+// diagonal blocks.  *info (cleared by the caller on this stream) receives the 1-based index of the first bad pivot.
+int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int *opt /* optional {G, near_big_from, w_panel, w_narrow, max_launches} */,
+                     hipStream_t st) {
+    if (!S || !info || Np < 128 || Np % 128 || ld < 2 * Np || (ld & 1) || Np > 32768) return GPBO_ERR_ARG;
+    if ((int64_t)15 * ld + 128 > 0x7fffffffLL) return GPBO_ERR_ARG;
+    CiPlanOptions o = ci_default_options((int)Np);
+    if (opt) {
+        if (opt[0] > 0) o.G = opt[0];
+        if (opt[1] > 0) o.near_big_from = opt[1];
+        if (opt[2] > 0) o.w_panel = opt[2];
+        if (opt[3] > 0) o.w_narrow = opt[3];
+    }
+    if (o.G < 1 || (o.G & 1)) return GPBO_ERR_ARG;
+    const std::vector<CiLaunch> plan = ci_plan((int)Np, o);
+    CiArgs a;
+    a.S = S;
+    a.ld = ld;
+    a.Np = (int32_t)Np;
+    a.info = info;
+    int left = (opt && opt[4] > 0) ? opt[4] : (int)plan.size();  // debugging: stop after this many launches
+    for (const CiLaunch &l : plan) {
+        if (left-- <= 0) break;
+        a.l = l;
+        const int nblk = l.job[0].nblk + l.job[1].nblk + l.job[2].nblk;
+        if (nblk <= 0) continue;
+        hipLaunchKernelGGL(cholinv_kernel, dim3((unsigned)nblk), dim3(512), 0, st, a);
+    }
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
+int gpbo_launch_transpose_w(const double *W, int64_t ldw, int64_t Np, double *U, hipStream_t st) {
+    dim3 grid((unsigned)(Np / NB), (unsigned)(Np / NB));
+    hipLaunchKernelGGL(transpose_w_kernel, grid, dim3(256), 0, st, W, ldw, U, Np);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
+// ---- plan introspection for the CPU simulator (no GPU needed) -----------------------------------------------------
+extern "C" int64_t gpbo_cholinv_plan(int64_t Np, const int32_t *opt, int32_t *out, int64_t cap) {
+    if (Np < 128 || Np % 128 || Np > 32768) return GPBO_ERR_ARG;
+    CiPlanOptions o = ci_default_options((int)Np);
+    if (opt) {
+        if (opt[0] > 0) o.G = opt[0];
+        if (opt[1] > 0) o.near_big_from = opt[1];
+        if (opt[2] > 0) o.w_panel = opt[2];
+        if (opt[3] > 0) o.w_narrow = opt[3];
+    }
+    if (o.G < 1 || (o.G & 1)) return GPBO_ERR_ARG;
+    const std::vector<CiLaunch> plan = ci_plan((int)Np, o);
+    const int64_t words = (int64_t)plan.size() * 27;  // 3 jobs x 9 int32 per launch
+    if (out) {
+        if (cap < words) return GPBO_ERR_WORKSPACE;
+        int64_t p = 0;
+        for (const CiLaunch &l : plan)
+            for (int q = 0; q < 3; ++q) {
+                const CiJob &jb = l.job[q];
+                const int32_t v[9] = {jb.kind, jb.nblk, jb.j, jb.k0, jb.K, jb.r0, jb.r1, jb.wlim, jb.t0};
+                for (int i = 0; i < 9; ++i) out[p++] = v[i];
+            }
+    }
+    return words;
+}
+
+extern "C" int gpbo_cholinv_tile(int32_t kind, int64_t Np, int32_t r0, int32_t wlim, int32_t t, int32_t *row0,
+                                 int32_t *col0) {
+    if (!row0 || !col0) return GPBO_ERR_ARG;
+    int r = 0, c = 0;
+    if (kind == CI_UPD_SMALL) ci_small_decode((int)Np, r0, wlim, t, &r, &c);
+    else if (kind == CI_UPD_BIG) ci_big_decode((int)Np, r0, wlim, t, &r, &c);
+    else return GPBO_ERR_ARG;
+    *row0 = r;
+    *col0 = c;
+    return GPBO_OK;
+}
+
+// The factorisation alone on a caller-provided stacked matrix (tests, tools/bench_factorise.py).
+extern "C" int gpbo_cholinv_f64(double *S, int64_t ld, int64_t Np, int32_t *info, const int32_t *opt, void *stream) {
+    hipStream_t st = gpbo_stream(stream);
+    if (!S || !info || Np < 128 || Np % 128 || ld < 2 * Np || (ld & 1) || Np > 32768) return GPBO_ERR_ARG;
+    if (hipMemsetAsync(info, 0, sizeof(int32_t), st) != hipSuccess) return GPBO_ERR_LAUNCH;
+    return gpbo_cholinv_run(S, ld, Np, info, opt, st);
+}

@@ -435,8 +435,22 @@ extern "C" int gpbo_factorise_f64(const double *X, const double *y, int64_t N, i
     double *W = L + Np * Np;
     double *dinv = W + Np * Np;
     double *tmp = dinv + Np * NB;
+    // Round 3: one sweep of row operations over the stacked matrix S = [K | 0] (cholinv.hip) leaves inv(L) in its right
+    // half; U is its transpose.  The two-pass chain of round 2 (blocked Cholesky, then the block-recursive triangular
+    // inverse) stays behind GPBO_FACTOR_OLD=1 for A/B runs and behind gpbo_potrf_f64 / gpbo_trtri_f64.
+    static const bool old_chain = getenv("GPBO_FACTOR_OLD") && atoi(getenv("GPBO_FACTOR_OLD"));
+    if (!old_chain) {
+        double *S = L;  // [Np x 2 Np]: the same 2 Np^2 doubles
+        int rc = gpbo_kxx_launch(X, N, d, ls_host, jitter1, jitter2, Kp, Np, S, 2 * Np, info, stream);
+        if (rc != GPBO_OK) return rc;
+        rc = gpbo_cholinv_run(S, 2 * Np, Np, info, nullptr, gpbo_stream(stream));
+        if (rc != GPBO_OK) return rc;
+        rc = gpbo_launch_transpose_w(S + Np, 2 * Np, Np, U, gpbo_stream(stream));
+        if (rc != GPBO_OK) return rc;
+        return gpbo_alpha_f64(U, y, N, Np, tmp, alpha, stream);
+    }
     // one launch builds K twice (Kp stays as the reference's cov_meas, L is factorised in place) and clears info
-    int rc = gpbo_kxx_launch(X, N, d, ls_host, jitter1, jitter2, Kp, Np, L, info, stream);
+    int rc = gpbo_kxx_launch(X, N, d, ls_host, jitter1, jitter2, Kp, Np, L, Np, info, stream);
     if (rc != GPBO_OK) return rc;
     rc = potrf_run(L, Np, dinv, info, true, stream);
     if (rc != GPBO_OK) return rc;

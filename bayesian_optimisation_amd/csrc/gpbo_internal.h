@@ -61,7 +61,10 @@ int gpbo_kstar_mu_mixed(const double *Xs, int64_t Mc, const double *Xsc, int64_t
                         const double *ls_host, const double *alpha, double diag_add, int64_t cand_base, float *KsT,
                         int64_t ldk, double *mu_part, void *stream);
 int gpbo_kxx_launch(const double *X, int64_t N, int32_t d, const double *ls_host, double jitter1, double jitter2,
-                    double *Kp, int64_t Np, double *K2, int32_t *info0, void *stream);
+                    double *Kp, int64_t Np, double *K2, int64_t ld2, int32_t *info0, void *stream);
+// fused Cholesky + inverse factor on the stacked matrix [A | W] (cholinv.hip)
+int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int *opt, hipStream_t st);
+int gpbo_launch_transpose_w(const double *W, int64_t ldw, int64_t Np, double *U, hipStream_t st);
 int gpbo_scale_points_launch(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host, double *Xsc,
                              unsigned long long *zero_word, void *stream);
 int gpbo_launch_transpose_upper(const double *W, int64_t Np, double *U, hipStream_t st);

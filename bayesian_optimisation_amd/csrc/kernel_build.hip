@@ -38,7 +38,9 @@ template <int D>
 __global__ __launch_bounds__(256) void kxx_kernel(const double *__restrict__ X, int N, LsArgs ls, double j1,
                                                   double j2, double *__restrict__ K, int Np,
                                                   double *__restrict__ K2 /* optional second copy (the one the
-                                                  Cholesky overwrites) */, int32_t *__restrict__ info0 /* optional:
+                                                  factorisation overwrites), row stride ld2; ld2 >= 2 Np: the stacked
+                                                  matrix [K | 0] of cholinv.hip, zeros written here too */, int ld2,
+                                                  int32_t *__restrict__ info0 /* optional:
                                                   zeroed here, saving the factorisation a launch */) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (info0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *info0 = 0;
@@ -58,7 +60,10 @@ __global__ __launch_bounds__(256) void kxx_kernel(const double *__restrict__ X, 
             v = (i == j) ? 1.0 : 0.0;
         }
         K[(int64_t)i * Np + j] = v;
-        if (K2) K2[(int64_t)i * Np + j] = v;
+        if (K2) {
+            K2[(int64_t)i * ld2 + j] = v;
+            if (ld2 >= 2 * Np) K2[(int64_t)i * ld2 + Np + j] = 0.0;
+        }
     }
 }
 
@@ -277,15 +282,16 @@ static int make_ls(const double *ls_host, int d, LsArgs *out) {
     }
 
 int gpbo_kxx_launch(const double *X, int64_t N, int32_t d, const double *ls_host, double jitter1, double jitter2,
-                    double *Kp, int64_t Np, double *K2, int32_t *info0, void *stream) {
+                    double *Kp, int64_t Np, double *K2, int64_t ld2, int32_t *info0, void *stream) {
     if (!X || !Kp || N < 1 || Np < N || Np % 64 != 0 || Np > (1 << 20)) return GPBO_ERR_ARG;
+    if (K2 && (ld2 < Np || ld2 > (1 << 21))) return GPBO_ERR_ARG;
     LsArgs ls;
     int rc = make_ls(ls_host, d, &ls);
     if (rc != GPBO_OK) return rc;
     dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / 8));
 #define CALL(DD) \
     hipLaunchKernelGGL(kxx_kernel<DD>, grid, dim3(256), 0, gpbo_stream(stream), X, (int)N, ls, jitter1, jitter2, Kp, (int)Np, \
-                       K2, info0)
+                       K2, (int)ld2, info0)
     GPBO_DISPATCH_D(d, CALL)
 #undef CALL
 #undef KSTAR_LAUNCH
@@ -295,7 +301,7 @@ int gpbo_kxx_launch(const double *X, int64_t N, int32_t d, const double *ls_host
 
 extern "C" int gpbo_kxx_f64(const double *X, int64_t N, int32_t d, const double *ls_host, double jitter1,
                             double jitter2, double *Kp, int64_t Np, void *stream) {
-    return gpbo_kxx_launch(X, N, d, ls_host, jitter1, jitter2, Kp, Np, nullptr, nullptr, stream);
+    return gpbo_kxx_launch(X, N, d, ls_host, jitter1, jitter2, Kp, Np, nullptr, 0, nullptr, stream);
 }
 
 int gpbo_scale_points_launch(const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host, double *Xsc,

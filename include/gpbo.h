@@ -90,12 +90,26 @@ int gpbo_potrf_f64(double *Kp, int64_t Np, double *dinv, int32_t *info, void *st
  * work: Np*Np doubles. Together with gpbo_potrf_f64 this is the factorisation the posterior uses. */
 int gpbo_trtri_f64(const double *L, const double *dinv, int64_t Np, double *U, double *work, void *stream);
 
+/* K4, round 3 - the same inverse (point_selector.py:89) in ONE sweep: fused Cholesky + inverse factor by row
+ * operations on the stacked matrix S = [A | W], [Np x ld] row-major with ld >= 2 Np (csrc/cholinv.hip).
+ * In: columns [0, Np) = the symmetric positive definite matrix (both triangles), columns [Np, 2 Np) = zeros.
+ * Out: columns [Np, 2 Np) = inv(L), lower triangular (U of gpbo_trtri_f64 is its transpose); the upper block triangle
+ * of columns [0, Np) holds L^T except on its 64 x 64 diagonal blocks, which keep their last Schur complements.
+ * info as gpbo_potrf_f64.  Np: a multiple of 128.  opt: NULL, or int32[5] {G, near_big_from, w_panel, w_narrow, max_launches} (0 = default): schedule tuning, and for
+ * tests the first max_launches launches of the plan only (gpbo_cholinv_plan reads the first four). */
+int gpbo_cholinv_f64(double *S, int64_t ld, int64_t Np, int32_t *info, const int32_t *opt, void *stream);
+/* The launch plan of gpbo_cholinv_f64 as data (no GPU needed; tests/test_cholinv_plan_cpu.py executes it with NumPy):
+ * returns the number of int32 words (27 per launch = 3 jobs x {kind, nblk, j, k0, K, r0, r1, wlim, t0}), writes them
+ * when out != NULL and cap suffices.  gpbo_cholinv_tile: tile t of an update job -> first row / first column of S. */
+int64_t gpbo_cholinv_plan(int64_t Np, const int32_t *opt, int32_t *out, int64_t cap);
+int gpbo_cholinv_tile(int32_t kind, int64_t Np, int32_t r0, int32_t wlim, int32_t t, int32_t *row0, int32_t *col0);
+
 /* alpha = K^-1 y = U (U^T y)   (point_selector.py:90 `inv @ measured_vals`).
  * y: [N]; alpha: [Np] (zero on the padding); tmp: [Np]. */
 int gpbo_alpha_f64(const double *U, const double *y, int64_t N, int64_t Np, double *tmp, double *alpha,
                    void *stream);
 
-/* One call = kxx + potrf + trtri + alpha.  work: gpbo_factorise_workspace_bytes(Np) bytes.
+/* One call = kxx + cholinv + transpose + alpha (round 2: kxx + potrf + trtri + alpha).  work: gpbo_factorise_workspace_bytes(Np) bytes.
  * Outputs: Kp keeps K (the reference's `cov_meas`, point_selector.py:79; L lives in the workspace),
  * U [Np x Np], alpha [Np], info (device int32, as gpbo_potrf_f64). */
 int64_t gpbo_factorise_workspace_bytes(int64_t Np);

@@ -1,4 +1,5 @@
-"""Time of gpbo_factorise_f64 alone (median of repeated groups): python tools/bench_factorise.py [N ...]"""
+"""Time of gpbo_factorise_f64 alone (median of repeated groups): python tools/bench_factorise.py [N ...]
+GPBO_FACTOR_OLD=1 selects the round-2 chain (potrf + trtri) for an A/B on the same box."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
