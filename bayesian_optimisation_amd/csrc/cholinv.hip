@@ -7,12 +7,13 @@
 // row operations over the stacked matrix S = [A | W] (cholinv_plan.h): on exit W = L^-1 = U^T.
 //
 // One kernel, three kinds of workgroup (512 threads), mixed inside a launch (cholinv_plan.h decides):
-//   PANEL      64 x 64 diagonal block: Cholesky AND the inverse of its factor in one elimination (registers + LDS +
-//              MFMA), computed redundantly by every workgroup of the block row, then row <- inv(L_jj) * row for the
-//              workgroup's own 64 x 128 tile on the matrix cores.  The critical path of the factorisation.
+//   PAIR       the 128 x 128 diagonal block of a pair of block rows: Cholesky AND the inverse of its factor (two
+//              64 x 64 eliminations in registers + LDS + MFMA with the Schur step between them), computed redundantly
+//              by every workgroup of the launch, then rows <- inv(L) * rows for the workgroup's own 64 columns, in
+//              registers on the matrix cores.  The critical path of the factorisation.
 //   UPD_SMALL  64 x 64 tile of out -= A^T B, K <= 256: MFMA fragments straight from global memory (k-major operands:
 //              16 lanes read 128 contiguous bytes), no LDS, no barrier - the lowest latency for the updates that sit on
-//              the critical path (the group's own rows, the next group's rows).
+//              the critical path (the next pair's rows).
 //   UPD_BIG    128 x 128 tile, 16-deep k tiles through a three-stage LDS ring filled by global_load_lds (the loop of
 //              sigma_acq_kernel): the bulk of the flops, run as filler workgroups beside the panels.
 // Dependencies are launch order on one stream; inside a launch no workgroup reads what another one writes
@@ -20,6 +21,9 @@
 #include "gpbo_internal.h"
 
 #include "cholinv_plan.h"
+
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -30,7 +34,7 @@ constexpr int LDT = 128 + 16;        // row stride of a 128-wide k-major operand
                                      // ds_read_b64 group (k and k+1) land in disjoint banks
 constexpr int BKT = 16;              // k depth of a stage
 constexpr int STAGE_D = 2 * BKT * LDT;                 // doubles per stage: A tile + B tile
-constexpr int PANEL_D = 2 * NB * LDM + NB * LDT;       // elimination matrix [128][LDM] + the row tile [64][LDT]
+constexpr int PANEL_D = 4 * NB * LDM;                  // PAIR: four [64][LDM] blocks
 constexpr int SMEM_D = (3 * STAGE_D > PANEL_D) ? 3 * STAGE_D : PANEL_D;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -60,6 +64,7 @@ struct CiArgs {
     int64_t ld;
     int32_t Np;
     int32_t *info;
+    unsigned long long *stamps;  // GPBO_DIAGNOSTICS builds: cycle stamps of the first PAIR workgroup of a launch
     CiLaunch l;
 };
 
@@ -228,44 +233,24 @@ __device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// PANEL(j), column tile pt.  The eliminated matrix is the 128 x 64 stack M = [D; I] in LDS (D = the block row's
-// diagonal block, already carrying every earlier contribution): the column operations of the Cholesky, applied to the
-// identity rows as well, leave L^-T in them.  The 64 columns go 16 at a time:
+// Cholesky of one 64 x 64 block AND the inverse of its factor, in one elimination.  The eliminated matrix is the
+// 128 x 64 stack [D; I] (Mtop = D, lower triangle, Mbot = I; both [64][LDM] in LDS): the column operations of the
+// Cholesky, applied to the identity rows as well, leave L^-T in them.  The 64 columns go 16 at a time:
 //   (1) wave 0 eliminates the 16 x 16 diagonal sub-block and the identity rows under it in registers (lane = row,
 //       pivots and multipliers broadcast with v_readlane);
 //   (2) the three non-zero 16 x 16 blocks of the panel are multiplied by the sub-block's L^-T on the matrix cores;
 //   (3) the trailing 16 x 16 blocks are updated on the matrix cores - wave 0 takes the next diagonal sub-block first
 //       and goes straight on to (1) while the other seven waves do the rest.
-// Then the workgroup's own 64 x 128 tile X of the block row becomes inv(L) X (lower-triangular product on the matrix
-// cores, k only up to the diagonal).  The diagonal block itself is left as it is (nothing reads R_jj later, and other
-// workgroups of this launch are still reading D); W's block j receives inv(L).
+// All 8 waves call it (barriers inside); the caller has synchronised after filling Mtop / Mbot.
+// Returns (wave 0 only) the 1-based column of the first non-positive / non-finite pivot, or 0.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void panel_body(double *__restrict__ S, int64_t ld, int Np, int j, int pt,
-                                           int32_t *__restrict__ info, double *smem) {
-    double *M = smem;                   // rows 0..63: D -> L (lower);  rows 64..127: I -> L^-T (upper)
-    double *Xs = smem + 2 * NB * LDM;   // [64][LDT]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+__device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int lane) {
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int c0 = 128 * ((64 * j) / 128 + pt);
-    const double *Dg = S + (int64_t)(64 * j) * ld + 64 * j;
-    const double *Xg = S + (int64_t)(64 * j) * ld + c0;
-    for (int e = tid; e < NB * NB; e += 512) {
-        const int r = e >> 6, c = e & 63;
-        M[r * LDM + c] = (c <= r) ? Dg[(int64_t)r * ld + c] : 0.0;
-        M[(NB + r) * LDM + c] = (c == r) ? 1.0 : 0.0;
-    }
-    for (int e = tid; e < NB * 64; e += 512) {
-        const int r = e >> 6, c2 = (e & 63) * 2;
-        *reinterpret_cast<d2_t *>(&Xs[r * LDT + c2]) = *reinterpret_cast<const d2_t *>(&Xg[(int64_t)r * ld + c2]);
-    }
-    __syncthreads();
-
-    int first_bad = 0;  // 1-based column of the first non-positive / non-finite pivot (wave 0)
+    auto rowp = [&](int R) { return (R < NB) ? Mtop + R * LDM : Mbot + (R - NB) * LDM; };  // row R of the stack
+    int first_bad = 0;
     auto eliminate = [&](int s) {
         const int l31 = lane & 31;
-        const int prow = (l31 < PB) ? (PB * s + l31) : (NB + PB * s + (l31 - PB));
-        double *row = M + prow * LDM + PB * s;
+        double *row = ((l31 < PB) ? Mtop + (PB * s + l31) * LDM : Mbot + (PB * s + (l31 - PB)) * LDM) + PB * s;
         double x[PB];
 #pragma unroll
         for (int k = 0; k < PB; ++k) x[k] = row[k];
@@ -283,31 +268,32 @@ __device__ __forceinline__ void panel_body(double *__restrict__ S, int64_t ld, i
             for (int k = 0; k < PB; ++k) row[k] = (lane < PB && k > lane) ? 0.0 : x[k];
         }
     };
-    auto panel = [&](int R0, int s) {
+    auto panel = [&](int R0, int s) {  // rows R0.. (16) of column block s  <-  (those rows) * L_ss^-T
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        const double *ra = rowp(R0 + l15) + PB * s;
 #pragma unroll
         for (int kk = 0; kk < PB; kk += 4) {
-            const double a = M[(R0 + l15) * LDM + PB * s + kk + l4];
-            const double b = M[(NB + PB * s + kk + l4) * LDM + PB * s + l15];
+            const double a = ra[kk + l4];
+            const double b = Mbot[(PB * s + kk + l4) * LDM + PB * s + l15];
             acc = mfma_f64_16x16x4(a, b, acc);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) M[(R0 + l4 + 4 * r) * LDM + PB * s + l15] = acc[r];
+        for (int r = 0; r < 4; ++r) rowp(R0 + l4 + 4 * r)[PB * s + l15] = acc[r];
     };
-    auto trail = [&](int R0, int c, int s) {
+    auto trail = [&](int R0, int c, int s) {  // rows R0.. of column block c  -=  (rows R0.., block s) * D[block c, block s]^T
         d4_t acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = M[(R0 + l4 + 4 * r) * LDM + PB * c + l15];
+        for (int r = 0; r < 4; ++r) acc[r] = rowp(R0 + l4 + 4 * r)[PB * c + l15];
+        const double *ra = rowp(R0 + l15) + PB * s;
 #pragma unroll
         for (int kk = 0; kk < PB; kk += 4) {
-            const double a = -M[(R0 + l15) * LDM + PB * s + kk + l4];
-            const double b = M[(PB * c + l15) * LDM + PB * s + kk + l4];
+            const double a = -ra[kk + l4];
+            const double b = Mtop[(PB * c + l15) * LDM + PB * s + kk + l4];
             acc = mfma_f64_16x16x4(a, b, acc);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) M[(R0 + l4 + 4 * r) * LDM + PB * c + l15] = acc[r];
+        for (int r = 0; r < 4; ++r) rowp(R0 + l4 + 4 * r)[PB * c + l15] = acc[r];
     };
-
     constexpr int NS = NB / PB;  // 4
     if (w == 0) eliminate(0);
     __syncthreads();
@@ -337,51 +323,165 @@ __device__ __forceinline__ void panel_body(double *__restrict__ S, int64_t ld, i
         }
         __syncthreads();
     }
-    if (pt == 0 && tid == 0 && first_bad) atomicCAS(info, 0, j * NB + first_bad);
+    return first_bad;
+}
 
-    // ---- row <- inv(L) * row for this workgroup's tile.  inv(L)[r][k] = M[64 + k][r], zero for k > r.
-    // wave -> row tiles {p, 3 - p} (balanced: row tile rt needs 4 (rt + 1) k steps) x two 16-column tiles
-    const int p = w & 1, cg = w >> 1;
-    // what each 64-column half of the tile is: 0 = not written, 1 = the scaled row, 2 = W's block j (= inv(L))
-    int what[2];
+// ---------------------------------------------------------------------------------------------------------------
+// PAIR(p), column tile pt: the 128 rows [128 p, 128 p + 128) in ONE workgroup launch - what used to be four launches
+// (diagonal block, narrow update, diagonal block, row scaling).  Every workgroup of the launch factorises the pair's
+// 128 x 128 diagonal block D = [D11 A12; . D22] redundantly (identical arithmetic, identical bits):
+//     L11, inv(L11)  <-  D11                         factor64
+//     R12 = inv(L11) A12                             (= L21^T)
+//     D22 -= R12^T R12 ;  L22, inv(L22)  <-  D22     factor64
+// and then applies inv(L) = [inv(L11) 0; -inv(L22) L21 inv(L11)  inv(L22)] to its own 64 columns X = [X1; X2] of the
+// two block rows as three products that never leave the registers:
+//     X1' = inv(L11) X1 ;   X2 <- X2 - R12^T X1' ;   X2' = inv(L22) X2
+// (waves 0..3, one 16-column strip each: the fp64 16x16x4 MFMA's C layout - row = lane/16 + 4 r - IS the B operand
+// layout of the next product, k = lane/16 within k step r).  W's diagonal block of the pair is the same computation
+// on X = I.  The pair's diagonal block of A is left alone: nothing reads it later, other workgroups are reading it now.
+// LDS: four [64][LDM] blocks - B0: D11 -> L11, then D22 -> L22;  B1: I -> inv(L11)^T (kept);  B2: I -> inv(L22)^T;
+// B3: A12 -> R12.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, int Np, int p, int pt,
+                                          int32_t *__restrict__ info, double *smem, unsigned long long *stamps) {
+    double *B0 = smem, *B1 = smem + NB * LDM, *B2 = smem + 2 * NB * LDM, *B3 = smem + 3 * NB * LDM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int r0 = 128 * p;
+#ifdef GPBO_DIAGNOSTICS
+    int nst = 0;
+#define CI_STAMP() do { if (stamps && pt == 0 && tid == 0) stamps[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CI_STAMP() do { } while (0)
+#endif
+    CI_STAMP();
+    // column tile: A part beyond the pair's diagonal block, then W part incl. the pair's own diagonal block of W
+    const int nA = (Np - (r0 + 128)) / 64;
+    const int c0 = (pt < nA) ? r0 + 128 + 64 * pt : Np + 64 * (pt - nA);
+    const int wid_blk = (c0 >= Np) ? (c0 - Np - r0) / 64 : -1;  // 0 / 1: column block of W's diagonal 128 x 128 block
+    const bool ident = c0 >= Np && c0 - Np >= r0;
+
+    // X strip of this wave (waves 0..3): B-operand fragments straight from global memory, in flight during phase 1
+    double x1[16], x2[16];
+    if (w < 4) {
+        const double *xp = S + (int64_t)(r0 + l4) * ld + c0 + 16 * w + l15;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int cc = c0 + 64 * h;
-        if (cc < Np) what[h] = (cc >= 64 * j + 64) ? 1 : 0;
-        else what[h] = (cc - Np < 64 * j) ? 1 : (cc - Np == 64 * j ? 2 : 0);
+        for (int s = 0; s < 16; ++s) {
+            if (!ident) {
+                x1[s] = xp[(int64_t)(4 * s) * ld];
+                x2[s] = xp[(int64_t)(64 + 4 * s) * ld];
+            } else {  // X = [I; 0] (column block 0) or [0; I] (column block 1): row 4 s + l4, column 16 w + l15
+                const double d = (4 * s + l4 == 16 * w + l15) ? 1.0 : 0.0;
+                x1[s] = (wid_blk == 0) ? d : 0.0;
+                x2[s] = (wid_blk == 1) ? d : 0.0;
+            }
+        }
     }
-    const int myhalf = cg >> 1;  // columns 32 cg .. 32 cg + 31
-    if (what[myhalf] == 1) {
+    // D22 tiles of this wave in MFMA C layout (tiles 2 w, 2 w + 1 of the 4 x 4 tiles: row tile = t / 4, col tile = t % 4)
+    const double *Dg = S + (int64_t)r0 * ld + r0;
+    d4_t d22[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int t = 2 * w + q, mi = t >> 2, ni = t & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d22[q][r] = Dg[(int64_t)(64 + 16 * mi + l4 + 4 * r) * ld + 64 + 16 * ni + l15];
+    }
+    for (int e = tid; e < NB * NB; e += 512) {
+        const int r = e >> 6, c = e & 63;
+        B0[r * LDM + c] = (c <= r) ? Dg[(int64_t)r * ld + c] : 0.0;
+        B1[r * LDM + c] = (c == r) ? 1.0 : 0.0;
+        B2[r * LDM + c] = (c == r) ? 1.0 : 0.0;
+        B3[r * LDM + c] = Dg[(int64_t)r * ld + 64 + c];
+    }
+    __syncthreads();
+    CI_STAMP();
+    const int bad1 = factor64(B0, B1, w, lane);   // ends with a barrier after the last panel step
+    CI_STAMP();
+    // R12 = inv(L11) A12: inv(L11)[r][k] = B1[k][r], zero for k > r.  16 output tiles, two per wave; both of a wave's
+    // tiles are read completely before the barrier, written after it (in place in B3).
+    {
+        d4_t acc[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int rt = q ? 3 - p : p;
-            d4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-            for (int ks = 0; ks < 4 * (rt + 1); ++ks) {
+            const int t = 2 * w + q, mi = t >> 2, ni = t & 3;
+            acc[q] = d4_t{0.0, 0.0, 0.0, 0.0};
+            for (int ks = 0; ks < 4 * (mi + 1); ++ks) {
                 const int k = 4 * ks + l4;
-                const double a = M[(NB + k) * LDM + rt * 16 + l15];
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const double b = Xs[k * LDT + (2 * cg + ni) * 16 + l15];
-                    acc[ni] = mfma_f64_16x16x4(a, b, acc[ni]);
-                }
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    S[(int64_t)(64 * j + rt * 16 + l4 + 4 * r) * ld + c0 + (2 * cg + ni) * 16 + l15] = acc[ni][r];
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (what[h] == 2) {
-            double *Wg = S + (int64_t)(64 * j) * ld + c0 + 64 * h;
-            for (int e = tid; e < NB * NB; e += 512) {
-                const int r = e >> 6, c = e & 63;
-                Wg[(int64_t)r * ld + c] = (c <= r) ? M[(NB + c) * LDM + r] : 0.0;
+                acc[q] = mfma_f64_16x16x4(B1[k * LDM + 16 * mi + l15], B3[k * LDM + 16 * ni + l15], acc[q]);
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int t = 2 * w + q, mi = t >> 2, ni = t & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) B3[(16 * mi + l4 + 4 * r) * LDM + 16 * ni + l15] = acc[q][r];
+        }
+        __syncthreads();
     }
+    // D22 -= R12^T R12 -> B0 (lower triangle; zeros above), B2 = I already
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int t = 2 * w + q, mi = t >> 2, ni = t & 3;
+        d4_t acc = d22[q];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int k = 4 * ks + l4;
+            acc = mfma_f64_16x16x4(-B3[k * LDM + 16 * mi + l15], B3[k * LDM + 16 * ni + l15], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * mi + l4 + 4 * r, cc = 16 * ni + l15;
+            B0[rr * LDM + cc] = (cc <= rr) ? acc[r] : 0.0;
+        }
+    }
+    __syncthreads();
+    CI_STAMP();
+    const int bad2 = factor64(B0, B2, w, lane);
+    CI_STAMP();
+    if (pt == 0 && tid == 0) {
+        const int bad = bad1 ? r0 + bad1 : (bad2 ? r0 + 64 + bad2 : 0);
+        if (bad) atomicCAS(info, 0, bad);
+    }
+    if (w < 4) {
+        double *xp = S + (int64_t)(r0 + l4) * ld + c0 + 16 * w + l15;
+        double y1[16];
+        // X1' = inv(L11) X1
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4 * (mi + 1); ++ks)
+                acc = mfma_f64_16x16x4(B1[(4 * ks + l4) * LDM + 16 * mi + l15], x1[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y1[4 * mi + r] = acc[r];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xp[(int64_t)(4 * s) * ld] = y1[s];
+        // X2 <- X2 - R12^T X1'  (L21[r][k] = R12[k][r])
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            d4_t acc = {x2[4 * mi], x2[4 * mi + 1], x2[4 * mi + 2], x2[4 * mi + 3]};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                acc = mfma_f64_16x16x4(-B3[(4 * ks + l4) * LDM + 16 * mi + l15], y1[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x2[4 * mi + r] = acc[r];
+        }
+        // X2' = inv(L22) X2
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4 * (mi + 1); ++ks)
+                acc = mfma_f64_16x16x4(B2[(4 * ks + l4) * LDM + 16 * mi + l15], x2[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xp[(int64_t)(64 + 16 * mi + 4 * r) * ld] = acc[r];
+        }
+    }
+    CI_STAMP();
+#undef CI_STAMP
 }
 
 __global__ __launch_bounds__(512) void cholinv_kernel(CiArgs a) {
@@ -391,7 +491,7 @@ __global__ __launch_bounds__(512) void cholinv_kernel(CiArgs a) {
     for (int q = 0; q < 3; ++q) {
         const CiJob &jb = a.l.job[q];
         if (b < jb.nblk) {
-            if (jb.kind == CI_PANEL) panel_body(a.S, a.ld, a.Np, jb.j, b, a.info, smem);
+            if (jb.kind == CI_PAIR) pair_body(a.S, a.ld, a.Np, jb.j, b, a.info, smem, a.stamps);
             else if (jb.kind == CI_UPD_SMALL) upd_small(a.S, a.ld, a.Np, jb, b);
             else if (jb.kind == CI_UPD_BIG) upd_big(a.S, a.ld, a.Np, jb, b, smem);
             return;
@@ -427,33 +527,50 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const double *__restri
 // S: [Np x ld] row-major, ld >= 2 Np, columns [0, Np) = the symmetric positive definite matrix, [Np, 2 Np) = zeros.
 // On return columns [Np, 2 Np) hold inv(L) (lower triangular); the upper block triangle of [0, Np) holds L^T except its
 // diagonal blocks.  *info (cleared by the caller on this stream) receives the 1-based index of the first bad pivot.
-int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int *opt /* optional {G, near_big_from, w_panel, w_narrow, max_launches} */,
+int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int *opt /* optional {-, near_big_from, -, -, max_launches} */,
                      hipStream_t st) {
     if (!S || !info || Np < 128 || Np % 128 || ld < 2 * Np || (ld & 1) || Np > 32768) return GPBO_ERR_ARG;
     if ((int64_t)15 * ld + 128 > 0x7fffffffLL) return GPBO_ERR_ARG;
     CiPlanOptions o = ci_default_options((int)Np);
-    if (opt) {
-        if (opt[0] > 0) o.G = opt[0];
-        if (opt[1] > 0) o.near_big_from = opt[1];
-        if (opt[2] > 0) o.w_panel = opt[2];
-        if (opt[3] > 0) o.w_narrow = opt[3];
-    }
-    if (o.G < 1 || (o.G & 1)) return GPBO_ERR_ARG;
+    if (opt && opt[1] > 0) o.near_big_from = opt[1];
     const std::vector<CiLaunch> plan = ci_plan((int)Np, o);
     CiArgs a;
     a.S = S;
     a.ld = ld;
     a.Np = (int32_t)Np;
     a.info = info;
+    a.stamps = nullptr;
     int left = (opt && opt[4] > 0) ? opt[4] : (int)plan.size();  // debugging: stop after this many launches
+#ifdef GPBO_DIAGNOSTICS
+    // GPBO_CI_STAMPS=1 (timing builds only): cycle stamps of workgroup 0 of every PAIR launch, averaged and printed
+    static unsigned long long *dstamps = nullptr;
+    const bool want_stamps = getenv("GPBO_CI_STAMPS") && atoi(getenv("GPBO_CI_STAMPS"));
+    if (want_stamps && !dstamps && hipMalloc(&dstamps, 8 * 8 * 1024) != hipSuccess) return GPBO_ERR_LAUNCH;
+    int npair = 0;
+#endif
     for (const CiLaunch &l : plan) {
         if (left-- <= 0) break;
         a.l = l;
         const int nblk = l.job[0].nblk + l.job[1].nblk + l.job[2].nblk;
         if (nblk <= 0) continue;
+#ifdef GPBO_DIAGNOSTICS
+        a.stamps = (want_stamps && l.job[0].kind == CI_PAIR && npair < 1024) ? dstamps + 8 * npair++ : nullptr;
+#endif
         hipLaunchKernelGGL(cholinv_kernel, dim3((unsigned)nblk), dim3(512), 0, st, a);
     }
     GPBO_CHECK_LAUNCH();
+#ifdef GPBO_DIAGNOSTICS
+    if (want_stamps && npair > 0) {
+        std::vector<unsigned long long> h(8 * npair);
+        if (hipStreamSynchronize(st) != hipSuccess) return GPBO_ERR_LAUNCH;
+        if (hipMemcpy(h.data(), dstamps, 8 * 8 * npair, hipMemcpyDeviceToHost) != hipSuccess) return GPBO_ERR_LAUNCH;
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < npair; ++i)
+            for (int q = 0; q < 5; ++q) sum[q] += (double)(h[8 * i + q + 1] - h[8 * i + q]);
+        fprintf(stderr, "PAIR stamps (cycles, mean of %d): load %.0f  factor1 %.0f  r12+schur %.0f  factor2 %.0f  xops+store %.0f\n",
+                npair, sum[0] / npair, sum[1] / npair, sum[2] / npair, sum[3] / npair, sum[4] / npair);
+    }
+#endif
     return GPBO_OK;
 }
 
@@ -468,13 +585,7 @@ int gpbo_launch_transpose_w(const double *W, int64_t ldw, int64_t Np, double *U,
 extern "C" int64_t gpbo_cholinv_plan(int64_t Np, const int32_t *opt, int32_t *out, int64_t cap) {
     if (Np < 128 || Np % 128 || Np > 32768) return GPBO_ERR_ARG;
     CiPlanOptions o = ci_default_options((int)Np);
-    if (opt) {
-        if (opt[0] > 0) o.G = opt[0];
-        if (opt[1] > 0) o.near_big_from = opt[1];
-        if (opt[2] > 0) o.w_panel = opt[2];
-        if (opt[3] > 0) o.w_narrow = opt[3];
-    }
-    if (o.G < 1 || (o.G & 1)) return GPBO_ERR_ARG;
+    if (opt && opt[1] > 0) o.near_big_from = opt[1];
     const std::vector<CiLaunch> plan = ci_plan((int)Np, o);
     const int64_t words = (int64_t)plan.size() * 27;  // 3 jobs x 9 int32 per launch
     if (out) {

@@ -11,22 +11,22 @@
 // with both operands read k-major (row k contiguous) - the layout the gfx950 fp64 MFMA fragments want from LDS.
 // The live columns of block row b are contiguous in S: [64 b, Np) of A, then [Np, Np + wlim) of W.
 //
-// Schedule.  Block rows are taken in groups of G.  Inside a group, row j first receives the contributions of the
-// group's earlier rows (NARROW, K = 64 (j - j0)), then PANEL(j) factorises its 64 x 64 diagonal block (redundantly in
-// every workgroup of the launch) and multiplies the row by the inverse of the block's factor.  After the group, its
-// rank-64G contribution goes to the NEXT group's rows at once (NEAR) and to all later rows (FAR) as filler workgroups
-// inside the next group's launches: one stream, dependencies by launch order only, no events, no in-kernel flags.
+// Schedule.  Rows are taken in pairs of block rows (128 rows).  PAIR(p) factorises the pair's 128 x 128 diagonal block
+// (redundantly in every workgroup of the launch) and multiplies the pair's rows by the inverse of the block's factor.
+// The pair's rank-128 contribution then goes to the NEXT pair's rows at once (NEAR) and to all later rows (FAR) as
+// filler workgroups inside the next pair's launch: one stream, dependencies by launch order only, no events, no
+// in-kernel flags.
 #pragma once
 #include <stdint.h>
 
 #include <vector>
 
-enum { CI_NONE = 0, CI_PANEL = 1, CI_UPD_SMALL = 2, CI_UPD_BIG = 3 };
+enum { CI_NONE = 0, CI_PAIR = 1, CI_UPD_SMALL = 2, CI_UPD_BIG = 3 };
 
 struct CiJob {
     int32_t kind;   // CI_*
     int32_t nblk;   // workgroups of this job in the launch
-    int32_t j;      // PANEL: block row
+    int32_t j;      // PAIR: pair index p (rows [128 p, 128 p + 128))
     int32_t k0, K;  // UPD: source rows [k0, k0 + K)
     int32_t r0, r1; // UPD: target rows [r0, r1), multiples of 64
     int32_t wlim;   // UPD: live W columns [Np, Np + wlim)
@@ -79,24 +79,18 @@ CI_HD inline void ci_big_decode(int Np, int r0, int wlim, int t, int *row0, int 
     *row0 = rr;
     *col0 = rr / 128 * 128 + 128 * t;
 }
-// PANEL(j): 128-wide column tiles of S from the tile that holds column 64 j to the one that holds W's block j
-CI_HD inline int ci_panel_ntiles(int Np, int j) {
-    const int first = (64 * j) / 128, last = (Np + 64 * j + 63) / 128;
-    return last - first + 1;
-}
+// PAIR(p): one workgroup per 64 live columns of the pair's rows: (Np - 128 (p + 1)) / 64 of A, 128 p / 64 of W, and the
+// two column blocks of W's own diagonal block = Np / 64 for every p.
+CI_HD inline int ci_pair_ntiles(int Np) { return Np / 64; }
 
 struct CiPlanOptions {
-    int G;             // block rows per group (even; the last group may be shorter)
-    int near_big_from; // NEAR goes to 128 x 128 tiles when it has more than this many 64 x 64 tiles
-    int w_panel, w_narrow;  // share of the FAR filler tiles a panel / narrow launch takes (relative weights)
+    int near_big_from;  // NEAR goes to 128 x 128 tiles when it has more than this many 64 x 64 tiles
 };
 
 inline CiPlanOptions ci_default_options(int Np) {
+    (void)Np;
     CiPlanOptions o;
-    o.G = (Np >= 6144) ? 4 : 2;
-    o.near_big_from = 600;
-    o.w_panel = 3;
-    o.w_narrow = 1;
+    o.near_big_from = 1 << 30;
     return o;
 }
 
@@ -108,57 +102,27 @@ inline CiJob ci_upd_job(int kind, int Np, int k0, int K, int r0, int r1, int wli
     return u;
 }
 
+// Per pair p: NEAR(p) brings the pair's rows up to date with pair p-1 (the older pairs reached them as FAR fillers),
+// then PAIR(p) runs with the FAR tiles of pair p-1 (its contribution to every row beyond pair p) as filler workgroups.
 inline std::vector<CiLaunch> ci_plan(int Np, const CiPlanOptions &o) {
     std::vector<CiLaunch> out;
-    const int nb = Np / 64, G = o.G;
-    CiJob far = {};  // the previous group's update of the rows beyond the current group's successor
-    for (int j0 = 0; j0 < nb; j0 += G) {
-        const int gend = (j0 + G < nb) ? j0 + G : nb;
-        std::vector<CiLaunch> L;
-        std::vector<int> weight;
-        for (int j = j0; j < gend; ++j) {
-            if (j > j0) {
-                CiLaunch l = {};
-                l.job[0] = ci_upd_job(CI_UPD_SMALL, Np, 64 * j0, 64 * (j - j0), 64 * j, 64 * j + 64, 64 * j);
-                L.push_back(l);
-                weight.push_back(o.w_narrow);
-            }
+    const int np = Np / 128;
+    for (int p = 0; p < np; ++p) {
+        if (p > 0) {  // NEAR: rows of pair p  -=  contribution of pair p-1
             CiLaunch l = {};
-            l.job[0].kind = CI_PANEL;
-            l.job[0].j = j;
-            l.job[0].nblk = ci_panel_ntiles(Np, j);
-            L.push_back(l);
-            weight.push_back(o.w_panel);
+            const int nsmall = ci_small_ntiles(Np, 128 * p, 128 * p + 128, 128 * p);
+            l.job[0] = ci_upd_job(nsmall > o.near_big_from ? CI_UPD_BIG : CI_UPD_SMALL, Np, 128 * (p - 1), 128, 128 * p,
+                                  128 * p + 128, 128 * p);
+            out.push_back(l);
         }
-        // FAR tiles of the previous group: spread over this group's panel / narrow launches (all of them read rows
-        // the previous group has finished and write rows beyond this group - nothing this group's launches touch)
-        if (far.kind != CI_NONE && far.nblk > 0) {
-            int wsum = 0;
-            for (int w : weight) wsum += w;
-            int done = 0, acc = 0;
-            for (size_t i = 0; i < L.size(); ++i) {
-                acc += weight[i];
-                const int upto = (i + 1 == L.size()) ? far.nblk : (int)((int64_t)far.nblk * acc / wsum);
-                if (upto > done) {
-                    CiJob f = far;
-                    f.t0 = done;
-                    f.nblk = upto - done;
-                    L[i].job[2] = f;
-                    done = upto;
-                }
-            }
-        }
-        far = CiJob{};
-        if (gend < nb) {
-            const int k0 = 64 * j0, K = 64 * (gend - j0), wlim = 64 * gend;
-            const int n0 = 64 * gend, n1 = (64 * (gend + G) < Np) ? 64 * (gend + G) : Np;
-            CiLaunch l = {};
-            const int nsmall = ci_small_ntiles(Np, n0, n1, wlim);
-            l.job[0] = ci_upd_job(nsmall > o.near_big_from ? CI_UPD_BIG : CI_UPD_SMALL, Np, k0, K, n0, n1, wlim);
-            L.push_back(l);
-            if (n1 < Np) far = ci_upd_job(CI_UPD_BIG, Np, k0, K, n1, Np, wlim);
-        }
-        for (const CiLaunch &l : L) out.push_back(l);
+        CiLaunch l = {};
+        l.job[0].kind = CI_PAIR;
+        l.job[0].j = p;
+        l.job[0].nblk = ci_pair_ntiles(Np);
+        // FAR of pair p-1: rows beyond pair p (which NEAR(p) has just served): reads rows of pair p-1 (final), writes
+        // rows >= 128 (p + 1) - nothing PAIR(p) touches
+        if (p > 0 && 128 * (p + 1) < Np) l.job[2] = ci_upd_job(CI_UPD_BIG, Np, 128 * (p - 1), 128, 128 * (p + 1), Np, 128 * p);
+        out.push_back(l);
     }
     return out;
 }

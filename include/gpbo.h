@@ -94,9 +94,9 @@ int gpbo_trtri_f64(const double *L, const double *dinv, int64_t Np, double *U, d
  * operations on the stacked matrix S = [A | W], [Np x ld] row-major with ld >= 2 Np (csrc/cholinv.hip).
  * In: columns [0, Np) = the symmetric positive definite matrix (both triangles), columns [Np, 2 Np) = zeros.
  * Out: columns [Np, 2 Np) = inv(L), lower triangular (U of gpbo_trtri_f64 is its transpose); the upper block triangle
- * of columns [0, Np) holds L^T except on its 64 x 64 diagonal blocks, which keep their last Schur complements.
- * info as gpbo_potrf_f64.  Np: a multiple of 128.  opt: NULL, or int32[5] {G, near_big_from, w_panel, w_narrow, max_launches} (0 = default): schedule tuning, and for
- * tests the first max_launches launches of the plan only (gpbo_cholinv_plan reads the first four). */
+ * of columns [0, Np) holds L^T except on its 128 x 128 diagonal blocks, which keep their last Schur complements.
+ * info as gpbo_potrf_f64.  Np: a multiple of 128.  opt: NULL, or int32[5] {reserved, near_big_from, reserved, reserved, max_launches} (0 = default): tile choice of
+ * the NEAR updates, and for tests the first max_launches launches of the plan only (gpbo_cholinv_plan reads the first four). */
 int gpbo_cholinv_f64(double *S, int64_t ld, int64_t Np, int32_t *info, const int32_t *opt, void *stream);
 /* The launch plan of gpbo_cholinv_f64 as data (no GPU needed; tests/test_cholinv_plan_cpu.py executes it with NumPy):
  * returns the number of int32 words (27 per launch = 3 jobs x {kind, nblk, j, k0, K, r0, r1, wlim, t0}), writes them

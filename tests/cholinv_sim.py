@@ -7,7 +7,7 @@ import numpy as np
 
 from bayesian_optimisation_amd import _lib
 
-NONE, PANEL, SMALL, BIG = 0, 1, 2, 3
+NONE, PAIR, SMALL, BIG = 0, 1, 2, 3
 
 
 def get_plan(Np, opt=None):
@@ -59,28 +59,33 @@ def run_plan(S, Np, plan, reads_tile_wide=True):
         for kind, nblk, j, k0, K, r0, r1, wlim, t0 in launch:
             if kind == NONE or nblk == 0:
                 continue
-            if kind == PANEL:
-                D = S[64 * j:64 * j + 64, 64 * j:64 * j + 64]
-                L = np.linalg.cholesky(np.tril(D) + np.tril(D, -1).T)
-                Linv = np.linalg.solve(L, np.eye(64))
+            if kind == PAIR:
+                r0p = 128 * j
+                D = S[r0p:r0p + 128, r0p:r0p + 128]
+                D = np.tril(D) + np.tril(D, -1).T
+                D[:64, 64:] = S[r0p:r0p + 64, r0p + 64:r0p + 128]  # the kernel reads A12 from the upper block
+                D[64:, :64] = D[:64, 64:].T
+                L = np.linalg.cholesky(D)
+                Linv = np.tril(np.linalg.solve(L, np.eye(128)))
+                nA = (Np - (r0p + 128)) // 64
+                assert nblk == Np // 64
                 for pt in range(nblk):
                     tile_id += 1
-                    c0 = 128 * ((64 * j) // 128 + pt)
-                    assert c0 + 128 <= 2 * Np
-                    tr.read(tile_id, 64 * j, 64 * j + 64, 64 * j, 64 * j + 64)
-                    tr.read(tile_id, 64 * j, 64 * j + 64, c0, c0 + 128)
+                    c0 = r0p + 128 + 64 * pt if pt < nA else Np + 64 * (pt - nA)
+                    assert c0 + 64 <= 2 * Np
+                    tr.read(tile_id, r0p, r0p + 128, r0p, r0p + 128)
+                    ident = c0 >= Np and c0 - Np >= r0p
+                    if ident:
+                        X = np.zeros((128, 64))
+                        blk = (c0 - Np - r0p) // 64
+                        X[64 * blk:64 * blk + 64, :] = np.eye(64)
+                    else:
+                        X = S[r0p:r0p + 128, c0:c0 + 64]
+                        tr.read(tile_id, r0p, r0p + 128, c0, c0 + 64)
+                    Y = Linv @ X
                     for h in range(2):
-                        cc = c0 + 64 * h
-                        if cc < Np:
-                            what = 1 if cc >= 64 * j + 64 else 0
-                        else:
-                            what = 1 if cc - Np < 64 * j else (2 if cc - Np == 64 * j else 0)
-                        if what == 1:
-                            pending.append((64 * j, cc, Linv @ S[64 * j:64 * j + 64, cc:cc + 64]))
-                            tr.write(tile_id, 64 * j, cc)
-                        elif what == 2:
-                            pending.append((64 * j, cc, np.tril(Linv)))
-                            tr.write(tile_id, 64 * j, cc)
+                        pending.append((r0p + 64 * h, c0, Y[64 * h:64 * h + 64]))
+                        tr.write(tile_id, r0p + 64 * h, c0)
             elif kind == SMALL:
                 for t in range(nblk):
                     tile_id += 1
