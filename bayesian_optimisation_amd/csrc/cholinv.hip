@@ -22,8 +22,12 @@
 
 #include "cholinv_plan.h"
 
+#include <array>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -33,7 +37,7 @@ constexpr int LDM = NB + 2;          // row stride of the elimination matrix in 
 constexpr int LDT = 128 + 16;        // row stride of a 128-wide k-major operand tile in LDS: lanes l and l+16 of a
                                      // ds_read_b64 group (k and k+1) land in disjoint banks
 constexpr int BKT = 16;              // k depth of a stage
-constexpr int STAGE_D = 2 * BKT * LDT;                 // doubles per stage: A tile + B tile
+constexpr int STAGE_D = BKT * (256 + 16 + LDT);        // doubles per stage of the widest ring: A tile [16][272] + B tile [16][144]
 constexpr int PANEL_D = 4 * NB * LDM;                  // PAIR: four [64][LDM] blocks
 constexpr int SMEM_D = (3 * STAGE_D > PANEL_D) ? 3 * STAGE_D : PANEL_D;
 
@@ -65,19 +69,27 @@ struct CiArgs {
     int32_t Np;
     int32_t *info;
     unsigned long long *stamps;  // GPBO_DIAGNOSTICS builds: cycle stamps of the first PAIR workgroup of a launch
+    const CiTile *tab;           // the plan's tile table (device)
     CiLaunch l;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// UPD_BIG: out[128 x 128] -= sum_k S[k][row0 + m] * S[k][col0 + n], k in [k0, k0 + K)
-// 8 waves as 4 (rows) x 2 (columns): wave tile 32 x 64 = 2 x 4 MFMA tiles; the two waves of a SIMD (w, w + 4) take the
-// even / odd 16-column tiles.  Per 16-deep k tile: 32 KiB by LDS-DMA (each wave two rows of either operand, 1 KiB per
-// instruction), 32 MFMAs per wave; one barrier in the middle of the tile (see sigma_acq_kernel for why there).
+// UPD_BIG: out[BM x 128] -= sum_k S[k][row0 + m] * S[k][col0 + n], k in [k0, k0 + K);  BM = 64 MI = 128 or 256.
+// 8 waves as 4 (rows) x 2 (columns): wave tile (BM/4) x 64 = MI x 4 MFMA tiles; the two waves of a SIMD (w, w + 4) take
+// the even / odd 16-column tiles.  Per 16-deep k tile: 16 (BM + 128) doubles by LDS-DMA (1 KiB per wave instruction),
+// 8 MI MFMAs per wave and k step; one barrier in the middle of the tile (see sigma_acq_kernel for why there).
+// BM = 256 is the tile of sigma_acq_kernel (6 B/clk/CU of operands); BM = 128 needs 8 B/clk/CU and has half the
+// MFMAs between two barriers: it serves the updates that have few tiles.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int Np, const CiJob &u, int t,
-                                        double *smem) {
-    int row0, col0;
-    ci_big_decode(Np, u.r0, u.wlim, u.t0 + t, &row0, &col0);
+template <int MI>
+__device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int Np, const CiTile &u, double *smem) {
+    constexpr int BM = 64 * MI;
+    constexpr int LDA = BM + 16;                  // A tile row stride (doubles)
+    constexpr int STG = BKT * (LDA + LDT);        // doubles per stage
+    constexpr int PA = BM / 128;                  // 1 KiB pieces per A row
+    constexpr int NPA = BKT * PA / 8, NPB = BKT / 8;  // pieces per wave per k tile
+    static_assert(3 * STG <= SMEM_D, "LDS ring");
+    const int row0 = u.row0, col0 = u.col0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid & 3, wq = wid >> 2;
@@ -85,30 +97,36 @@ __device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int 
 
     const double *pa = S + (int64_t)u.k0 * ld + row0;
     const double *pb = S + (int64_t)u.k0 * ld + col0;
-    unsigned voff[2];
-    int lds_off[2];
+    unsigned voffA[NPA], voffB[NPB];
+    int ldsA[NPA], ldsB[NPB];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        voff[r] = (unsigned)((wid + 8 * r) * (unsigned)ld + lane * 2);
-        lds_off[r] = (wid + 8 * r) * LDT;
+    for (int r = 0; r < NPA; ++r) {
+        const int v = wid + 8 * r, row = v / PA, piece = v % PA;
+        voffA[r] = (unsigned)(row * (unsigned)ld + piece * 128 + lane * 2);
+        ldsA[r] = row * LDA + piece * 128;
+    }
+#pragma unroll
+    for (int r = 0; r < NPB; ++r) {
+        voffB[r] = (unsigned)((wid + 8 * r) * (unsigned)ld + lane * 2);
+        ldsB[r] = BKT * LDA + (wid + 8 * r) * LDT;
     }
     const int nk = u.K / BKT;
     int pk = 0, pbuf = 0;
     auto stage_next = [&]() {
-        double *St = smem + pbuf * STAGE_D;
+        double *St = smem + pbuf * STG;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) glds16(pa + voff[r], St + lds_off[r]);
+        for (int r = 0; r < NPA; ++r) glds16(pa + voffA[r], St + ldsA[r]);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) glds16(pb + voff[r], St + BKT * LDT + lds_off[r]);
+        for (int r = 0; r < NPB; ++r) glds16(pb + voffB[r], St + ldsB[r]);
         pbuf = (pbuf == 2) ? 0 : pbuf + 1;
         ++pk;
         pa += (int64_t)BKT * ld;
         pb += (int64_t)BKT * ld;
     };
 
-    d4_t acc[2][4];
+    d4_t acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
 
@@ -117,62 +135,108 @@ __device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    double a0[2], b0[4], a1[2], b1[4];
-    auto lds_frag = [&](double (&af)[2], double (&bf)[4], int buf, int kk) {
-        const double *As = smem + buf * STAGE_D;
-        const double *Bs = As + BKT * LDT;
+    double a0[MI], b0[4], a1[MI], b1[4];
+    auto lds_frag = [&](double (&af)[MI], double (&bf)[4], int buf, int kk) {
+        const double *As = smem + buf * STG;
+        const double *Bs = As + BKT * LDA;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) af[mi] = As[(kk + l4) * LDT + wr * 32 + mi * 16 + l15];
+        for (int mi = 0; mi < MI; ++mi) af[mi] = As[(kk + l4) * LDA + wr * (BM / 4) + mi * 16 + l15];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[(kk + l4) * LDT + (2 * ni + wq) * 16 + l15];
     };
-    auto mfma8 = [&](const double (&af)[2], const double (&bf)[4]) {
+    auto mfma_half = [&](const double (&af)[MI], const double (&bf)[4], int nlo) {
+#pragma unroll
+        for (int ni = nlo; ni < nlo + 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf[ni], acc[mi][ni]);
+    };
+    // The C tile is streamed INTO the accumulators while the k loop runs: row batch mi (its 16 live values per lane) is
+    // loaded during k tile mi and subtracted from the accumulators during k tile mi + 1, so acc = sum - C and the
+    // epilogue is nothing but the (posted) stores of -acc.  Read after the loop instead, the C tiles of all workgroups
+    // of a launch cross the fabric together and unhidden: 15 us of a 30 us 128 x 128 x 128 tile, 21 of 84 us at
+    // 256 x 128 x 256 (tools/bench_ci_jobs.py) - a rank-128 update moves 16 B per 256 flop, the chip's HBM balance.
+    double *cbp = S + (int64_t)(row0 + wr * (BM / 4) + l4) * ld + col0 + wq * 16 + l15;  // element (mi, ni, r): + (16 mi + 4 r) ld + 32 ni
+    auto live_at = [&](int mi, int ni) {
+        const int rbase = row0 + wr * (BM / 4) + mi * 16, cbase = col0 + (2 * ni + wq) * 16;
+        return rbase < u.r1 && (cbase < Np ? cbase >= (rbase & ~63) : cbase < Np + u.wlim);
+    };
+    double cb[4][4];
+    auto load_batch = [&](int mi) {  // mi may be a run-time value: nothing here indexes a register array with it
+        const double *cp = cbp + (int64_t)(16 * mi) * ld;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            if (live_at(mi, ni)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cb[ni][r] = cp[(int64_t)(4 * r) * ld + 32 * ni];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cb[ni][r] = 0.0;
+            }
+        }
+    };
+    auto fold_batch = [&](auto mi_tag) {  // compile-time mi: a run-time index would send the accumulators to scratch
+        constexpr int mi = decltype(mi_tag)::value;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf[ni], acc[mi][ni]);
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] -= cb[ni][r];
     };
     lds_frag(a0, b0, 0, 0);
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    auto k_tile = [&](auto kt_tag) {  // kt_tag::value = the k tile's index while C is on the move (0 .. MI), else -1
+        constexpr int KT = decltype(kt_tag)::value;
         const int nxt = (cur == 2) ? 0 : cur + 1;
         __builtin_amdgcn_sched_barrier(0);
-        mfma8(a0, b0);
+        mfma_half(a0, b0, 0);
         lds_frag(a1, b1, cur, 4);
         __builtin_amdgcn_sched_barrier(0);
-        mfma8(a1, b1);
+        mfma_half(a0, b0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(a1, b1, 0);
         lds_frag(a0, b0, cur, 8);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own share of tile kt+1 has landed
-        __builtin_amdgcn_s_barrier();                      // ... everybody's has; everybody has left tile kt-1
-        if (pk < nk) stage_next();                         // tile kt+2 into the stage tile kt-1 occupied
+        mfma_half(a1, b1, 2);
         __builtin_amdgcn_sched_barrier(0);
-        mfma8(a0, b0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own share of tile kt+1 has landed (and C batch kt-1)
+        __builtin_amdgcn_s_barrier();                      // ... everybody's has; everybody has left tile kt-1
+        if constexpr (KT > 0 && KT <= MI) fold_batch(std::integral_constant<int, (KT > 0 ? KT - 1 : 0)>{});  // C batch KT-1
+        if constexpr (KT >= 0 && KT < MI) load_batch(KT);                                                    // batch KT on its way
+        // tile kt+2 into the stage tile kt-1 occupied; the two waves of a SIMD issue their DMAs half a tile apart
+        if (pk < nk && wq == 0) stage_next();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(a0, b0, 0);
         lds_frag(a1, b1, cur, 12);
         __builtin_amdgcn_sched_barrier(0);
-        mfma8(a1, b1);
+        mfma_half(a0, b0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(a1, b1, 0);
         lds_frag(a0, b0, nxt, 0);  // first step of the next tile (stale but in-bounds after the last one)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(a1, b1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pk < nk && wq != 0) stage_next();
         cur = nxt;
+    };
+    // the first MI + 1 k tiles also move C (K >= 16 (MI + 1) = 80: every update of the plan has K >= 128)
+    k_tile(std::integral_constant<int, 0>{});
+    k_tile(std::integral_constant<int, 1>{});
+    k_tile(std::integral_constant<int, 2>{});
+    if constexpr (MI == 4) {
+        k_tile(std::integral_constant<int, 3>{});
+        k_tile(std::integral_constant<int, 4>{});
     }
-
-    // out = C - acc on the live part of the tile (masks are uniform per 16 x 16 MFMA tile: boundaries are 64-granular)
+    for (int kt = MI + 1; kt < nk; ++kt) k_tile(std::integral_constant<int, -1>{});
+    // out = C - sum = -acc on the live part of the tile (masks are uniform per 16 x 16 MFMA tile: 64-granular)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int rbase = row0 + wr * 32 + mi * 16;
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const int cbase = col0 + (2 * ni + wq) * 16;
-            const bool live = rbase < u.r1 && (cbase < Np ? cbase >= (rbase & ~63) : cbase < Np + u.wlim);
-            if (live) {
-                double *cp = S + (int64_t)(rbase + l4) * ld + cbase + l15;
-                double c[4];
+            if (live_at(mi, ni)) {
+                double *cp = cbp + (int64_t)(16 * mi) * ld + 32 * ni;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) c[r] = cp[(int64_t)(4 * r) * ld];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cp[(int64_t)(4 * r) * ld] = c[r] - acc[mi][ni][r];
+                for (int r = 0; r < 4; ++r) cp[(int64_t)(4 * r) * ld] = -acc[mi][ni][r];
             }
         }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -180,9 +244,8 @@ __device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int 
 // 16 x 32.  Fragments come straight from global memory, 32 k at a time (24 loads in flight per lane), the next 32 k
 // are in flight while the current ones are multiplied.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, int Np, const CiJob &u, int t) {
-    int row0, col0;
-    ci_small_decode(Np, u.r0, u.wlim, u.t0 + t, &row0, &col0);
+__device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, const CiTile &u) {
+    const int row0 = u.row0, col0 = u.col0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wrow = wid & 3, wcol = wid >> 2;
@@ -486,18 +549,15 @@ __device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, in
 
 __global__ __launch_bounds__(512) void cholinv_kernel(CiArgs a) {
     __shared__ double smem[SMEM_D];
-    int b = blockIdx.x;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const CiJob &jb = a.l.job[q];
-        if (b < jb.nblk) {
-            if (jb.kind == CI_PAIR) pair_body(a.S, a.ld, a.Np, jb.j, b, a.info, smem, a.stamps);
-            else if (jb.kind == CI_UPD_SMALL) upd_small(a.S, a.ld, a.Np, jb, b);
-            else if (jb.kind == CI_UPD_BIG) upd_big(a.S, a.ld, a.Np, jb, b, smem);
-            return;
-        }
-        b -= jb.nblk;
+    const int b = blockIdx.x;
+    if (b < a.l.npair) {
+        pair_body(a.S, a.ld, a.Np, a.l.pair, b, a.info, smem, a.stamps);
+        return;
     }
+    const CiTile t = a.tab[a.l.tile0 + (b - a.l.npair)];  // wave-uniform: scalar loads
+    if (t.kind == CI_UPD_SMALL) upd_small(a.S, a.ld, t);
+    else if (t.kind == CI_UPD_BIG) upd_big<2>(a.S, a.ld, a.Np, t, smem);
+    else if (t.kind == CI_UPD_BIG256) upd_big<4>(a.S, a.ld, a.Np, t, smem);
 }
 
 // U = W^T restricted to the upper triangle (W = the right half of S, lower triangular): 64x64 tiles through LDS.
@@ -524,23 +584,62 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const double *__restri
 
 }  // namespace
 
+// ---- host side ---------------------------------------------------------------------------------------------------
+// The plan of a size is built once and its tile table kept on the device (per device, size and options), for the life of
+// the process.  Not a capturable operation the FIRST time a size is seen (synchronous upload); afterwards the call only
+// enqueues kernels.
+struct DevPlan {
+    CiPlan plan;
+    CiTile *dtiles = nullptr;
+};
+
+static const DevPlan *plan_for(int Np, const CiPlanOptions &o) {
+    static std::mutex mu;
+    static std::map<std::array<int, 6>, DevPlan *> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const std::array<int, 6> key = {dev, Np, o.win, o.far_k, o.far_kind, o.defer};
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    DevPlan *dp = new DevPlan;
+    dp->plan = ci_plan(Np, o);
+    const size_t bytes = dp->plan.tiles.size() * sizeof(CiTile);
+    if (bytes) {
+        if (hipMalloc(&dp->dtiles, bytes) != hipSuccess) { delete dp; return nullptr; }
+        if (hipMemcpy(dp->dtiles, dp->plan.tiles.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(dp->dtiles);
+            delete dp;
+            return nullptr;
+        }
+    }
+    cache[key] = dp;
+    return dp;
+}
+
+static bool ci_sizes_ok(const double *S, int64_t ld, int64_t Np) {
+    return S && Np >= 128 && Np % 128 == 0 && ld >= 2 * Np && (ld & 1) == 0 && Np <= 32768 &&
+           (int64_t)15 * ld + 256 <= 0x7fffffffLL;
+}
+
 // S: [Np x ld] row-major, ld >= 2 Np, columns [0, Np) = the symmetric positive definite matrix, [Np, 2 Np) = zeros.
 // On return columns [Np, 2 Np) hold inv(L) (lower triangular); the upper block triangle of [0, Np) holds L^T except its
-// diagonal blocks.  *info (cleared by the caller on this stream) receives the 1-based index of the first bad pivot.
-int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int *opt /* optional {-, near_big_from, -, -, max_launches} */,
-                     hipStream_t st) {
-    if (!S || !info || Np < 128 || Np % 128 || ld < 2 * Np || (ld & 1) || Np > 32768) return GPBO_ERR_ARG;
-    if ((int64_t)15 * ld + 128 > 0x7fffffffLL) return GPBO_ERR_ARG;
-    CiPlanOptions o = ci_default_options((int)Np);
-    if (opt && opt[1] > 0) o.near_big_from = opt[1];
-    const std::vector<CiLaunch> plan = ci_plan((int)Np, o);
+// 128 x 128 diagonal blocks.  *info (cleared by the caller on this stream) receives the 1-based index of the first bad
+// pivot.  opt: NULL or int32[5] {win, far_k, far_kind, defer + 1, max_launches}, 0 = default.
+int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int *opt, hipStream_t st) {
+    if (!ci_sizes_ok(S, ld, Np) || !info) return GPBO_ERR_ARG;
+    const CiPlanOptions o = ci_options_from((int)Np, opt);
+    if (!ci_options_ok(o)) return GPBO_ERR_ARG;
+    const DevPlan *dp = plan_for((int)Np, o);
+    if (!dp) return GPBO_ERR_LAUNCH;
     CiArgs a;
     a.S = S;
     a.ld = ld;
     a.Np = (int32_t)Np;
     a.info = info;
     a.stamps = nullptr;
-    int left = (opt && opt[4] > 0) ? opt[4] : (int)plan.size();  // debugging: stop after this many launches
+    a.tab = dp->dtiles;
+    int left = (opt && opt[4] > 0) ? opt[4] : (int)dp->plan.launches.size();  // tests: stop after this many launches
 #ifdef GPBO_DIAGNOSTICS
     // GPBO_CI_STAMPS=1 (timing builds only): cycle stamps of workgroup 0 of every PAIR launch, averaged and printed
     static unsigned long long *dstamps = nullptr;
@@ -548,13 +647,13 @@ int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int
     if (want_stamps && !dstamps && hipMalloc(&dstamps, 8 * 8 * 1024) != hipSuccess) return GPBO_ERR_LAUNCH;
     int npair = 0;
 #endif
-    for (const CiLaunch &l : plan) {
+    for (const CiLaunch &l : dp->plan.launches) {
         if (left-- <= 0) break;
         a.l = l;
-        const int nblk = l.job[0].nblk + l.job[1].nblk + l.job[2].nblk;
+        const int nblk = l.npair + l.ntile;
         if (nblk <= 0) continue;
 #ifdef GPBO_DIAGNOSTICS
-        a.stamps = (want_stamps && l.job[0].kind == CI_PAIR && npair < 1024) ? dstamps + 8 * npair++ : nullptr;
+        a.stamps = (want_stamps && l.npair > 0 && npair < 1024) ? dstamps + 8 * npair++ : nullptr;
 #endif
         hipLaunchKernelGGL(cholinv_kernel, dim3((unsigned)nblk), dim3(512), 0, st, a);
     }
@@ -582,41 +681,78 @@ int gpbo_launch_transpose_w(const double *W, int64_t ldw, int64_t Np, double *U,
 }
 
 // ---- plan introspection for the CPU simulator (no GPU needed) -----------------------------------------------------
-extern "C" int64_t gpbo_cholinv_plan(int64_t Np, const int32_t *opt, int32_t *out, int64_t cap) {
-    if (Np < 128 || Np % 128 || Np > 32768) return GPBO_ERR_ARG;
-    CiPlanOptions o = ci_default_options((int)Np);
-    if (opt && opt[1] > 0) o.near_big_from = opt[1];
-    const std::vector<CiLaunch> plan = ci_plan((int)Np, o);
-    const int64_t words = (int64_t)plan.size() * 27;  // 3 jobs x 9 int32 per launch
-    if (out) {
-        if (cap < words) return GPBO_ERR_WORKSPACE;
-        int64_t p = 0;
-        for (const CiLaunch &l : plan)
-            for (int q = 0; q < 3; ++q) {
-                const CiJob &jb = l.job[q];
-                const int32_t v[9] = {jb.kind, jb.nblk, jb.j, jb.k0, jb.K, jb.r0, jb.r1, jb.wlim, jb.t0};
-                for (int i = 0; i < 9; ++i) out[p++] = v[i];
-            }
+extern "C" int gpbo_cholinv_plan(int64_t Np, const int32_t *opt, int64_t *n_launch, int64_t *n_tile, int32_t *launches,
+                                 int32_t *tiles) {
+    if (Np < 128 || Np % 128 || Np > 32768 || !n_launch || !n_tile) return GPBO_ERR_ARG;
+    const CiPlanOptions o = ci_options_from((int)Np, opt);
+    if (!ci_options_ok(o)) return GPBO_ERR_ARG;
+    const CiPlan P = ci_plan((int)Np, o);
+    if (launches) {
+        if (*n_launch < (int64_t)P.launches.size()) return GPBO_ERR_WORKSPACE;
+        for (size_t i = 0; i < P.launches.size(); ++i) {
+            const CiLaunch &l = P.launches[i];
+            const int32_t v[4] = {l.pair, l.npair, l.tile0, l.ntile};
+            for (int q = 0; q < 4; ++q) launches[4 * i + q] = v[q];
+        }
     }
-    return words;
-}
-
-extern "C" int gpbo_cholinv_tile(int32_t kind, int64_t Np, int32_t r0, int32_t wlim, int32_t t, int32_t *row0,
-                                 int32_t *col0) {
-    if (!row0 || !col0) return GPBO_ERR_ARG;
-    int r = 0, c = 0;
-    if (kind == CI_UPD_SMALL) ci_small_decode((int)Np, r0, wlim, t, &r, &c);
-    else if (kind == CI_UPD_BIG) ci_big_decode((int)Np, r0, wlim, t, &r, &c);
-    else return GPBO_ERR_ARG;
-    *row0 = r;
-    *col0 = c;
+    if (tiles) {
+        if (*n_tile < (int64_t)P.tiles.size()) return GPBO_ERR_WORKSPACE;
+        for (size_t i = 0; i < P.tiles.size(); ++i) {
+            const CiTile &t = P.tiles[i];
+            const int32_t v[8] = {t.kind, t.k0, t.K, t.row0, t.col0, t.r1, t.wlim, 0};
+            for (int q = 0; q < 8; ++q) tiles[8 * i + q] = v[q];
+        }
+    }
+    *n_launch = (int64_t)P.launches.size();
+    *n_tile = (int64_t)P.tiles.size();
     return GPBO_OK;
 }
 
 // The factorisation alone on a caller-provided stacked matrix (tests, tools/bench_factorise.py).
 extern "C" int gpbo_cholinv_f64(double *S, int64_t ld, int64_t Np, int32_t *info, const int32_t *opt, void *stream) {
     hipStream_t st = gpbo_stream(stream);
-    if (!S || !info || Np < 128 || Np % 128 || ld < 2 * Np || (ld & 1) || Np > 32768) return GPBO_ERR_ARG;
+    if (!ci_sizes_ok(S, ld, Np) || !info) return GPBO_ERR_ARG;
     if (hipMemsetAsync(info, 0, sizeof(int32_t), st) != hipSuccess) return GPBO_ERR_LAUNCH;
     return gpbo_cholinv_run(S, ld, Np, info, opt, st);
+}
+
+// One launch made of the PAIR workgroups of `pair` (pair < 0: none) and the given tiles, `reps` times (tests: a tile kind
+// against NumPy; tools/bench_ci_jobs.py: its time).  tiles: host array, 8 words per tile as gpbo_cholinv_plan writes them.
+// Synchronous (uploads the tiles, waits for the launches).
+extern "C" int gpbo_cholinv_tiles_f64(double *S, int64_t ld, int64_t Np, int32_t *info, int32_t pair,
+                                      const int32_t *tiles, int64_t ntile, int32_t reps, void *stream) {
+    if (!ci_sizes_ok(S, ld, Np) || !info || reps < 1 || ntile < 0 || (ntile > 0 && !tiles) || ntile > (1 << 24)) return GPBO_ERR_ARG;
+    if (pair >= 0 && 128 * ((int64_t)pair + 1) > Np) return GPBO_ERR_ARG;
+    if (pair < 0 && ntile == 0) return GPBO_ERR_ARG;
+    std::vector<CiTile> h((size_t)ntile);
+    for (int64_t i = 0; i < ntile; ++i) {
+        const int32_t *v = tiles + 8 * i;
+        CiTile t = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], 0};
+        const int th = t.kind == CI_UPD_SMALL ? 64 : t.kind == CI_UPD_BIG ? 128 : t.kind == CI_UPD_BIG256 ? 256 : 0;
+        const int tw = t.kind == CI_UPD_SMALL ? 64 : 128;
+        if (!th || t.K < (th == 64 ? 32 : 128) || t.K % 32 || t.k0 < 0 || t.k0 + t.K > t.row0 || t.row0 % 64 || t.col0 % tw ||
+            t.row0 >= Np || t.col0 < 0 || t.col0 + tw > 2 * Np || t.r1 > Np || t.r1 <= t.row0 || t.wlim < 0 || t.wlim > Np ||
+            (th == 64 && (t.col0 < t.row0 || t.col0 + 64 > Np + t.wlim || t.row0 + 64 > t.r1)))
+            return GPBO_ERR_ARG;
+        h[(size_t)i] = t;
+    }
+    CiTile *d = nullptr;
+    if (ntile && (hipMalloc(&d, (size_t)ntile * sizeof(CiTile)) != hipSuccess)) return GPBO_ERR_LAUNCH;
+    if (ntile && hipMemcpy(d, h.data(), (size_t)ntile * sizeof(CiTile), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return GPBO_ERR_LAUNCH;
+    }
+    CiArgs a;
+    a.S = S;
+    a.ld = ld;
+    a.Np = (int32_t)Np;
+    a.info = info;
+    a.stamps = nullptr;
+    a.tab = d;
+    a.l = CiLaunch{pair, pair >= 0 ? ci_pair_ntiles((int)Np) : 0, 0, (int32_t)ntile};
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(cholinv_kernel, dim3((unsigned)(a.l.npair + a.l.ntile)), dim3(512), 0, gpbo_stream(stream), a);
+    const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(gpbo_stream(stream)) == hipSuccess;
+    if (d) (void)hipFree(d);
+    return ok ? GPBO_OK : GPBO_ERR_LAUNCH;
 }

@@ -1,128 +1,153 @@
-// Launch plan of the fused Cholesky + inverse factor (cholinv.hip).  Host-only C++ (no HIP types): the same header is
-// compiled into libgpbo and into the CPU simulator tests/c/cholinv_sim.cpp, which executes the plan with plain loops
-// and checks it against LAPACK - so the schedule (what reads what, in which launch) is verified without a GPU.
+// Launch plan of the fused Cholesky + inverse factor (cholinv.hip).  Host-only C++ (no HIP types): the plan is data - a
+// list of launches and a table of tiles - that libgpbo uploads once per matrix size and that tests/cholinv_sim.py
+// executes with NumPy (gpbo_cholinv_plan exports it), so the schedule (what reads what, in which launch) is verified
+// without a GPU.
 //
 // What is factorised: cov_meas = K(X,X) + jitter (/root/reference/point_selector.py:79), which the reference inverts
 // with np.linalg.inv (:89).  Here S = [A | W] is one Np x 2Np row-major matrix, A = cov_meas, W = 0.  ROW operations
-// L^-1 [A | I] = [L^T | L^-1] are applied block row by block row (64 rows), so that on exit
+// L^-1 [A | I] = [L^T | L^-1] are applied pair by pair of block rows (128 rows), so that on exit
 //     A (upper block triangle) = R = L^T         W (lower triangle) = L^-1 = U^T
 // and the variance kernel's U = L^-T is one transposition away.  Every product of the algorithm has the shape
 //     out[r, c] -= sum_k S[k, r] * S[k, c]        (k = finished rows; r = target rows; c = live columns of those rows)
 // with both operands read k-major (row k contiguous) - the layout the gfx950 fp64 MFMA fragments want from LDS.
 // The live columns of block row b are contiguous in S: [64 b, Np) of A, then [Np, Np + wlim) of W.
 //
-// Schedule.  Rows are taken in pairs of block rows (128 rows).  PAIR(p) factorises the pair's 128 x 128 diagonal block
-// (redundantly in every workgroup of the launch) and multiplies the pair's rows by the inverse of the block's factor.
-// The pair's rank-128 contribution then goes to the NEXT pair's rows at once (NEAR) and to all later rows (FAR) as
-// filler workgroups inside the next pair's launch: one stream, dependencies by launch order only, no events, no
-// in-kernel flags.
+// Schedule.  PAIR(p) factorises the pair's 128 x 128 diagonal block (redundantly in every workgroup of the launch) and
+// multiplies the pair's rows by the inverse of the block's factor.  Each pair of target rows t keeps a count applied[t]
+// of the source rows it has received; it must be 128 p when PAIR(p = t) runs.  Updates ride as filler workgroups beside
+// the PAIR workgroups of a launch (one stream, dependencies by launch order only, no events, no in-kernel flags):
+//   NEAR    its own launch before PAIR(p): the last 128 source rows (pair p-1) into pair p, 64 x 64 tiles
+//   WINDOW  beside PAIR(p): targets p+1 .. p+win brought up to 128 p (rank 128, or what a deferral left)
+//   FAR     beside PAIR(p): targets beyond the window brought up to the last multiple of far_k (rank 256: a rank-128
+//           update moves 16 bytes of its target per 256 flop, which is the chip's HBM balance - measured: its tiles
+//           spend as long in their read-modify-write as in their MFMAs); half of a FAR wave is deferred to the next
+//           launch so that odd and even launches carry similar loads.
 #pragma once
 #include <stdint.h>
 
 #include <vector>
 
-enum { CI_NONE = 0, CI_PAIR = 1, CI_UPD_SMALL = 2, CI_UPD_BIG = 3 };
+enum { CI_NONE = 0, CI_PAIR = 1, CI_UPD_SMALL = 2, CI_UPD_BIG = 3, CI_UPD_BIG256 = 4 };
 
-struct CiJob {
-    int32_t kind;   // CI_*
-    int32_t nblk;   // workgroups of this job in the launch
-    int32_t j;      // PAIR: pair index p (rows [128 p, 128 p + 128))
-    int32_t k0, K;  // UPD: source rows [k0, k0 + K)
-    int32_t r0, r1; // UPD: target rows [r0, r1), multiples of 64
-    int32_t wlim;   // UPD: live W columns [Np, Np + wlim)
-    int32_t t0;     // UPD: first tile of the job's enumeration taken by this launch
+// out[rows row0.., cols col0..] -= sum_{k in [k0, k0+K)} S[k][row0 + m] * S[k][col0 + n], stores masked to rows < r1 and
+// to the live columns (col < Np: col >= 64 floor(row / 64);  col >= Np: col < Np + wlim).  SMALL: 64 x 64 (never masked),
+// BIG: 128 x 128, BIG256: 256 x 128.
+struct CiTile {
+    int32_t kind, k0, K, row0, col0, r1, wlim, pad;
 };
 
+// workgroups [0, npair) = PAIR(pair) (column tile = workgroup index), then tiles [tile0, tile0 + ntile) of the table
 struct CiLaunch {
-    CiJob job[3];
+    int32_t pair, npair, tile0, ntile;
 };
 
-#if defined(__HIPCC__)
-#define CI_HD __host__ __device__
-#else
-#define CI_HD
-#endif
-
-// ---- tile enumerations (shared by the planner, the kernels and the simulator) -------------------------------------
-// SMALL: 64 x 64 tiles that cover the live region exactly.  Block row b has (Np + wlim) / 64 - b tiles.
-CI_HD inline int ci_small_ntiles(int Np, int r0, int r1, int wlim) {
-    const int tot = (Np + wlim) / 64;
-    int n = 0;
-    for (int b = r0 / 64; b < r1 / 64; ++b) n += tot - b;
-    return n;
-}
-CI_HD inline void ci_small_decode(int Np, int r0, int wlim, int t, int *row0, int *col0) {
-    const int tot = (Np + wlim) / 64;
-    int b = r0 / 64;
-    while (t >= tot - b) { t -= tot - b; ++b; }
-    *row0 = 64 * b;
-    *col0 = 64 * (b + t);
-}
-// BIG: 128 x 128 tiles on 128-aligned columns of S; row tile i starts at r0 + 128 i (r0 a multiple of 64); stores are
-// masked to the live region (64-granular), rows to r1.
-CI_HD inline int ci_big_ncol(int Np, int rr, int wlim) {
-    return (Np + (wlim + 127) / 128 * 128 - rr / 128 * 128) / 128;
-}
-CI_HD inline int ci_big_ntiles(int Np, int r0, int r1, int wlim) {
-    int n = 0;
-    for (int rr = r0; rr < r1; rr += 128) n += ci_big_ncol(Np, rr, wlim);
-    return n;
-}
-CI_HD inline void ci_big_decode(int Np, int r0, int wlim, int t, int *row0, int *col0) {
-    int rr = r0;
-    for (;;) {
-        const int nc = ci_big_ncol(Np, rr, wlim);
-        if (t < nc) break;
-        t -= nc;
-        rr += 128;
-    }
-    *row0 = rr;
-    *col0 = rr / 128 * 128 + 128 * t;
-}
-// PAIR(p): one workgroup per 64 live columns of the pair's rows: (Np - 128 (p + 1)) / 64 of A, 128 p / 64 of W, and the
-// two column blocks of W's own diagonal block = Np / 64 for every p.
-CI_HD inline int ci_pair_ntiles(int Np) { return Np / 64; }
+struct CiPlan {
+    std::vector<CiLaunch> launches;
+    std::vector<CiTile> tiles;
+};
 
 struct CiPlanOptions {
-    int near_big_from;  // NEAR goes to 128 x 128 tiles when it has more than this many 64 x 64 tiles
+    int win;       // targets p+1 .. p+win are kept up to date with every finished pair
+    int far_k;     // rank of the updates of the targets beyond the window (multiple of 128)
+    int far_kind;  // CI_UPD_BIG or CI_UPD_BIG256 (pairs of targets with equal history) for them
+    int defer;     // 1: the farther half of a FAR wave waits for the next launch
 };
 
 inline CiPlanOptions ci_default_options(int Np) {
     (void)Np;
     CiPlanOptions o;
-    o.near_big_from = 1 << 30;
+    o.win = 2;
+    o.far_k = 256;
+    o.far_kind = CI_UPD_BIG;
+    o.defer = 1;
     return o;
 }
 
-inline CiJob ci_upd_job(int kind, int Np, int k0, int K, int r0, int r1, int wlim) {
-    CiJob u = {};
-    u.kind = kind;
-    u.k0 = k0; u.K = K; u.r0 = r0; u.r1 = r1; u.wlim = wlim; u.t0 = 0;
-    u.nblk = (kind == CI_UPD_SMALL) ? ci_small_ntiles(Np, r0, r1, wlim) : ci_big_ntiles(Np, r0, r1, wlim);
-    return u;
+inline bool ci_options_ok(const CiPlanOptions &o) {
+    return o.win >= 1 && o.win <= 64 && o.far_k >= 128 && o.far_k <= 1024 && o.far_k % 128 == 0 &&
+           (o.far_kind == CI_UPD_BIG || o.far_kind == CI_UPD_BIG256) && (o.defer == 0 || o.defer == 1);
 }
 
-// Per pair p: NEAR(p) brings the pair's rows up to date with pair p-1 (the older pairs reached them as FAR fillers),
-// then PAIR(p) runs with the FAR tiles of pair p-1 (its contribution to every row beyond pair p) as filler workgroups.
-inline std::vector<CiLaunch> ci_plan(int Np, const CiPlanOptions &o) {
-    std::vector<CiLaunch> out;
-    const int np = Np / 128;
-    for (int p = 0; p < np; ++p) {
-        if (p > 0) {  // NEAR: rows of pair p  -=  contribution of pair p-1
-            CiLaunch l = {};
-            const int nsmall = ci_small_ntiles(Np, 128 * p, 128 * p + 128, 128 * p);
-            l.job[0] = ci_upd_job(nsmall > o.near_big_from ? CI_UPD_BIG : CI_UPD_SMALL, Np, 128 * (p - 1), 128, 128 * p,
-                                  128 * p + 128, 128 * p);
-            out.push_back(l);
-        }
-        CiLaunch l = {};
-        l.job[0].kind = CI_PAIR;
-        l.job[0].j = p;
-        l.job[0].nblk = ci_pair_ntiles(Np);
-        // FAR of pair p-1: rows beyond pair p (which NEAR(p) has just served): reads rows of pair p-1 (final), writes
-        // rows >= 128 (p + 1) - nothing PAIR(p) touches
-        if (p > 0 && 128 * (p + 1) < Np) l.job[2] = ci_upd_job(CI_UPD_BIG, Np, 128 * (p - 1), 128, 128 * (p + 1), Np, 128 * p);
-        out.push_back(l);
+// opt: NULL or int32[4] {win, far_k, far_kind, defer + 1}; 0 keeps the default
+inline CiPlanOptions ci_options_from(int Np, const int32_t *opt) {
+    CiPlanOptions o = ci_default_options(Np);
+    if (opt) {
+        if (opt[0] > 0) o.win = opt[0];
+        if (opt[1] > 0) o.far_k = opt[1];
+        if (opt[2] > 0) o.far_kind = opt[2];
+        if (opt[3] > 0) o.defer = opt[3] - 1;
     }
-    return out;
+    return o;
+}
+
+// PAIR(p): one workgroup per 64 live columns of the pair's rows: (Np - 128 (p + 1)) / 64 of A, 128 p / 64 of W, and the
+// two column blocks of W's own diagonal block = Np / 64 for every p.
+inline int ci_pair_ntiles(int Np) { return Np / 64; }
+
+// tiles of one update: target rows [row0, row0 + rows), sources [k0, k0 + K)
+inline void ci_emit_update(std::vector<CiTile> &out, int kind, int Np, int row0, int rows, int k0, int K) {
+    const int wlim = k0 + K;  // W columns beyond the sources' own extent are zero in the source rows
+    if (kind == CI_UPD_SMALL) {
+        for (int b = row0 / 64; b < (row0 + rows) / 64; ++b)
+            for (int c = 64 * b; c < Np + wlim; c += 64) out.push_back(CiTile{kind, k0, K, 64 * b, c, row0 + rows, wlim, 0});
+        return;
+    }
+    const int th = (kind == CI_UPD_BIG256) ? 256 : 128;
+    for (int rr = row0; rr < row0 + rows; rr += th)
+        for (int c = rr / 128 * 128; c < Np + (wlim + 127) / 128 * 128; c += 128)
+            out.push_back(CiTile{kind, k0, K, rr, c, row0 + rows, wlim, 0});
+}
+
+inline CiPlan ci_plan(int Np, const CiPlanOptions &o) {
+    CiPlan P;
+    const int np = Np / 128;
+    std::vector<int> applied(np, 0);
+    for (int p = 0; p < np; ++p) {
+        if (p > 0) {  // NEAR: whatever pair p still lacks (128 rows when the fillers kept up)
+            CiLaunch l = {-1, 0, (int)P.tiles.size(), 0};
+            ci_emit_update(P.tiles, CI_UPD_SMALL, Np, 128 * p, 128, applied[p], 128 * p - applied[p]);
+            applied[p] = 128 * p;
+            l.ntile = (int)P.tiles.size() - l.tile0;
+            P.launches.push_back(l);
+        }
+        CiLaunch l = {p, ci_pair_ntiles(Np), (int)P.tiles.size(), 0};
+        const int fin = 128 * p;  // source rows below this are final when this launch starts
+        // FAR first (long tiles first): targets beyond the window, up to the last multiple of far_k
+        const int qb = fin / o.far_k * o.far_k;
+        std::vector<int> far;
+        for (int t = p + 1 + o.win; t < np; ++t)
+            if (qb - applied[t] >= o.far_k) far.push_back(t);
+        size_t take = far.size();
+        if (o.defer && fin == qb && far.size() > 4) {
+            // a fresh wave (the launch right after a far_k boundary): the nearer targets now, the farther ones with the
+            // next launch; cost of a target ~ its live width
+            int64_t tot = 0, acc = 0;
+            for (int t : far) tot += 2 * Np - 128 * t;
+            take = 0;
+            while (take < far.size() && 2 * acc < tot) acc += 2 * Np - 128 * far[take++];
+        }
+        for (size_t i = 0; i < take; ++i) {
+            const int t = far[i];
+            const bool pair_ok = o.far_kind == CI_UPD_BIG256 && i + 1 < take && far[i + 1] == t + 1 &&
+                                 applied[t + 1] == applied[t];
+            if (pair_ok) {
+                ci_emit_update(P.tiles, CI_UPD_BIG256, Np, 128 * t, 256, applied[t], qb - applied[t]);
+                applied[t] = applied[t + 1] = qb;
+                ++i;
+            } else {
+                ci_emit_update(P.tiles, CI_UPD_BIG, Np, 128 * t, 128, applied[t], qb - applied[t]);
+                applied[t] = qb;
+            }
+        }
+        // WINDOW: the next targets, fully up to date
+        for (int t = p + 1; t <= p + o.win && t < np; ++t) {
+            if (fin - applied[t] >= 128) {
+                ci_emit_update(P.tiles, CI_UPD_BIG, Np, 128 * t, 128, applied[t], fin - applied[t]);
+                applied[t] = fin;
+            }
+        }
+        l.ntile = (int)P.tiles.size() - l.tile0;
+        P.launches.push_back(l);
+    }
+    return P;
 }

@@ -7,24 +7,21 @@ import numpy as np
 
 from bayesian_optimisation_amd import _lib
 
-NONE, PAIR, SMALL, BIG = 0, 1, 2, 3
+SMALL, BIG, BIG256 = 2, 3, 4
+TILE_ROWS = {SMALL: 64, BIG: 128, BIG256: 256}
 
 
 def get_plan(Np, opt=None):
+    """(launches [n x 4]: pair, npair, tile0, ntile;  tiles [m x 8]: kind, k0, K, row0, col0, r1, wlim, 0)"""
     lib = _lib.load()
-    o = (C.c_int32 * 4)(*(opt or [0, 0, 0, 0]))
-    words = lib.gpbo_cholinv_plan(Np, C.cast(o, C.c_void_p), None, 0)
-    assert words > 0 and words % 27 == 0
-    buf = (C.c_int32 * words)()
-    assert lib.gpbo_cholinv_plan(Np, C.cast(o, C.c_void_p), C.cast(buf, C.c_void_p), words) == words
-    return np.frombuffer(buf, dtype=np.int32).reshape(-1, 3, 9).copy()
-
-
-def tile_of(kind, Np, r0, wlim, t):
-    lib = _lib.load()
-    r, c = C.c_int32(), C.c_int32()
-    assert lib.gpbo_cholinv_tile(kind, Np, r0, wlim, t, C.byref(r), C.byref(c)) == 0
-    return r.value, c.value
+    o = (C.c_int32 * 5)(*((opt or [0, 0, 0, 0]) + [0])[:5])
+    nl, nt = C.c_int64(0), C.c_int64(0)
+    assert lib.gpbo_cholinv_plan(Np, C.cast(o, C.c_void_p), C.byref(nl), C.byref(nt), None, None) == 0
+    L = np.zeros((nl.value, 4), dtype=np.int32)
+    T = np.zeros((max(nt.value, 1), 8), dtype=np.int32)
+    assert lib.gpbo_cholinv_plan(Np, C.cast(o, C.c_void_p), C.byref(nl), C.byref(nt), L.ctypes.data_as(C.c_void_p),
+                                 T.ctypes.data_as(C.c_void_p)) == 0
+    return L, T[:nt.value]
 
 
 class Tracker:
@@ -49,76 +46,78 @@ class Tracker:
             assert not bad.any(), f"tile {tid} reads a block that tile {w[bad][0]} of the same launch writes"
 
 
-def run_plan(S, Np, plan, reads_tile_wide=True):
-    """S: [Np x 2Np] = [A | 0].  Executes the plan in place.  Writes of a launch are applied after all its tiles have been
-    computed from the state before the launch (what concurrent workgroups may or may not see is excluded by the tracker)."""
+def run_tile(S, Np, tile, tr, tile_id, pending):
+    """The semantics of one update workgroup (csrc/cholinv.hip: upd_small / upd_big)."""
+    kind, k0, K, row0, col0, r1, wlim, _ = (int(v) for v in tile)
+    H = TILE_ROWS[kind]
+    Wd = 64 if kind == SMALL else 128
+    assert K >= (32 if kind == SMALL else 128) and K % 32 == 0 and k0 + K <= row0 and col0 % Wd == 0
+    assert col0 + Wd <= 2 * Np and row0 + H <= 2 * Np and r1 <= Np
+    A = S[k0:k0 + K, row0:row0 + H]      # may run into the W half: in bounds, masked below
+    B = S[k0:k0 + K, col0:col0 + Wd]
+    tr.read(tile_id, k0, k0 + K, row0, row0 + H)
+    tr.read(tile_id, k0, k0 + K, col0, col0 + Wd)
+    P = A.T @ B
+    for rb in range(H // 64):
+        rr = row0 + 64 * rb
+        if rr >= r1:
+            continue
+        for cb in range(Wd // 64):
+            cc = col0 + 64 * cb
+            live = (cc >= rr) if cc < Np else (cc < Np + wlim)
+            if kind == SMALL:
+                assert live
+            if live:
+                pending.append((rr, cc, S[rr:rr + 64, cc:cc + 64] - P[64 * rb:64 * rb + 64, 64 * cb:64 * cb + 64]))
+                tr.write(tile_id, rr, cc)
+
+
+def run_pair(S, Np, p, npair, tr, tile_id, pending):
+    """The semantics of the PAIR workgroups of pair p (csrc/cholinv.hip: pair_body)."""
+    r0p = 128 * p
+    D = S[r0p:r0p + 128, r0p:r0p + 128]
+    D = np.tril(D) + np.tril(D, -1).T
+    D[:64, 64:] = S[r0p:r0p + 64, r0p + 64:r0p + 128]  # the kernel reads A12 from the upper block
+    D[64:, :64] = D[:64, 64:].T
+    L = np.linalg.cholesky(D)
+    Linv = np.tril(np.linalg.solve(L, np.eye(128)))
+    nA = (Np - (r0p + 128)) // 64
+    assert npair == Np // 64
+    for pt in range(npair):
+        tile_id += 1
+        c0 = r0p + 128 + 64 * pt if pt < nA else Np + 64 * (pt - nA)
+        assert c0 + 64 <= 2 * Np
+        tr.read(tile_id, r0p, r0p + 128, r0p, r0p + 128)
+        ident = c0 >= Np and c0 - Np >= r0p
+        if ident:
+            X = np.zeros((128, 64))
+            blk = (c0 - Np - r0p) // 64
+            X[64 * blk:64 * blk + 64, :] = np.eye(64)
+        else:
+            X = S[r0p:r0p + 128, c0:c0 + 64]
+            tr.read(tile_id, r0p, r0p + 128, c0, c0 + 64)
+        Y = Linv @ X
+        for h in range(2):
+            pending.append((r0p + 64 * h, c0, Y[64 * h:64 * h + 64]))
+            tr.write(tile_id, r0p + 64 * h, c0)
+    return tile_id
+
+
+def run_plan(S, Np, plan, first=0, count=None):
+    """S: [Np x 2Np] = [A | 0].  Executes launches [first, first + count) of the plan in place.  Writes of a launch are
+    applied after all its tiles have been computed from the state before the launch (what concurrent workgroups may or
+    may not see is excluded by the tracker)."""
+    L, T = plan
     tile_id = 0
-    for launch in plan:
+    last = len(L) if count is None else first + count
+    for pair, npair, tile0, ntile in L[first:last]:
         tr = Tracker(Np)
         pending = []
-        for kind, nblk, j, k0, K, r0, r1, wlim, t0 in launch:
-            if kind == NONE or nblk == 0:
-                continue
-            if kind == PAIR:
-                r0p = 128 * j
-                D = S[r0p:r0p + 128, r0p:r0p + 128]
-                D = np.tril(D) + np.tril(D, -1).T
-                D[:64, 64:] = S[r0p:r0p + 64, r0p + 64:r0p + 128]  # the kernel reads A12 from the upper block
-                D[64:, :64] = D[:64, 64:].T
-                L = np.linalg.cholesky(D)
-                Linv = np.tril(np.linalg.solve(L, np.eye(128)))
-                nA = (Np - (r0p + 128)) // 64
-                assert nblk == Np // 64
-                for pt in range(nblk):
-                    tile_id += 1
-                    c0 = r0p + 128 + 64 * pt if pt < nA else Np + 64 * (pt - nA)
-                    assert c0 + 64 <= 2 * Np
-                    tr.read(tile_id, r0p, r0p + 128, r0p, r0p + 128)
-                    ident = c0 >= Np and c0 - Np >= r0p
-                    if ident:
-                        X = np.zeros((128, 64))
-                        blk = (c0 - Np - r0p) // 64
-                        X[64 * blk:64 * blk + 64, :] = np.eye(64)
-                    else:
-                        X = S[r0p:r0p + 128, c0:c0 + 64]
-                        tr.read(tile_id, r0p, r0p + 128, c0, c0 + 64)
-                    Y = Linv @ X
-                    for h in range(2):
-                        pending.append((r0p + 64 * h, c0, Y[64 * h:64 * h + 64]))
-                        tr.write(tile_id, r0p + 64 * h, c0)
-            elif kind == SMALL:
-                for t in range(nblk):
-                    tile_id += 1
-                    row0, col0 = tile_of(SMALL, Np, r0, wlim, t0 + t)
-                    assert r0 <= row0 < r1 and row0 <= col0 and col0 + 64 <= Np + wlim
-                    A = S[k0:k0 + K, row0:row0 + 64]
-                    B = S[k0:k0 + K, col0:col0 + 64]
-                    tr.read(tile_id, k0, k0 + K, row0, row0 + 64)
-                    tr.read(tile_id, k0, k0 + K, col0, col0 + 64)
-                    pending.append((row0, col0, S[row0:row0 + 64, col0:col0 + 64] - A.T @ B))
-                    tr.write(tile_id, row0, col0)
-            elif kind == BIG:
-                for t in range(nblk):
-                    tile_id += 1
-                    row0, col0 = tile_of(BIG, Np, r0, wlim, t0 + t)
-                    assert r0 <= row0 < r1 and col0 % 128 == 0 and col0 + 128 <= 2 * Np and row0 + 128 <= 2 * Np
-                    A = S[k0:k0 + K, row0:row0 + 128]      # may run into the W half: in bounds, masked below
-                    B = S[k0:k0 + K, col0:col0 + 128]
-                    tr.read(tile_id, k0, k0 + K, row0, row0 + 128)
-                    tr.read(tile_id, k0, k0 + K, col0, col0 + 128)
-                    P = A.T @ B
-                    for rb in range(2):
-                        rr = row0 + 64 * rb
-                        if rr >= r1:
-                            continue
-                        for cb in range(2):
-                            cc = col0 + 64 * cb
-                            live = (cc >= rr) if cc < Np else (cc < Np + wlim)
-                            if live:
-                                pending.append((rr, cc, S[rr:rr + 64, cc:cc + 64] - P[64 * rb:64 * rb + 64, 64 * cb:64 * cb + 64]))
-                                tr.write(tile_id, rr, cc)
-            else:
-                raise AssertionError(kind)
+        if npair > 0:
+            tile_id = run_pair(S, Np, int(pair), int(npair), tr, tile_id, pending)
+        for t in T[tile0:tile0 + ntile]:
+            tile_id += 1
+            run_tile(S, Np, t, tr, tile_id, pending)
         tr.check()
         for r, c, v in pending:
             S[r:r + 64, c:c + 64] = v

@@ -1,9 +1,9 @@
 """The launch plan of the fused Cholesky + inverse factor (csrc/cholinv_plan.h), executed on the CPU.
 
-libgpbo.so exports its plan as data (gpbo_cholinv_plan / gpbo_cholinv_tile: host code, no GPU).  This test runs every job
-of every launch with NumPy, tile by tile, with the semantics the HIP workgroups implement (csrc/cholinv.hip), and checks
+libgpbo.so exports its plan as data (gpbo_cholinv_plan: host code, no GPU).  This test runs every workgroup of every
+launch with NumPy, tile by tile, with the semantics the HIP workgroups implement (csrc/cholinv.hip), and checks
   * the result: W = inv(L) of LAPACK's Cholesky factor (what /root/reference/point_selector.py:89 gets from np.linalg.inv
-    is W^T W), for several sizes, group sizes and tile choices;
+    is W^T W), for several sizes, windows, far ranks and tile choices;
   * the schedule: inside one launch no tile reads a 64 x 64 block that another tile of the launch writes, and no two
     tiles write the same block - dependencies are carried by launch order alone, so this is what makes the GPU run
     race-free.
@@ -14,11 +14,13 @@ import numpy as np
 import pytest
 
 from bayesian_optimisation_amd import _lib
-from cholinv_sim import BIG, PAIR, SMALL, get_plan, run_plan, spd
+from cholinv_sim import BIG, BIG256, SMALL, get_plan, run_plan, spd
+
+OPTS = [(128, None), (256, None), (384, None), (512, None), (640, [1, 128, 3, 1]), (896, None), (896, [2, 256, 4, 2]),
+        (1024, [3, 384, 3, 2]), (1152, [1, 256, 4, 1]), (1536, [2, 512, 4, 2]), (1664, None)]
 
 
-@pytest.mark.parametrize("Np,opt", [(128, None), (256, None), (384, None), (512, None), (640, [0, 1, 0, 0]), (896, None),
-                                    (1024, [0, 20, 0, 0])])
+@pytest.mark.parametrize("Np,opt", OPTS)
 def test_plan_executed_on_the_cpu_gives_the_inverse_factor(Np, opt):
     A = spd(Np, Np)
     S = np.zeros((Np, 2 * Np))
@@ -41,14 +43,24 @@ def test_plan_executed_on_the_cpu_gives_the_inverse_factor(Np, opt):
 
 @pytest.mark.parametrize("Np", [1024, 4096, 8192])
 def test_plan_shape_at_the_benchmark_sizes(Np):
-    """Every pair of block rows gets exactly one PAIR launch; workgroup counts stay inside one grid dimension."""
-    plan = get_plan(Np)
-    pairs = [int(l[0][2]) for l in plan if l[0][0] == PAIR]
+    """Every pair of block rows gets exactly one PAIR launch, preceded (but for the first) by a NEAR launch of rank 128;
+    every tile is well formed; the far updates have rank 256; workgroup counts stay inside one grid dimension."""
+    L, T = get_plan(Np)
+    pairs = [int(l[0]) for l in L if l[1] > 0]
     assert pairs == list(range(Np // 128))
-    for l in plan:
-        assert 0 < int(l[:, 1].sum()) < 2 ** 31
-        for kind, nblk, j, k0, K, r0, r1, wlim, t0 in l:
-            if kind in (SMALL, BIG):
-                assert K % 32 == 0 and 0 < K <= 512 and r0 % 64 == 0 and r1 % 64 == 0 and k0 + K <= r0 and wlim <= r0
+    assert (L[:, 1] + L[:, 3] > 0).all() and (L[:, 1] + L[:, 3] < 2 ** 20).all()
+    assert int(L[-1, 2] + L[-1, 3]) == len(T)
+    assert set(np.unique(T[:, 0])) <= {SMALL, BIG, BIG256}
+    assert (T[:, 2] >= 128).all() and (T[:, 2] % 128 == 0).all() and (T[:, 1] + T[:, 2] <= T[:, 3]).all()
+    near = [T[l[2]:l[2] + l[3]] for l in L if l[1] == 0]
+    assert len(near) == Np // 128 - 1 and all((n[:, 0] == SMALL).all() and (n[:, 2] == 128).all() for n in near)
+    flops = (T[:, 2].astype(np.int64) * np.where(T[:, 0] == SMALL, 64 * 64, np.where(T[:, 0] == BIG, 128 * 128, 256 * 128))).sum()
+    big = T[T[:, 0] != SMALL]
+    far_share = (big[big[:, 2] >= 256][:, 2].astype(np.int64) * 128 * 128).sum() / max(flops, 1)
+    if Np >= 4096:
+        assert far_share > 0.7, far_share  # most of the work moves 16 bytes of target per >= 512 flop
     lib = _lib.load()
-    assert lib.gpbo_cholinv_plan(Np + 64, None, None, 0) == -1
+    n1, n2 = C.c_int64(0), C.c_int64(0)
+    assert lib.gpbo_cholinv_plan(Np + 64, None, C.byref(n1), C.byref(n2), None, None) == -1
+    bad = (C.c_int32 * 5)(0, 200, 0, 0, 0)  # far rank not a multiple of 128
+    assert lib.gpbo_cholinv_plan(Np, C.cast(bad, C.c_void_p), C.byref(n1), C.byref(n2), None, None) == -1

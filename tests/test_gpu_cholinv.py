@@ -1,5 +1,5 @@
 """The fused Cholesky + inverse factor (gpbo_cholinv_f64, csrc/cholinv.hip) on the MI355X against LAPACK and against the
-CPU execution of the same launch plan (tests/test_cholinv_plan_cpu.py), launch by launch.
+CPU execution of the same launch plan (tests/cholinv_sim.py), launch by launch and tile kind by tile kind.
 Replaces np.linalg.inv(cov_meas) of /root/reference/point_selector.py:89."""
 import ctypes as C
 
@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from bayesian_optimisation_amd import _lib  # noqa: E402
-from cholinv_sim import get_plan, run_plan, spd  # noqa: E402
+from cholinv_sim import BIG, BIG256, SMALL, Tracker, get_plan, run_plan, run_tile, spd  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -42,24 +42,58 @@ def run_gpu(env, A, opt=None):
     return dS.cpu().numpy(), int(info.item())
 
 
-@pytest.mark.parametrize("Np,opt", [(256, [0, 0, 0, 0]), (512, [0, 1, 0, 0]), (640, [0, 0, 0, 0])])
+@pytest.mark.parametrize("Np,opt", [(256, [0, 0, 0, 0]), (640, [1, 128, 3, 1]), (896, [2, 256, 4, 2]), (1152, [2, 256, 3, 2])])
 def test_every_launch_matches_the_cpu_execution_of_the_plan(env, Np, opt):
     A = spd(Np, 100 + Np)
     plan = get_plan(Np, opt)
     S = np.zeros((Np, 2 * Np))
     S[:, :Np] = A
-    for n in range(1, len(plan) + 1):
-        run_plan(S, Np, plan[n - 1:n])
+    for n in range(1, len(plan[0]) + 1):
+        run_plan(S, Np, plan, first=n - 1, count=1)
         got, info = run_gpu(env, A, opt + [n])
         assert info == 0
-        # live data only: blocks the CPU execution has written so far, plus everything still untouched, must agree;
-        # the dead lower block triangle of the left half is never written by either
         err = np.max(np.abs(got - S))
-        assert err <= 1e-9, f"launch {n} of {len(plan)} ({plan[n - 1][:, 0]}): max |diff| {err}"
+        assert err <= 1e-9, f"launch {n} of {len(plan[0])} ({plan[0][n - 1]}): max |diff| {err}"
 
 
-@pytest.mark.parametrize("Np,opt", [(128, None), (384, None), (1024, None), (1024, [0, 50, 0, 0]), (2176, None),
-                                    (2176, [0, 1, 0, 0]), (4096, None), (4224, None)])
+@pytest.mark.parametrize("kind,K", [(SMALL, 32), (SMALL, 128), (SMALL, 352), (BIG, 128), (BIG, 400 // 16 * 16), (BIG256, 128),
+                                    (BIG256, 512)])
+def test_one_tile_kind_against_numpy(env, kind, K):
+    """A handful of tiles of one kind with sources [k0, k0 + K): live masks, ragged last row tile, W-side columns."""
+    K = K // 32 * 32
+    t = env.torch
+    Np = 1152
+    rng = np.random.default_rng(K + kind)
+    S = rng.standard_normal((Np, 2 * Np))
+    k0 = 64
+    r0 = 640 if kind != SMALL else 576
+    H = {SMALL: 64, BIG: 128, BIG256: 256}[kind]
+    wlim = (k0 + K + 63) // 64 * 64
+    tiles = []
+    if kind == SMALL:
+        for c in sorted({r0, r0 + 64, Np - 64, Np, Np + wlim - 64}):
+            tiles.append([kind, k0, K, r0, c, r0 + 64, wlim, 0])
+    else:
+        for row0 in (r0, Np - 128):  # the second one is ragged for 256-row tiles
+            for c in sorted({row0, min(row0 + 128, Np - 128), Np - 128, Np, Np + (wlim + 127) // 128 * 128 - 128}):
+                tiles.append([kind, k0, K, row0, c, Np, wlim, 0])
+    T = np.array(tiles, dtype=np.int32)
+    ref = S.copy()
+    tr, pending = Tracker(Np), []
+    for i, tl in enumerate(T):
+        run_tile(ref, Np, tl, tr, i + 1, pending)
+    for r, c, v in pending:
+        ref[r:r + 64, c:c + 64] = v
+    dS = t.from_numpy(S).to(env.dev)
+    info = t.zeros(1, dtype=t.int32, device=env.dev)
+    st = env.lib.gpbo_cholinv_tiles_f64(env.p(dS), 2 * Np, Np, env.p(info), -1, T.ctypes.data_as(C.c_void_p), len(T), 1, env.stream())
+    assert st == 0
+    got = dS.cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 1e-11 * K
+
+
+@pytest.mark.parametrize("Np,opt", [(128, None), (384, None), (1024, None), (1024, [1, 128, 3, 1]), (2176, None),
+                                    (2176, [3, 512, 4, 2]), (4096, None), (4224, [2, 256, 4, 2])])
 def test_inverse_factor_vs_lapack(env, Np, opt):
     A = spd(Np, Np)
     got, info = run_gpu(env, A, (opt + [0]) if opt else None)
