@@ -34,7 +34,7 @@ SIGNATURES = {
     "gpbo_trtri_f64": (C.c_int, [_p, _p, _i64, _p, _p, _p]),
     "gpbo_cholinv_f64": (C.c_int, [_p, _i64, _i64, _p, _p, _p]),
     "gpbo_cholinv_plan": (C.c_int, [_i64, _p, _p, _p, _p, _p]),
-    "gpbo_cholinv_tiles_f64": (C.c_int, [_p, _i64, _i64, _p, _i32, _p, _i64, _i32, _p]),
+    "gpbo_cholinv_tiles_f64": (C.c_int, [_p, _i64, _i64, _p, _i32, _p, _i64, _i32, _i32, _p]),
     "gpbo_alpha_f64": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p]),
     "gpbo_factorise_workspace_bytes": (_i64, [_i64]),
     "gpbo_factorise_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _f64, _f64, _i64, _p, _p, _p, _p, _p, _i64, _p]),

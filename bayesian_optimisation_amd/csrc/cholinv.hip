@@ -82,7 +82,15 @@ struct CiArgs {
 // MFMAs between two barriers: it serves the updates that have few tiles.
 // ---------------------------------------------------------------------------------------------------------------
 template <int MI>
-__device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int Np, const CiTile &u, double *smem) {
+__device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int Np, const CiTile &u, double *smem,
+                                        unsigned long long *stamps) {
+#ifdef GPBO_DIAGNOSTICS
+    int nst = 0;
+#define CI_TSTAMP() do { if (stamps && threadIdx.x == 0) stamps[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CI_TSTAMP() do { } while (0)
+#endif
+    CI_TSTAMP();
     constexpr int BM = 64 * MI;
     constexpr int LDA = BM + 16;                  // A tile row stride (doubles)
     constexpr int STG = BKT * (LDA + LDT);        // doubles per stage
@@ -134,6 +142,7 @@ __device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int 
     if (pk < nk) stage_next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    CI_TSTAMP();
 
     double a0[MI], b0[4], a1[MI], b1[4];
     auto lds_frag = [&](double (&af)[MI], double (&bf)[4], int buf, int kk) {
@@ -225,7 +234,9 @@ __device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int 
         k_tile(std::integral_constant<int, 3>{});
         k_tile(std::integral_constant<int, 4>{});
     }
+    CI_TSTAMP();
     for (int kt = MI + 1; kt < nk; ++kt) k_tile(std::integral_constant<int, -1>{});
+    CI_TSTAMP();
     // out = C - sum = -acc on the live part of the tile (masks are uniform per 16 x 16 MFMA tile: 64-granular)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -237,6 +248,12 @@ __device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int 
                 for (int r = 0; r < 4; ++r) cp[(int64_t)(4 * r) * ld] = -acc[mi][ni][r];
             }
         }
+    CI_TSTAMP();
+#ifdef GPBO_DIAGNOSTICS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    CI_TSTAMP();
+#undef CI_TSTAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -305,9 +322,12 @@ __device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, co
 //   (3) the trailing 16 x 16 blocks are updated on the matrix cores - wave 0 takes the next diagonal sub-block first
 //       and goes straight on to (1) while the other seven waves do the rest.
 // All 8 waves call it (barriers inside); the caller has synchronised after filling Mtop / Mbot.
+// has_bg: waves 4..7 do not help with (3) but run bg(s) there, s = 0, 1, 2 - work of the caller that touches neither Mtop
+// nor Mbot and contains no barrier (wave 0's elimination is ~3000 cycles during which they would otherwise wait).
 // Returns (wave 0 only) the 1-based column of the first non-positive / non-finite pivot, or 0.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int lane) {
+template <typename BG>
+__device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int lane, bool has_bg, BG &&bg) {
     const int l15 = lane & 15, l4 = lane >> 4;
     auto rowp = [&](int R) { return (R < NB) ? Mtop + R * LDM : Mbot + (R - NB) * LDM; };  // row R of the stack
     int first_bad = 0;
@@ -370,16 +390,19 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
         if (w == 0) {  // (3)
             trail(PB * (s + 1), s + 1, s);
             eliminate(s + 1);
+        } else if (has_bg && w >= 4) {
+            bg(s);
         } else {
+            const int nh = has_bg ? 3 : 7;  // helper waves 1 .. nh
             int q = 0;
             for (int c = s + 1; c < NS; ++c) {
                 for (int R = c; R < NS; ++R) {
                     if (R == s + 1 && c == s + 1) continue;
-                    if (q % 7 == w - 1) trail(PB * R, c, s);
+                    if (q % nh == w - 1) trail(PB * R, c, s);
                     ++q;
                 }
                 for (int m = 0; m <= s; ++m) {
-                    if (q % 7 == w - 1) trail(NB + PB * m, c, s);
+                    if (q % nh == w - 1) trail(NB + PB * m, c, s);
                     ++q;
                 }
             }
@@ -399,8 +422,8 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
 // and then applies inv(L) = [inv(L11) 0; -inv(L22) L21 inv(L11)  inv(L22)] to its own 64 columns X = [X1; X2] of the
 // two block rows as three products that never leave the registers:
 //     X1' = inv(L11) X1 ;   X2 <- X2 - R12^T X1' ;   X2' = inv(L22) X2
-// (waves 0..3, one 16-column strip each: the fp64 16x16x4 MFMA's C layout - row = lane/16 + 4 r - IS the B operand
-// layout of the next product, k = lane/16 within k step r).  W's diagonal block of the pair is the same computation
+// (waves 4..7, one 16-column strip each: the fp64 16x16x4 MFMA's C layout - row = lane/16 + 4 r - IS the B operand
+// layout of the next product, k = lane/16 within k step r; the first two products run beside the second elimination).  W's diagonal block of the pair is the same computation
 // on X = I.  The pair's diagonal block of A is left alone: nothing reads it later, other workgroups are reading it now.
 // LDS: four [64][LDM] blocks - B0: D11 -> L11, then D22 -> L22;  B1: I -> inv(L11)^T (kept);  B2: I -> inv(L22)^T;
 // B3: A12 -> R12.
@@ -424,124 +447,197 @@ __device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, in
     const int c0 = (pt < nA) ? r0 + 128 + 64 * pt : Np + 64 * (pt - nA);
     const int wid_blk = (c0 >= Np) ? (c0 - Np - r0) / 64 : -1;  // 0 / 1: column block of W's diagonal 128 x 128 block
     const bool ident = c0 >= Np && c0 - Np >= r0;
+    const double *Dg = S + (int64_t)r0 * ld + r0;
 
-    // X strip of this wave (waves 0..3): B-operand fragments straight from global memory, in flight during phase 1
+    // Everything the workgroup reads from global memory is requested here, in the order it is needed: D11 and A12
+    // (eight elements per thread each: registers first, LDS after - one round trip, not eight), the wave's tiles of D22
+    // in MFMA C layout, and the X strip of waves 4..7 as B-operand fragments (consumed after the first elimination).
+    double dv[8], av[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + 512 * i, r = e >> 6, c = e & 63;
+        dv[i] = Dg[(int64_t)r * ld + c];
+        av[i] = Dg[(int64_t)r * ld + 64 + c];
+    }
+    // Schur step tiles: the ten lower 16 x 16 tiles of D22, tile w for every wave, tiles 8 / 9 for waves 0 / 1 too
+    auto schur_tile = [](int i, int *mi, int *ni) {  // i -> (mi, ni), mi >= ni, row-major over the lower triangle
+        int m = 0;
+        while ((m + 1) * (m + 2) / 2 <= i) ++m;
+        *mi = m;
+        *ni = i - m * (m + 1) / 2;
+    };
+    d4_t d22[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int mi, ni;
+        schur_tile(q ? 8 + (w & 1) : w, &mi, &ni);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d22[q][r] = Dg[(int64_t)(64 + 16 * mi + l4 + 4 * r) * ld + 64 + 16 * ni + l15];
+    }
+    const int xs = w & 3;  // strip of the X waves (4..7)
     double x1[16], x2[16];
-    if (w < 4) {
-        const double *xp = S + (int64_t)(r0 + l4) * ld + c0 + 16 * w + l15;
+    if (w >= 4) {
+        const double *xp = S + (int64_t)(r0 + l4) * ld + c0 + 16 * xs + l15;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             if (!ident) {
                 x1[s] = xp[(int64_t)(4 * s) * ld];
                 x2[s] = xp[(int64_t)(64 + 4 * s) * ld];
-            } else {  // X = [I; 0] (column block 0) or [0; I] (column block 1): row 4 s + l4, column 16 w + l15
-                const double d = (4 * s + l4 == 16 * w + l15) ? 1.0 : 0.0;
+            } else {  // X = [I; 0] (column block 0) or [0; I] (column block 1): row 4 s + l4, column 16 xs + l15
+                const double d = (4 * s + l4 == 16 * xs + l15) ? 1.0 : 0.0;
                 x1[s] = (wid_blk == 0) ? d : 0.0;
                 x2[s] = (wid_blk == 1) ? d : 0.0;
             }
         }
     }
-    // D22 tiles of this wave in MFMA C layout (tiles 2 w, 2 w + 1 of the 4 x 4 tiles: row tile = t / 4, col tile = t % 4)
-    const double *Dg = S + (int64_t)r0 * ld + r0;
-    d4_t d22[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int t = 2 * w + q, mi = t >> 2, ni = t & 3;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d22[q][r] = Dg[(int64_t)(64 + 16 * mi + l4 + 4 * r) * ld + 64 + 16 * ni + l15];
-    }
-    for (int e = tid; e < NB * NB; e += 512) {
-        const int r = e >> 6, c = e & 63;
-        B0[r * LDM + c] = (c <= r) ? Dg[(int64_t)r * ld + c] : 0.0;
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + 512 * i, r = e >> 6, c = e & 63;
+        B0[r * LDM + c] = (c <= r) ? dv[i] : 0.0;
         B1[r * LDM + c] = (c == r) ? 1.0 : 0.0;
         B2[r * LDM + c] = (c == r) ? 1.0 : 0.0;
-        B3[r * LDM + c] = Dg[(int64_t)r * ld + 64 + c];
+        B3[r * LDM + c] = av[i];
     }
     __syncthreads();
     CI_STAMP();
-    const int bad1 = factor64(B0, B1, w, lane);   // ends with a barrier after the last panel step
+    const int bad1 = factor64(B0, B1, w, lane, false, [](int) {});   // ends with a barrier after the last panel step
     CI_STAMP();
-    // R12 = inv(L11) A12: inv(L11)[r][k] = B1[k][r], zero for k > r.  16 output tiles, two per wave; both of a wave's
-    // tiles are read completely before the barrier, written after it (in place in B3).
+    // R12 = inv(L11) A12: inv(L11)[r][k] = B1[k][r], zero for k > r.  Wave w: column tile w & 3 of the row tiles
+    // {w >> 2, 3 - (w >> 2)} (4 (mi + 1) k steps each: 20 per wave); read completely before the barrier, written after.
     {
-        d4_t acc[2];
+        const int ni = w & 3, mia = w >> 2, mib = 3 - mia;
+        // a dependent fp64 MFMA chain issues one instruction per ~2 pipe slots: every tile's sum is split over the parity
+        // of the k step (two chains per tile, four per wave), added at the end
+        d4_t acca = {0.0, 0.0, 0.0, 0.0}, accb = acca, acca2 = acca, accb2 = acca;
+        // fully unrolled with wave-uniform guards (mib > mia): the LDS reads of all k steps are in flight at once
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int t = 2 * w + q, mi = t >> 2, ni = t & 3;
-            acc[q] = d4_t{0.0, 0.0, 0.0, 0.0};
-            for (int ks = 0; ks < 4 * (mi + 1); ++ks) {
+        for (int ks = 0; ks < 16; ks += 2) {
+            if (ks < 4 * (mib + 1)) {
                 const int k = 4 * ks + l4;
-                acc[q] = mfma_f64_16x16x4(B1[k * LDM + 16 * mi + l15], B3[k * LDM + 16 * ni + l15], acc[q]);
+                const double bv = B3[k * LDM + 16 * ni + l15], bw = B3[(k + 4) * LDM + 16 * ni + l15];
+                accb = mfma_f64_16x16x4(B1[k * LDM + 16 * mib + l15], bv, accb);
+                accb2 = mfma_f64_16x16x4(B1[(k + 4) * LDM + 16 * mib + l15], bw, accb2);
+                if (ks < 4 * (mia + 1)) {
+                    acca = mfma_f64_16x16x4(B1[k * LDM + 16 * mia + l15], bv, acca);
+                    acca2 = mfma_f64_16x16x4(B1[(k + 4) * LDM + 16 * mia + l15], bw, acca2);
+                }
             }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int t = 2 * w + q, mi = t >> 2, ni = t & 3;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) B3[(16 * mi + l4 + 4 * r) * LDM + 16 * ni + l15] = acc[q][r];
-        }
-        __syncthreads();
-    }
-    // D22 -= R12^T R12 -> B0 (lower triangle; zeros above), B2 = I already
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int t = 2 * w + q, mi = t >> 2, ni = t & 3;
-        d4_t acc = d22[q];
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const int k = 4 * ks + l4;
-            acc = mfma_f64_16x16x4(-B3[k * LDM + 16 * mi + l15], B3[k * LDM + 16 * ni + l15], acc);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int rr = 16 * mi + l4 + 4 * r, cc = 16 * ni + l15;
-            B0[rr * LDM + cc] = (cc <= rr) ? acc[r] : 0.0;
+            acca[r] += acca2[r];
+            accb[r] += accb2[r];
         }
+        CI_STAMP();
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            B3[(16 * mia + l4 + 4 * r) * LDM + 16 * ni + l15] = acca[r];
+            B3[(16 * mib + l4 + 4 * r) * LDM + 16 * ni + l15] = accb[r];
+        }
+        __syncthreads();
+        CI_STAMP();
+    }
+    // D22 -= R12^T R12, lower tiles only -> B0 (the elimination reads nothing above the diagonal); B2 = I already
+    {
+        int mi0, ni0, mi1, ni1;
+        schur_tile(w, &mi0, &ni0);
+        schur_tile(8 + (w & 1), &mi1, &ni1);
+        const bool two = w < 2;
+        d4_t acc0 = d22[0], acc1 = d22[1], acc0b = {0.0, 0.0, 0.0, 0.0}, acc1b = acc0b;
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 2) {
+            const int k = 4 * ks + l4;
+            acc0 = mfma_f64_16x16x4(-B3[k * LDM + 16 * mi0 + l15], B3[k * LDM + 16 * ni0 + l15], acc0);
+            acc0b = mfma_f64_16x16x4(-B3[(k + 4) * LDM + 16 * mi0 + l15], B3[(k + 4) * LDM + 16 * ni0 + l15], acc0b);
+            if (two) {
+                acc1 = mfma_f64_16x16x4(-B3[k * LDM + 16 * mi1 + l15], B3[k * LDM + 16 * ni1 + l15], acc1);
+                acc1b = mfma_f64_16x16x4(-B3[(k + 4) * LDM + 16 * mi1 + l15], B3[(k + 4) * LDM + 16 * ni1 + l15], acc1b);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc0[r] += acc0b[r];
+            acc1[r] += acc1b[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * mi0 + l4 + 4 * r, cc = 16 * ni0 + l15;
+            B0[rr * LDM + cc] = (cc <= rr) ? acc0[r] : 0.0;
+            if (two) {
+                const int r2 = 16 * mi1 + l4 + 4 * r, c2 = 16 * ni1 + l15;
+                B0[r2 * LDM + c2] = (c2 <= r2) ? acc1[r] : 0.0;
+            }
+        }
+        // the strictly upper tiles of B0 still hold L11's zeros / entries: above the diagonal nothing is read
     }
     __syncthreads();
     CI_STAMP();
-    const int bad2 = factor64(B0, B2, w, lane);
+    // Second elimination, and beside it (waves 4..7, while wave 0 eliminates): X1' = inv(L11) X1, then
+    // X2 <- X2 - R12^T X1' in two halves - both only need B1 and B3, which the elimination does not touch.
+    double y1[16];
+    double *xp = S + (int64_t)(r0 + l4) * ld + c0 + 16 * xs + l15;
+    auto x_bg = [&](int s) {
+        if (s == 0) {
+            d4_t acc[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)  // the four row tiles are independent chains: k outside, tiles inside
+#pragma unroll
+                for (int mi = ks / 4; mi < 4; ++mi)
+                    acc[mi] = mfma_f64_16x16x4(B1[(4 * ks + l4) * LDM + 16 * mi + l15], x1[ks], acc[mi]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y1[4 * mi + r] = acc[mi][r];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xp[(int64_t)(4 * q) * ld] = y1[q];
+        } else {
+            const int m0 = 2 * (s - 1);  // s = 1: row tiles 0, 1;  s = 2: row tiles 2, 3
+            d4_t acc[2], accb[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+            if (s == 1) {
+                acc[0] = d4_t{x2[0], x2[1], x2[2], x2[3]};
+                acc[1] = d4_t{x2[4], x2[5], x2[6], x2[7]};
+            } else {
+                acc[0] = d4_t{x2[8], x2[9], x2[10], x2[11]};
+                acc[1] = d4_t{x2[12], x2[13], x2[14], x2[15]};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 16; ks += 2)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    acc[h] = mfma_f64_16x16x4(-B3[(4 * ks + l4) * LDM + 16 * (m0 + h) + l15], y1[ks], acc[h]);
+                    accb[h] = mfma_f64_16x16x4(-B3[(4 * ks + 4 + l4) * LDM + 16 * (m0 + h) + l15], y1[ks + 1], accb[h]);
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[h][r] += accb[h][r];
+            if (s == 1) {
+                x2[0] = acc[0][0]; x2[1] = acc[0][1]; x2[2] = acc[0][2]; x2[3] = acc[0][3];
+                x2[4] = acc[1][0]; x2[5] = acc[1][1]; x2[6] = acc[1][2]; x2[7] = acc[1][3];
+            } else {
+                x2[8] = acc[0][0]; x2[9] = acc[0][1]; x2[10] = acc[0][2]; x2[11] = acc[0][3];
+                x2[12] = acc[1][0]; x2[13] = acc[1][1]; x2[14] = acc[1][2]; x2[15] = acc[1][3];
+            }
+        }
+    };
+    const int bad2 = factor64(B0, B2, w, lane, true, x_bg);
     CI_STAMP();
     if (pt == 0 && tid == 0) {
         const int bad = bad1 ? r0 + bad1 : (bad2 ? r0 + 64 + bad2 : 0);
         if (bad) atomicCAS(info, 0, bad);
     }
-    if (w < 4) {
-        double *xp = S + (int64_t)(r0 + l4) * ld + c0 + 16 * w + l15;
-        double y1[16];
-        // X1' = inv(L11) X1
+    if (w >= 4) {  // X2' = inv(L22) X2
+        d4_t acc[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 4 * (mi + 1); ++ks)
-                acc = mfma_f64_16x16x4(B1[(4 * ks + l4) * LDM + 16 * mi + l15], x1[ks], acc);
+            for (int mi = ks / 4; mi < 4; ++mi)
+                acc[mi] = mfma_f64_16x16x4(B2[(4 * ks + l4) * LDM + 16 * mi + l15], x2[ks], acc[mi]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y1[4 * mi + r] = acc[r];
-        }
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) xp[(int64_t)(4 * s) * ld] = y1[s];
-        // X2 <- X2 - R12^T X1'  (L21[r][k] = R12[k][r])
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            d4_t acc = {x2[4 * mi], x2[4 * mi + 1], x2[4 * mi + 2], x2[4 * mi + 3]};
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks)
-                acc = mfma_f64_16x16x4(-B3[(4 * ks + l4) * LDM + 16 * mi + l15], y1[ks], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x2[4 * mi + r] = acc[r];
-        }
-        // X2' = inv(L22) X2
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4 * (mi + 1); ++ks)
-                acc = mfma_f64_16x16x4(B2[(4 * ks + l4) * LDM + 16 * mi + l15], x2[ks], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xp[(int64_t)(64 + 16 * mi + 4 * r) * ld] = acc[r];
-        }
+            for (int r = 0; r < 4; ++r) xp[(int64_t)(64 + 16 * mi + 4 * r) * ld] = acc[mi][r];
     }
     CI_STAMP();
 #undef CI_STAMP
@@ -554,10 +650,19 @@ __global__ __launch_bounds__(512) void cholinv_kernel(CiArgs a) {
         pair_body(a.S, a.ld, a.Np, a.l.pair, b, a.info, smem, a.stamps);
         return;
     }
-    const CiTile t = a.tab[a.l.tile0 + (b - a.l.npair)];  // wave-uniform: scalar loads
-    if (t.kind == CI_UPD_SMALL) upd_small(a.S, a.ld, t);
-    else if (t.kind == CI_UPD_BIG) upd_big<2>(a.S, a.ld, a.Np, t, smem);
-    else if (t.kind == CI_UPD_BIG256) upd_big<4>(a.S, a.ld, a.Np, t, smem);
+    const int first = (b - a.l.npair) * a.l.group;
+    const int last = (first + a.l.group < a.l.ntile) ? first + a.l.group : a.l.ntile;
+    for (int i = first; i < last; ++i) {
+        if (i > first) __syncthreads();  // the previous tile's last LDS reads are done before the ring is refilled
+        const CiTile t = a.tab[a.l.tile0 + i];  // wave-uniform: scalar loads
+        unsigned long long *ts = nullptr;
+#ifdef GPBO_DIAGNOSTICS
+        if (a.stamps && a.l.npair == 0) ts = a.stamps + 8 * (i & 1023);  // update-only launches: every tile
+#endif
+        if (t.kind == CI_UPD_SMALL) upd_small(a.S, a.ld, t);
+        else if (t.kind == CI_UPD_BIG) upd_big<2>(a.S, a.ld, a.Np, t, smem, ts);
+        else if (t.kind == CI_UPD_BIG256) upd_big<4>(a.S, a.ld, a.Np, t, smem, ts);
+    }
 }
 
 // U = W^T restricted to the upper triangle (W = the right half of S, lower triangular): 64x64 tiles through LDS.
@@ -595,10 +700,10 @@ struct DevPlan {
 
 static const DevPlan *plan_for(int Np, const CiPlanOptions &o) {
     static std::mutex mu;
-    static std::map<std::array<int, 6>, DevPlan *> cache;
+    static std::map<std::array<int, 7>, DevPlan *> cache;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    const std::array<int, 6> key = {dev, Np, o.win, o.far_k, o.far_kind, o.defer};
+    const std::array<int, 7> key = {dev, Np, o.win, o.far_k, o.far_kind, o.defer, o.group_from};
     std::lock_guard<std::mutex> g(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
@@ -625,7 +730,7 @@ static bool ci_sizes_ok(const double *S, int64_t ld, int64_t Np) {
 // S: [Np x ld] row-major, ld >= 2 Np, columns [0, Np) = the symmetric positive definite matrix, [Np, 2 Np) = zeros.
 // On return columns [Np, 2 Np) hold inv(L) (lower triangular); the upper block triangle of [0, Np) holds L^T except its
 // 128 x 128 diagonal blocks.  *info (cleared by the caller on this stream) receives the 1-based index of the first bad
-// pivot.  opt: NULL or int32[5] {win, far_k, far_kind, defer + 1, max_launches}, 0 = default.
+// pivot.  opt: NULL or int32[6] {win, far_k, far_kind, defer + 1, max_launches, group_from + 1}, 0 = default.
 int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int *opt, hipStream_t st) {
     if (!ci_sizes_ok(S, ld, Np) || !info) return GPBO_ERR_ARG;
     const CiPlanOptions o = ci_options_from((int)Np, opt);
@@ -650,7 +755,7 @@ int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int
     for (const CiLaunch &l : dp->plan.launches) {
         if (left-- <= 0) break;
         a.l = l;
-        const int nblk = l.npair + l.ntile;
+        const int nblk = ci_launch_blocks(l);
         if (nblk <= 0) continue;
 #ifdef GPBO_DIAGNOSTICS
         a.stamps = (want_stamps && l.npair > 0 && npair < 1024) ? dstamps + 8 * npair++ : nullptr;
@@ -663,11 +768,12 @@ int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int
         std::vector<unsigned long long> h(8 * npair);
         if (hipStreamSynchronize(st) != hipSuccess) return GPBO_ERR_LAUNCH;
         if (hipMemcpy(h.data(), dstamps, 8 * 8 * npair, hipMemcpyDeviceToHost) != hipSuccess) return GPBO_ERR_LAUNCH;
-        double sum[6] = {0, 0, 0, 0, 0, 0};
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int i = 0; i < npair; ++i)
-            for (int q = 0; q < 5; ++q) sum[q] += (double)(h[8 * i + q + 1] - h[8 * i + q]);
-        fprintf(stderr, "PAIR stamps (cycles, mean of %d): load %.0f  factor1 %.0f  r12+schur %.0f  factor2 %.0f  xops+store %.0f\n",
-                npair, sum[0] / npair, sum[1] / npair, sum[2] / npair, sum[3] / npair, sum[4] / npair);
+            for (int q = 0; q < 7; ++q) sum[q] += (double)(h[8 * i + q + 1] - h[8 * i + q]);
+        fprintf(stderr, "PAIR stamps (wave 0, cycles, mean of %d): load %.0f  factor1 %.0f  r12 products %.0f  r12 barrier+store %.0f  schur %.0f  "
+                "factor2 (+X1', X2 update) %.0f  end %.0f\n", npair, sum[0] / npair, sum[1] / npair, sum[2] / npair, sum[3] / npair,
+                sum[4] / npair, sum[5] / npair, sum[6] / npair);
     }
 #endif
     return GPBO_OK;
@@ -691,8 +797,8 @@ extern "C" int gpbo_cholinv_plan(int64_t Np, const int32_t *opt, int64_t *n_laun
         if (*n_launch < (int64_t)P.launches.size()) return GPBO_ERR_WORKSPACE;
         for (size_t i = 0; i < P.launches.size(); ++i) {
             const CiLaunch &l = P.launches[i];
-            const int32_t v[4] = {l.pair, l.npair, l.tile0, l.ntile};
-            for (int q = 0; q < 4; ++q) launches[4 * i + q] = v[q];
+            const int32_t v[5] = {l.pair, l.npair, l.tile0, l.ntile, l.group};
+            for (int q = 0; q < 5; ++q) launches[5 * i + q] = v[q];
         }
     }
     if (tiles) {
@@ -720,8 +826,8 @@ extern "C" int gpbo_cholinv_f64(double *S, int64_t ld, int64_t Np, int32_t *info
 // against NumPy; tools/bench_ci_jobs.py: its time).  tiles: host array, 8 words per tile as gpbo_cholinv_plan writes them.
 // Synchronous (uploads the tiles, waits for the launches).
 extern "C" int gpbo_cholinv_tiles_f64(double *S, int64_t ld, int64_t Np, int32_t *info, int32_t pair,
-                                      const int32_t *tiles, int64_t ntile, int32_t reps, void *stream) {
-    if (!ci_sizes_ok(S, ld, Np) || !info || reps < 1 || ntile < 0 || (ntile > 0 && !tiles) || ntile > (1 << 24)) return GPBO_ERR_ARG;
+                                      const int32_t *tiles, int64_t ntile, int32_t group, int32_t reps, void *stream) {
+    if (!ci_sizes_ok(S, ld, Np) || !info || reps < 1 || group < 1 || group > 64 || ntile < 0 || (ntile > 0 && !tiles) || ntile > (1 << 24)) return GPBO_ERR_ARG;
     if (pair >= 0 && 128 * ((int64_t)pair + 1) > Np) return GPBO_ERR_ARG;
     if (pair < 0 && ntile == 0) return GPBO_ERR_ARG;
     std::vector<CiTile> h((size_t)ntile);
@@ -749,10 +855,37 @@ extern "C" int gpbo_cholinv_tiles_f64(double *S, int64_t ld, int64_t Np, int32_t
     a.info = info;
     a.stamps = nullptr;
     a.tab = d;
-    a.l = CiLaunch{pair, pair >= 0 ? ci_pair_ntiles((int)Np) : 0, 0, (int32_t)ntile};
+    a.l = CiLaunch{pair, pair >= 0 ? ci_pair_ntiles((int)Np) : 0, 0, (int32_t)ntile, group};
+#ifdef GPBO_DIAGNOSTICS
+    unsigned long long *dst = nullptr;
+    const bool want_stamps = getenv("GPBO_CI_STAMPS") && atoi(getenv("GPBO_CI_STAMPS")) && pair < 0;
+    if (want_stamps && hipMalloc(&dst, 8 * 8 * 1024) == hipSuccess) {
+        (void)hipMemset(dst, 0, 8 * 8 * 1024);
+        a.stamps = dst;
+    }
+#endif
     for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL(cholinv_kernel, dim3((unsigned)(a.l.npair + a.l.ntile)), dim3(512), 0, gpbo_stream(stream), a);
+        hipLaunchKernelGGL(cholinv_kernel, dim3((unsigned)ci_launch_blocks(a.l)), dim3(512), 0, gpbo_stream(stream), a);
     const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(gpbo_stream(stream)) == hipSuccess;
+#ifdef GPBO_DIAGNOSTICS
+    if (dst) {
+        std::vector<unsigned long long> h(8 * 1024);
+        if (hipMemcpy(h.data(), dst, 8 * 8 * 1024, hipMemcpyDeviceToHost) == hipSuccess) {
+            const int n = ntile < 1024 ? (int)ntile : 1024;
+            double sum[5] = {0, 0, 0, 0, 0};
+            unsigned long long first = ~0ull, lastt = 0;
+            for (int i = 0; i < n; ++i) {
+                for (int q = 0; q < 5; ++q) sum[q] += (double)(h[8 * i + q + 1] - h[8 * i + q]);
+                if (h[8 * i] < first) first = h[8 * i];
+                if (h[8 * i + 5] > lastt) lastt = h[8 * i + 5];
+            }
+            fprintf(stderr, "tile stamps (cycles, mean of %d tiles of the last launch): prologue %.0f  k tiles with C %.0f  steady k tiles %.0f  "
+                    "stores issued %.0f  stores done %.0f;  first start -> last end %.0f\n", n, sum[0] / n, sum[1] / n, sum[2] / n,
+                    sum[3] / n, sum[4] / n, (double)(lastt - first));
+        }
+        (void)hipFree(dst);
+    }
+#endif
     if (d) (void)hipFree(d);
     return ok ? GPBO_OK : GPBO_ERR_LAUNCH;
 }

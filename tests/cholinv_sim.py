@@ -12,12 +12,12 @@ TILE_ROWS = {SMALL: 64, BIG: 128, BIG256: 256}
 
 
 def get_plan(Np, opt=None):
-    """(launches [n x 4]: pair, npair, tile0, ntile;  tiles [m x 8]: kind, k0, K, row0, col0, r1, wlim, 0)"""
+    """(launches [n x 5]: pair, npair, tile0, ntile, tiles per workgroup;  tiles [m x 8]: kind, k0, K, row0, col0, r1, wlim, 0)"""
     lib = _lib.load()
-    o = (C.c_int32 * 5)(*((opt or [0, 0, 0, 0]) + [0])[:5])
+    o = (C.c_int32 * 6)(*((list(opt or []) + [0] * 6)[:6]))
     nl, nt = C.c_int64(0), C.c_int64(0)
     assert lib.gpbo_cholinv_plan(Np, C.cast(o, C.c_void_p), C.byref(nl), C.byref(nt), None, None) == 0
-    L = np.zeros((nl.value, 4), dtype=np.int32)
+    L = np.zeros((nl.value, 5), dtype=np.int32)
     T = np.zeros((max(nt.value, 1), 8), dtype=np.int32)
     assert lib.gpbo_cholinv_plan(Np, C.cast(o, C.c_void_p), C.byref(nl), C.byref(nt), L.ctypes.data_as(C.c_void_p),
                                  T.ctypes.data_as(C.c_void_p)) == 0
@@ -110,7 +110,7 @@ def run_plan(S, Np, plan, first=0, count=None):
     L, T = plan
     tile_id = 0
     last = len(L) if count is None else first + count
-    for pair, npair, tile0, ntile in L[first:last]:
+    for pair, npair, tile0, ntile, _group in L[first:last]:
         tr = Tracker(Np)
         pending = []
         if npair > 0:

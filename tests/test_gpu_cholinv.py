@@ -35,14 +35,14 @@ def run_gpu(env, A, opt=None):
     S[:, :Np] = A
     dS = t.from_numpy(S).to(env.dev)
     info = t.full((1,), -7, dtype=t.int32, device=env.dev)
-    o = (C.c_int32 * 5)(*(opt or [0, 0, 0, 0, 0]))
+    o = (C.c_int32 * 6)(*((list(opt or []) + [0] * 6)[:6]))
     st = env.lib.gpbo_cholinv_f64(env.p(dS), 2 * Np, Np, env.p(info), C.cast(o, C.c_void_p), env.stream())
     assert st == 0
     t.cuda.synchronize()
     return dS.cpu().numpy(), int(info.item())
 
 
-@pytest.mark.parametrize("Np,opt", [(256, [0, 0, 0, 0]), (640, [1, 128, 3, 1]), (896, [2, 256, 4, 2]), (1152, [2, 256, 3, 2])])
+@pytest.mark.parametrize("Np,opt", [(256, [0, 0, 0, 0]), (640, [1, 128, 3, 1]), (896, [2, 256, 4, 2]), (1152, [2, 256, 3, 2]), (2304, [1, 128, 3, 1])])
 def test_every_launch_matches_the_cpu_execution_of_the_plan(env, Np, opt):
     A = spd(Np, 100 + Np)
     plan = get_plan(Np, opt)
@@ -53,7 +53,8 @@ def test_every_launch_matches_the_cpu_execution_of_the_plan(env, Np, opt):
         got, info = run_gpu(env, A, opt + [n])
         assert info == 0
         err = np.max(np.abs(got - S))
-        assert err <= 1e-9, f"launch {n} of {len(plan[0])} ({plan[0][n - 1]}): max |diff| {err}"
+        tol = 3e-11 * max(1.0, np.abs(S).max())  # entries of inv(L) reach ~1 / sqrt(jitter) = 100
+        assert err <= tol, f"launch {n} of {len(plan[0])} ({plan[0][n - 1]}): max |diff| {err} > {tol}"
 
 
 @pytest.mark.parametrize("kind,K", [(SMALL, 32), (SMALL, 128), (SMALL, 352), (BIG, 128), (BIG, 400 // 16 * 16), (BIG256, 128),
@@ -86,14 +87,14 @@ def test_one_tile_kind_against_numpy(env, kind, K):
         ref[r:r + 64, c:c + 64] = v
     dS = t.from_numpy(S).to(env.dev)
     info = t.zeros(1, dtype=t.int32, device=env.dev)
-    st = env.lib.gpbo_cholinv_tiles_f64(env.p(dS), 2 * Np, Np, env.p(info), -1, T.ctypes.data_as(C.c_void_p), len(T), 1, env.stream())
+    st = env.lib.gpbo_cholinv_tiles_f64(env.p(dS), 2 * Np, Np, env.p(info), -1, T.ctypes.data_as(C.c_void_p), len(T), 2, 1, env.stream())
     assert st == 0
     got = dS.cpu().numpy()
     assert np.max(np.abs(got - ref)) <= 1e-11 * K
 
 
 @pytest.mark.parametrize("Np,opt", [(128, None), (384, None), (1024, None), (1024, [1, 128, 3, 1]), (2176, None),
-                                    (2176, [3, 512, 4, 2]), (4096, None), (4224, [2, 256, 4, 2])])
+                                    (2176, [3, 512, 4, 2]), (4096, None), (4224, [2, 256, 4, 3])])
 def test_inverse_factor_vs_lapack(env, Np, opt):
     A = spd(Np, Np)
     got, info = run_gpu(env, A, (opt + [0]) if opt else None)

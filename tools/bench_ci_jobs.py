@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bayesian_optimisation_amd import _lib
 lib = _lib.load()
+GROUP = int(os.environ.get('CI_GROUP', '1'))
 Np = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda", 0)
 S = torch.rand(Np, 2 * Np, dtype=torch.float64, device=dev) * 1e-3
@@ -18,7 +19,7 @@ def run(pair, tiles, reps=20):
     S0 = S.clone()
     def go(n):
         rc = lib.gpbo_cholinv_tiles_f64(C.c_void_p(S0.data_ptr()), 2 * Np, Np, C.c_void_p(info.data_ptr()), pair,
-                                        T.ctypes.data_as(C.c_void_p), len(T), n, st)
+                                        T.ctypes.data_as(C.c_void_p), len(T), GROUP, n, st)
         assert rc == 0, rc
     go(2)
     S0.copy_(S); torch.cuda.synchronize()
