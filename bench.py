@@ -96,7 +96,7 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best, variance_dtype="f64"):
+def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best, variance_dtype="f64", winner=None):
     """The oracle's Cholesky route (NumPy/LAPACK, BLAS threads = host cores) on a bounded sample of the
     same workload; factorisation excluded (it is amortised over the 2^21 candidates of a real step).  The sample is
     sized from a 1024-candidate probe so that the leg takes about `target_s` seconds."""
@@ -119,10 +119,11 @@ def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best, variance_dty
 
     vdt = np.float32 if variance_dtype == "f32" else np.float64   # config 4: the fp32 restatement
 
-    def run(P):
+    def run(P, with_value=False):
         mu, sig = O.posterior_chol(X, y, P, ls, L=L, alpha=alpha, variance_dtype=vdt)
         a = O.lcb(mu, sig, 4) if acq == "lcb" else O.expected_improvement(mu, sig, f_best, 0.0)
-        return int(np.flatnonzero(a == a.max())[0])
+        i = int(np.flatnonzero(a == a.max())[0])
+        return (i, float(a[i])) if with_value else i
 
     if fixed_sample:
         ns = min(fixed_sample, len(Xs))
@@ -137,7 +138,19 @@ def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best, variance_dty
     dt = time.perf_counter() - t0
     if vdt is np.float32:   # what is TIMED is the fp32 restatement; what the GPU's decision is checked against is fp64
         vdt = np.float64
-        idx = run(Xs[:ns])
+    # Untimed: the oracle's (index, value) on the sample and on a window around the arg-max the GPU reported, so that the
+    # check below speaks about the winner and not only about the first candidates.
+    idx, val = run(Xs[:ns], with_value=True)
+    window = None
+    if winner is not None:
+        w0 = max(0, min(int(winner) - 2048, len(Xs) - 4096))
+        w1 = min(len(Xs), w0 + 4096)
+        if w1 > ns:  # otherwise the sample already holds the winner
+            wi, wv = run(Xs[w0:w1], with_value=True)
+            window = (w0, w1)
+            if wv > val or (wv == val and w0 + wi < idx):
+                idx, val = w0 + wi, wv
+    cpu_baseline.last_window = window
     return dict(value=ns / dt, unit="candidate acquisitions/s", cores=int(threads), kind="port",
                 sample=f"first {ns} of the rank's candidates, N={N}, d={d}, posterior + {acq.upper()} + arg-max, "
                        f"{dt:.1f} s wall, factorisation excluded (oracle/gp_oracle.py posterior_chol"
@@ -497,10 +510,21 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not qei:
             cb, idx_cpu, ns = cpu_baseline(X, y, Xs_local, ls, args.acq, args.cpu_seconds, args.cpu_sample, f_best,
-                                           "f32" if f32 else "f64")
-            r = {"f32": gp.score_f32, "i8": gp.score_i8, "i8c": gp.score_i8c, "f64b": gp.score_bound}.get(
-                args.dtype, gp.score)(Xsd[:ns], **acq_kw)
-            cb["argmax_match_on_sample"] = bool(r.best_idx == idx_cpu)
+                                           "f32" if f32 else "f64", winner=best[1] - lo)
+            score_fn = {"f32": gp.score_f32, "i8": gp.score_i8, "i8c": gp.score_i8c, "f64b": gp.score_bound}.get(
+                args.dtype, gp.score)
+            r = score_fn(Xsd[:ns], **acq_kw)
+            gpu_idx, gpu_val = r.best_idx, r.best_val
+            win = cpu_baseline.last_window
+            if win is not None:  # the same union on the GPU: the sample and the window around the reported arg-max
+                rw = score_fn(Xsd[win[0]:win[1]], idx_offset=win[0], **acq_kw)
+                if rw.best_val > gpu_val or (rw.best_val == gpu_val and rw.best_idx < gpu_idx):
+                    gpu_idx, gpu_val = rw.best_idx, rw.best_val
+            cb["argmax_match_on_sample"] = bool(gpu_idx == idx_cpu)
+            cb["sample_contains_reported_argmax"] = bool(best[1] - lo < ns or (win is not None and win[0] <= best[1] - lo < win[1]))
+            cb["reported_argmax_is_the_samples"] = bool(gpu_idx == best[1] - lo)
+            if win is not None:
+                cb["sample"] += f"; arg-max check (untimed): that sample plus candidates [{win[0]}, {win[1]}) around the reported arg-max"
             out["cpu_baseline"] = cb
         if f32 or i8 or bnd:
             out["screen"] = gp.last_screen   # survivors of the screen, tolerance / threshold and its check, fallback flag
