@@ -776,7 +776,9 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
     // prefix-bound route: K(X*,X) with the pair distances on the matrix cores and the mean reported from below by its error
     // bound (kstar_mfma.hip; GPBO_PREFIX_VALU=1: the difference-form kernel instead, for A/B runs)
     static const bool prefix_valu = getenv("GPBO_PREFIX_VALU") && atoi(getenv("GPBO_PREFIX_VALU"));
-    const bool kstar_mfma = n_prefix > 0 && !prefix_valu;
+    static const bool overlap_env = getenv("GPBO_OVERLAP") && atoi(getenv("GPBO_OVERLAP"));
+    // (and only while the unused rows of the K*^T slab can take that launch's mean partials)
+    const bool kstar_mfma = n_prefix > 0 && !prefix_valu && !overlap_env && n_prefix + n_prefix / GPBO_KS_SLICE <= Np;
     void *prep_buf = w + L.prep_off;
     if (kstar_mfma) {
         int rc0 = gpbo_kstar_mfma_prep(X, N, Np, d, ls_host, alpha, prep_buf, stream);
@@ -793,7 +795,6 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
     // Measured on MI355X (N=512, M=2^20): running K(X*,X) of chunk c+1 beside the variance kernel of chunk c gains
     // nothing - the variance launches slow down by what the overlap hides (0.59 -> 0.70 ms), i.e. fp64 VALU work
     // and fp64 MFMA work do not co-execute on gfx950.  Kept as an opt-in (GPBO_OVERLAP=1) for other shapes.
-    static const bool overlap_env = getenv("GPBO_OVERLAP") && atoi(getenv("GPBO_OVERLAP"));
     const int64_t nchunks = (M + chunk - 1) / chunk;
     Helper *hp = (nchunks > 1 && overlap_env) ? helper_for_current_device() : nullptr;
     // Fork: the helper stream builds K(X*,X)+mu of chunk c+1 (fp64 VALU + HBM writes) while the caller's
@@ -823,10 +824,25 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
         } else if (prof && prof->count < prof->capacity) {
             prof->kmode[prof->count] = 0;
         }
-        int rc = kstar_mfma ? gpbo_kstar_mu_mfma(Xs + s * d, Mc, N, Np, d, ls_host, alpha, prep_buf, KsT[b], chunk, mu_part[b],
-                                                 n_prefix, ks)
-                            : gpbo_kstar_mu_rows(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, diag_add, idx_offset + s,
-                                                 KsT[b], chunk, mu_part[b], n_prefix ? n_prefix : Np, ks);
+        int rc;
+        if (kstar_mfma) {
+            // The MEAN of all N observations from the matrix-core kernel (expanded distances; reported from below by its
+            // own error bound), but the n_prefix stored rows of K*^T from the difference-form kernel of the plain pass:
+            // the expanded form's entry error grows with the points' distance from the centroid in length-scale units
+            // (unnormalised inputs), is amplified by |U| and would need a data-dependent variance pad; with the plain
+            // pass's own entries |v[:J]|^2 is a partial sum of the very squares the plain pass adds up, so the bound
+            // holds for any inputs.  Costs n_prefix / N of the fp64-VALU kernel: 6 % at N / 16.
+            rc = gpbo_kstar_mu_mfma(Xs + s * d, Mc, N, Np, d, ls_host, alpha, prep_buf, KsT[b], chunk, mu_part[b], 0, ks);
+            if (rc != GPBO_OK) return rc;
+            const int64_t nrow = (N < n_prefix) ? N : n_prefix;
+            // (its mean partials - of the first n_prefix observations only - are not wanted: they go to rows of the K*^T
+            //  slab that the prefix mode neither writes nor reads, [n_prefix, n_prefix + n_prefix / 64))
+            rc = gpbo_kstar_mu_rows(Xs + s * d, Mc, Xsc, nrow, n_prefix, d, ls_host, alpha, 0.0, idx_offset + s, KsT[b], chunk,
+                                    KsT[b] + n_prefix * chunk, n_prefix, ks);
+        } else {
+            rc = gpbo_kstar_mu_rows(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT[b], chunk,
+                                    mu_part[b], n_prefix ? n_prefix : Np, ks);
+        }
         if (rc != GPBO_OK) return rc;
         if (hp && hipEventRecord(hp->kdone[b], ks) != hipSuccess) return GPBO_ERR_LAUNCH;
         return GPBO_OK;

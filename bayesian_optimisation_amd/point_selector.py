@@ -14,8 +14,14 @@ Differences from the reference, all deliberate:
     is materialised only when M <= COV_PRED_MAX_M; `cov_meas_pred` (:81) only when M*N is small.
   * Failures raise instead of returning garbage: numpy.linalg.LinAlgError when K is not positive
     definite, IndexError when the acquisition contains NaN (the reference's own failure at :207).
-  * Extra, not in the reference: `precision="fp32"` / `"i8"` (fp64 factorisation and means; the N^2 variance product
-    as an fp32 or int8-sliced SCREEN; the selected point is still decided by the fp64 kernels), `expected_improvement(xi)`,
+  * Extra, not in the reference: `precision="fp32"` / `"i8"` / `"i8c"` (fp64 factorisation and means; the N^2 variance
+    product as an fp32 / int8-sliced / three-digit int8 SCREEN).  In these modes EVERY acquisition call - LCB with any
+    `explore`, EI - returns the index the fp64 kernels decide (screen + fp64 re-score of the survivors with THAT
+    acquisition), `mean_func` is the fp64 kernels' bit for bit, and `cov_func` / `acq_func_eval` are the SCREEN's:
+    |cov_func - fp64| <= SCREEN_SIGMA_TOL[precision] (5e-3 for fp32 and i8c, 2e-9 for i8; also in `last_screen`), so the
+    arg-max of `acq_func_eval` itself can differ from the returned index when two candidates are closer than that.
+    A caller that plots or post-processes these arrays at the reference's 1e-8 should stay with precision="fp64".
+    Also extra: `expected_improvement(xi)`,
     `q_expected_improvement()`, `dense_outputs=False` (next point only: the dense attributes stay None and the acquisition
     calls go through the exact prefix bound), `kernel_params` may be preset (then no
     ARD search runs), optional multi-GPU candidate sharding when torch.distributed is initialised,
@@ -34,6 +40,8 @@ COV_PRED_MAX_M = 4096          # cov_pred is M x M: 128 MiB at this size
 COV_MEAS_PRED_MAX = 1 << 24    # entries of the (M, N) cross covariance kept for inspection
 MAX_APPEND_ROWS = 64           # more new rows than this: a fresh factorisation is cheaper than row-by-row appends
 MAX_APPENDED_COLUMNS = 256     # columns built by appends since the last full factorisation before a refresh is due
+# |cov_func - fp64 sigma| of the screened precisions (asserted in tests/test_gpu_parity.py, test_gpu_i8.py, test_gpu_i8c.py)
+SCREEN_SIGMA_TOL = {"fp32": 5e-3, "i8": 2e-9, "i8c": 5e-3}
 
 
 def _plot_hooks():
@@ -91,6 +99,8 @@ class PointSelector:
         self._state_path = state_path
         self._inc = None               # (X, y, ls) of the factorisation held by self._gp
         self.last_update = None        # "factorise" | "append": what the last update_surrogate() did
+        self.last_screen = None        # screened precisions: DeviceGP.last_screen of the last acquisition + sigma_abs_tol
+        self._screen_ctx = None        # screened precisions: (candidate shard on the device, diag_add)
 
     # ------------------------------------------------------------------------------------------
     def _cov_get(self, name):
@@ -173,8 +183,11 @@ class PointSelector:
             return
         if self._precision in ("fp32", "i8", "i8c"):   # screened variance product (fp32: BASELINE config 4's mode), fp64 decision
             score = {"fp32": gp.score_f32, "i8": gp.score_i8, "i8c": gp.score_i8c}[self._precision]
-            res = score(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
+            self._screen_ctx = (gp._dev(Xs[lo:hi]), diag_add)
+            res = score(self._screen_ctx[0], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
+            self.last_screen = dict(gp.last_screen, sigma_abs_tol=SCREEN_SIGMA_TOL[self._precision])
         else:
+            self._screen_ctx = None
             res = gp.score(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
         self._mu_dev, self._sigma_dev = res.mu, res.sigma
         mu, sigma, acq = res.mu.cpu().numpy(), res.sigma.cpu().numpy(), res.acq.cpu().numpy()
@@ -345,8 +358,16 @@ class PointSelector:
                 self._cached[key] = (None, D.allreduce_argmax(res.best_val, res.best_idx, res.nan_count))
         elif key not in self._cached:
             lo, hi = self._lo_hi
-            res = self._gp.acquisition_on_posterior(self._mu_dev, self._sigma_dev, acquisition=kind,
-                                                    idx_offset=lo, **kw)
+            if self._screen_ctx is not None:
+                # screened precision: the stored sigma is the screen's, so the decision for THIS acquisition is made the
+                # way the cached LCB(4) one was - a screen pass with it, then the fp64 kernels on every survivor
+                score = {"fp32": self._gp.score_f32, "i8": self._gp.score_i8, "i8c": self._gp.score_i8c}[self._precision]
+                Xd, diag_add = self._screen_ctx
+                res = score(Xd, acquisition=kind, dense=True, idx_offset=lo, diag_add=diag_add, **kw)
+                self.last_screen = dict(self._gp.last_screen, sigma_abs_tol=SCREEN_SIGMA_TOL[self._precision])
+            else:
+                res = self._gp.acquisition_on_posterior(self._mu_dev, self._sigma_dev, acquisition=kind,
+                                                        idx_offset=lo, **kw)
             acq = res.acq.cpu().numpy()
             best = D.allreduce_argmax(res.best_val, res.best_idx, res.nan_count)
             world, _ = self._world()

@@ -217,3 +217,44 @@ def test_drop_in_class_without_dense_outputs_returns_the_same_multi_index():
     assert only[3].mean_func is None and only[3].cov_func is None and only[3].acq_func_eval is None
     assert full[3].mean_func.shape == (g, g, g)
     assert only[3]._gp.last_screen["mode"] == "bound"
+
+
+@pytest.mark.parametrize("scale,ls_lo,ls_hi,yscale", [(1e3, 8.0, 60.0, 1e-3), (5e4, 300.0, 4e3, 1e-6), (1.0, 0.02, 0.2, 1e-4)])
+def test_unnormalised_inputs_and_small_objectives(scale, ls_lo, ls_hi, yscale):
+    """raw physical units (coordinates of 1e3 .. 5e4 with length scales of 10 .. 1e3, far from the centroid
+    in length-scale units) and a small |y| - where an expanded-distance K(X*,X) entry error, amplified by |U|, could
+    overstate |v[:J]|^2 by more than the fixed pad.  The stored prefix rows now come from the difference-form kernel of
+    the plain pass: the bound must hold for every candidate and the selected point must be the plain pass's."""
+    rng = np.random.default_rng(int(scale) + 7)
+    d, N, M = 6, 1500, 60000
+    X = rng.uniform(0, scale, (N, d))
+    Xs = rng.uniform(-0.05 * scale, 1.05 * scale, (M, d))
+    Xs[:200] = X[:200] + 1e-7 * scale * rng.standard_normal((200, d))  # candidates on top of observations: tiny variance
+    ls = np.exp(rng.uniform(np.log(ls_lo), np.log(ls_hi), d))
+    y = yscale * rng.standard_normal(N)
+    gp = DeviceGP(chunk=1 << 15).factorise(X, y, ls)
+    full = gp.score(Xs, dense=True)
+    acq64 = full.acq.cpu().numpy()
+    for kw in (dict(acquisition="lcb", explore=4.0), dict(acquisition="lcb", explore=0.25),
+               dict(acquisition="ei", f_best=float(y.min()), xi=0.0)):
+        r64 = gp.score(Xs, **kw)
+        rb = gp.score_bound(Xs, **kw)
+        assert rb.best_idx == r64.best_idx and rb.nan_count == r64.nan_count == 0
+        assert abs(rb.best_val - r64.best_val) <= 1e-9 * max(1.0, abs(r64.best_val))
+    # the first pass itself: an upper bound of the fp64 acquisition for EVERY candidate
+    import ctypes as C
+
+    from bayesian_optimisation_amd import _lib
+
+    t = gp.torch
+    Xsd = gp._dev(Xs)
+    chunk, wbytes = gp._ensure_post_workspace(M)
+    ub = t.empty(M, dtype=t.float64, device=gp.device)
+    J = 128
+    st = gp.lib.gpbo_posterior_prefix_f64(gp._ptr(Xsd), M, gp._ptr(gp.X), gp.N, gp.Np, gp.d, gp.ls_h.ctypes.data_as(C.c_void_p),
+                                          gp._ptr(gp.U), gp._ptr(gp.alpha), 1.000101, _lib.ACQ_LCB, 4.0, 0.0, 0, chunk, J, None,
+                                          None, gp._ptr(ub), gp._ptr(gp._result), gp._ptr(gp._work_post), wbytes, None,
+                                          gp._stream())
+    assert st == 0
+    t.cuda.synchronize()
+    assert (ub.cpu().numpy() >= acq64).all()

@@ -549,6 +549,34 @@ def test_dropin_fp32_precision_mode(golden):
     assert idx[0] == _first_argmax(g["acq_func_eval"])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "i8", "i8c"])
+def test_screened_precisions_decide_every_acquisition_in_fp64(precision):
+    """EI and LCB with another `explore` under a screened precision: the index is the fp64 selector's (screen + fp64
+    re-score with THAT acquisition), not the arg-max of an acquisition built on the screen's sigma; mean_func is the
+    fp64 kernels'; cov_func stays inside the documented bound, which last_screen repeats."""
+    from bayesian_optimisation_amd.point_selector import SCREEN_SIGMA_TOL
+
+    X, y, Xs, ls = make_problem(700, 6000, 6)
+    out = {}
+    for prec in ("fp64", precision):
+        ps = PointSelector(precision=prec)
+        ps.measured_pts, ps.measured_vals = X, y
+        ps.feature_domain, ps.predicted_pts = [6000], Xs
+        ps.set_kernel_params(ls)
+        ps.update_surrogate()
+        out[prec] = (ps.lower_confidence_bound(), ps.expected_improvement(), ps.expected_improvement(xi=0.05),
+                     ps.lower_confidence_bound(explore=1), ps.lower_confidence_bound(explore=10), ps.mean_func.copy(),
+                     ps.cov_func.copy(), ps)
+    a, b = out["fp64"], out[precision]
+    for i in range(5):
+        assert np.array_equal(a[i], b[i]), i
+    assert np.array_equal(a[5], b[5])
+    assert np.max(np.abs(a[6] - b[6])) <= SCREEN_SIGMA_TOL[precision]
+    ls_ = b[7].last_screen
+    assert ls_["sigma_abs_tol"] == SCREEN_SIGMA_TOL[precision] and not ls_["fallback"] and 4 * ls_["err_max"] <= ls_["tau"]
+    assert a[7].last_screen is None
+
+
 def test_nan_candidate_coordinate_is_counted():
     X, y, Xs, ls = make_problem(20, 600, 3)
     Xs = Xs.copy()

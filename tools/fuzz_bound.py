@@ -32,6 +32,9 @@ while time.time() < t_end:
     elif kind == 2:
         X[: N // 2] = 0.5 + 0.05 * rng.standard_normal((N // 2, d))
     Xs = rng.uniform(-0.1, 1.1, (M, d))
+    if rng.random() < 0.25:  # raw physical units: large coordinates, length scales to match
+        sc = float(rng.choice([1e2, 1e3, 5e4]))
+        X, Xs, ls = X * sc, Xs * sc, ls * sc * float(rng.choice([0.05, 0.3, 1.0]))
     y = rng.standard_normal(N) * rng.choice([1e-6, 0.1, 1.0, 30.0]) + rng.choice([0.0, 5.0])
     for i in rng.integers(0, M, int(rng.integers(0, 4))):
         Xs[i, rng.integers(0, d)] = np.nan
