@@ -97,6 +97,16 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
     if (wresc < 0) return GPBO_ERR_ARG;
     double *dub = bound_route ? A.alloc<double>(M) : nullptr;
     char *dresc = bound_route ? A.alloc<char>(wresc + 256) : nullptr;
+    // the bound's observation subset (subset.hip): chosen by farthest-point sampling, independent of the arrival order
+    const int64_t Ns = (J2 > J1) ? J2 : J1;
+    const bool with_subset = bound_route && Ns <= N;
+    const int64_t wsub = with_subset ? gpbo_bound_subset_workspace_bytes(N, Ns) : 0;
+    if (wsub < 0) return GPBO_ERR_ARG;
+    int64_t *dperm = with_subset ? A.alloc<int64_t>(Ns) : nullptr;
+    double *dXsub = with_subset ? A.alloc<double>(Ns * d) : nullptr;
+    double *dUsub = with_subset ? A.alloc<double>(Ns * Ns) : nullptr;
+    int32_t *dinfo_sub = with_subset ? A.alloc<int32_t>(1) : nullptr;
+    char *dwsub = with_subset ? A.alloc<char>(wsub + 256) : nullptr;
     if (!A.ok) return GPBO_ERR_WORKSPACE;
     void *st = reinterpret_cast<void *>(A.stream);
 
@@ -121,15 +131,32 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
     const double prior_var = (1.0 + jitter1) + jitter2;  // diagonal of cov_pred as the reference rounds it
     bool decided = false;
     if (bound_route) {
-        rc = gpbo_posterior_prefix_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, chunk, J1, nullptr,
-                                       nullptr, dub, dres, dwork, wpost, nullptr, st);
+        bool sub_ok = false;
+        if (with_subset) {
+            char *ws = reinterpret_cast<char *>(((uintptr_t)dwsub + 255) & ~(uintptr_t)255);
+            rc = gpbo_bound_subset_f64(dX, N, d, ls, jitter1, jitter2, J1, J2, dperm, dXsub, dUsub, dinfo_sub, ws, wsub, st);
+            if (rc != GPBO_OK) return rc;
+            int32_t isub = 0;
+            if (!A.d2h(&isub, dinfo_sub, sizeof(int32_t)) || !A.sync()) return GPBO_ERR_LAUNCH;
+            sub_ok = isub == 0;   // (K_SS not positive definite at this jitter: the literal prefix instead)
+        }
+        if (sub_ok)
+            rc = gpbo_posterior_prefix_subset_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, chunk, J1,
+                                                  dXsub, Ns, Ns, dUsub, nullptr, nullptr, dub, dres, dwork, wpost, nullptr, st);
+        else
+            rc = gpbo_posterior_prefix_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, chunk, J1,
+                                           nullptr, nullptr, dub, dres, dwork, wpost, nullptr, st);
         if (rc != GPBO_OK) return rc;
         gpbo_screen_stats stats;
         char *wr = reinterpret_cast<char *>(((uintptr_t)dresc + 255) & ~(uintptr_t)255);
         int64_t stride = M / 1024;
         if (stride < 1) stride = 1;
-        rc = gpbo_bound_select_f64(dXs, M, dub, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, stride, bcap,
-                                   bchunk, J2, dres, &stats, wr, wresc, st);
+        if (sub_ok)
+            rc = gpbo_bound_select_subset_f64(dXs, M, dub, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, stride,
+                                              bcap, bchunk, J2, dXsub, Ns, Ns, dUsub, dres, &stats, wr, wresc, st);
+        else
+            rc = gpbo_bound_select_f64(dXs, M, dub, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, stride, bcap,
+                                       bchunk, J2, dres, &stats, wr, wresc, st);
         if (rc != GPBO_OK) return rc;
         decided = !stats.fallback;
     }

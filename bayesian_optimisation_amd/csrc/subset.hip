@@ -1,0 +1,248 @@
+// Order-independent observation subset for the exact prefix bound.
+//
+// The bound of sigma_acq.hip / rescore.hip uses the variance reduction from a SUBSET of the observations:
+//     sigma_c^2 = c - k_c^T K^-1 k_c  <=  c - k_S^T K_SS^-1 k_S          for every subset S
+// (conditioning on fewer observations cannot lower the posterior variance of /root/reference/point_selector.py:91).  Round 2
+// took S = the first J observations in ARRIVAL order - a Sobol stream covers the domain with any prefix, a sorted or
+// clustered history does not, and the bound then separates nothing.  Here S is chosen by farthest-point sampling in
+// length-scale units (each new member is the observation farthest from the members so far; the first one is the
+// observation farthest from the centroid; ties to the lowest index): it depends on the SET of observations, not on their
+// order, and spreads over whatever region they occupy.  The subset's own factor U_S = chol(K_SS)^-T comes from the same
+// factorisation kernels (cholinv.hip) on the gathered rows; for the second-level bound the subset is extended - by the
+// first not-yet-chosen observations in index order - to J2 members, the first J of which are the first-level set
+// (leading blocks of a Cholesky factor and of its inverse are the factor and inverse of the leading block).
+#include "gpbo_internal.h"
+
+#include <limits>
+
+namespace {
+
+constexpr int FT = 1024;  // threads of the single workgroup
+
+struct FpsLs {
+    double isc[GPBO_MAX_D];  // 1 / ls_k
+};
+
+__device__ __forceinline__ void block_argmax(double &v, int64_t &i, double *s_val, int64_t *s_idx) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int64_t oi = __shfl_xor(i, off);
+        if (gpbo_better(ov, oi, v, i)) { v = ov; i = oi; }
+    }
+    if (lane == 0) { s_val[w] = v; s_idx[w] = i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double bv = s_val[0];
+        int64_t bi = s_idx[0];
+        for (int q = 1; q < FT / 64; ++q)
+            if (gpbo_better(s_val[q], s_idx[q], bv, bi)) { bv = s_val[q]; bi = s_idx[q]; }
+        s_val[0] = bv;
+        s_idx[0] = bi;
+    }
+    __syncthreads();
+    v = s_val[0];
+    i = s_idx[0];
+    __syncthreads();
+}
+
+// perm[0 .. J) = farthest-point sequence; perm[J .. J2) = the first J2 - J observations not among them, in index order.
+// One workgroup.  PTS > 0: every thread keeps its PTS observations (scaled coordinates) and their distances to the
+// member set in registers (N <= 1024 PTS) - a selection step is then d fmas per point and one block arg-max, ~1 us;
+// PTS == 0: any N, coordinates re-read and distances kept in `mind` (global) every step.
+template <int PTS, int D>
+__global__ __launch_bounds__(FT) void fps_kernel(const double *__restrict__ X, int64_t N, int d_rt, FpsLs ls, int64_t J, int64_t J2,
+                                                 double *__restrict__ mind, int64_t *__restrict__ perm) {
+    __shared__ double s_val[FT / 64];
+    __shared__ int64_t s_idx[FT / 64];
+    __shared__ double s_c[GPBO_MAX_D];
+    __shared__ long long s_scan[FT];
+    const int tid = threadIdx.x;
+    const int d = (PTS > 0) ? D : d_rt;
+    const double ninf = -std::numeric_limits<double>::infinity();
+    constexpr int NP = PTS > 0 ? PTS : 1, ND = PTS > 0 ? D : 1;
+    double xr[NP][ND], md[NP];
+    if (PTS > 0) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int64_t i = tid + (int64_t)FT * q;
+#pragma unroll
+            for (int k = 0; k < ND; ++k) xr[q][k] = (i < N) ? X[i * D + k] * ls.isc[k] : 0.0;
+            md[q] = std::numeric_limits<double>::infinity();
+        }
+    }
+    // centroid (fixed-order reduction: per-thread partial sums, then thread 0 over the 1024 partials of each coordinate)
+    for (int k = 0; k < d; ++k) {
+        double s = 0.0;
+        for (int64_t i = tid; i < N; i += FT) s += X[i * d + k] * ls.isc[k];
+        reinterpret_cast<double *>(s_scan)[tid] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int q = 0; q < FT; ++q) t += reinterpret_cast<double *>(s_scan)[q];
+            s_c[k] = t / (double)N;
+        }
+        __syncthreads();
+    }
+    // distance of this thread's points to s_c, folded into their running minimum; returns the thread's best (value, index)
+    auto sweep = [&](int64_t member, double &bv, int64_t &bi) {
+        bv = ninf;
+        bi = std::numeric_limits<int64_t>::max();
+        if (PTS > 0) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int64_t i = tid + (int64_t)FT * q;
+                double dist = 0.0;
+#pragma unroll
+                for (int k = 0; k < ND; ++k) {
+                    const double df = xr[q][k] - s_c[k];
+                    dist = fma(df, df, dist);
+                }
+                double m = (member < 0) ? dist : fmin(md[q], dist);
+                if (member >= 0) {
+                    if (i == member) m = ninf;  // a member is never chosen again (its duplicates: distance 0, chosen last)
+                    md[q] = m;
+                }
+                if (i < N && gpbo_better(m, i, bv, bi)) { bv = m; bi = i; }
+            }
+        } else {
+            for (int64_t i = tid; i < N; i += FT) {
+                double dist = 0.0;
+                for (int k = 0; k < d; ++k) {
+                    const double df = X[i * d + k] * ls.isc[k] - s_c[k];
+                    dist = fma(df, df, dist);
+                }
+                double m = dist;
+                if (member >= 0) {
+                    m = fmin(mind[i], dist);
+                    if (i == member) m = ninf;
+                    mind[i] = m;
+                } else {
+                    mind[i] = std::numeric_limits<double>::infinity();
+                }
+                if (gpbo_better(m, i, bv, bi)) { bv = m; bi = i; }
+            }
+        }
+    };
+    double bv;
+    int64_t bi;
+    sweep(-1, bv, bi);  // first member: farthest from the centroid
+    block_argmax(bv, bi, s_val, s_idx);
+    for (int64_t j = 0; j < J; ++j) {
+        const int64_t p = bi;
+        if (tid == 0) perm[j] = p;
+        if (tid < d) s_c[tid] = X[p * d + tid] * ls.isc[tid];
+        __syncthreads();
+        sweep(p, bv, bi);
+        block_argmax(bv, bi, s_val, s_idx);
+    }
+    if (PTS > 0) {  // the extension below reads the membership from `mind`
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int64_t i = tid + (int64_t)FT * q;
+            if (i < N) mind[i] = md[q];
+        }
+        __syncthreads();
+    }
+    // extension to J2 members: unchosen observations (mind > -inf) in index order; thread t owns a contiguous range
+    if (J2 > J) {
+        const int64_t per = (N + FT - 1) / FT, lo = (int64_t)tid * per, hi = (lo + per < N) ? lo + per : N;
+        long long cnt = 0;
+        for (int64_t i = lo; i < hi; ++i) cnt += (mind[i] != ninf);
+        s_scan[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < FT; off <<= 1) {  // inclusive Hillis-Steele scan
+            const long long add = (tid >= off) ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += add;
+            __syncthreads();
+        }
+        long long pos = s_scan[tid] - cnt;
+        for (int64_t i = lo; i < hi; ++i) {
+            if (mind[i] != ninf) {
+                if (pos < J2 - J) perm[J + pos] = i;
+                ++pos;
+            }
+        }
+    }
+}
+
+__global__ void gather_obs_kernel(const double *__restrict__ X, int d, const int64_t *__restrict__ perm, int64_t n,
+                                  double *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * d) return;
+    out[e] = X[perm[e / d] * d + (e % d)];
+}
+
+struct SubsetLayout {
+    int64_t mind_off, k_off, y_off, alpha_off, fact_off, fact_bytes, total;
+};
+
+SubsetLayout subset_layout(int64_t N, int64_t Ns) {
+    SubsetLayout L;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { const int64_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    L.mind_off = take((int64_t)sizeof(double) * N);
+    L.k_off = take((int64_t)sizeof(double) * Ns * Ns);
+    L.y_off = take((int64_t)sizeof(double) * Ns);
+    L.alpha_off = take((int64_t)sizeof(double) * Ns);
+    L.fact_bytes = gpbo_factorise_workspace_bytes(Ns);
+    L.fact_off = take(L.fact_bytes);
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+
+extern "C" int64_t gpbo_bound_subset_workspace_bytes(int64_t N, int64_t Ns) {
+    if (N < 1 || Ns < 128 || Ns % 128 || Ns > N) return GPBO_ERR_ARG;
+    return subset_layout(N, Ns).total;
+}
+
+// perm_out [Ns] int64, Xsub_out [Ns x d], Usub_out [Ns x Ns] (all device).  Ns = max(J, J2) members, a multiple of 128, <= N.
+extern "C" int gpbo_bound_subset_f64(const double *X, int64_t N, int32_t d, const double *ls_host, double jitter1,
+                                     double jitter2, int64_t J, int64_t J2, int64_t *perm_out, double *Xsub_out,
+                                     double *Usub_out, int32_t *info, void *work, int64_t work_bytes, void *stream) {
+    if (!X || !ls_host || !perm_out || !Xsub_out || !Usub_out || !info || !work) return GPBO_ERR_ARG;
+    const int64_t Ns = (J2 > J) ? J2 : J;
+    if (N < 1 || d < 1 || d > GPBO_MAX_D || J < 128 || J % 128 || (J2 != 0 && (J2 < J || J2 % 128)) || Ns > N) return GPBO_ERR_ARG;
+    if ((uintptr_t)work & 255) return GPBO_ERR_ARG;
+    const SubsetLayout L = subset_layout(N, Ns);
+    if (work_bytes < L.total) return GPBO_ERR_WORKSPACE;
+    FpsLs ls;
+    for (int k = 0; k < GPBO_MAX_D; ++k) ls.isc[k] = 0.0;
+    for (int k = 0; k < d; ++k) {
+        if (!(ls_host[k] > 0.0)) return GPBO_ERR_ARG;
+        ls.isc[k] = 1.0 / ls_host[k];
+    }
+    hipStream_t st = gpbo_stream(stream);
+    char *w = reinterpret_cast<char *>(work);
+    double *mind = reinterpret_cast<double *>(w + L.mind_off);
+    double *Ksub = reinterpret_cast<double *>(w + L.k_off);
+    double *ysub = reinterpret_cast<double *>(w + L.y_off);
+    double *asub = reinterpret_cast<double *>(w + L.alpha_off);
+    // registers hold up to 8 observations per thread at d <= 8 (4 at d <= 16); beyond: the global-memory form
+#define GPBO_FPS(P, DD) hipLaunchKernelGGL((fps_kernel<P, DD>), dim3(1), dim3(FT), 0, st, X, N, (int)d, ls, J, Ns, mind, perm_out)
+    const int64_t pts = (N + FT - 1) / FT;
+    bool launched = false;
+#define GPBO_FPS_D(DD)                                                                   \
+    if (!launched && d == DD) {                                                          \
+        if (pts <= 1) { GPBO_FPS(1, DD); launched = true; }                              \
+        else if (pts <= 2) { GPBO_FPS(2, DD); launched = true; }                         \
+        else if (pts <= 4) { GPBO_FPS(4, DD); launched = true; }                         \
+        else if (pts <= 8 && DD <= 8) { GPBO_FPS(8, DD); launched = true; }              \
+    }
+    GPBO_FPS_D(1) GPBO_FPS_D(2) GPBO_FPS_D(3) GPBO_FPS_D(4) GPBO_FPS_D(5) GPBO_FPS_D(6) GPBO_FPS_D(7) GPBO_FPS_D(8)
+    GPBO_FPS_D(9) GPBO_FPS_D(10) GPBO_FPS_D(11) GPBO_FPS_D(12) GPBO_FPS_D(13) GPBO_FPS_D(14) GPBO_FPS_D(15) GPBO_FPS_D(16)
+    if (!launched) GPBO_FPS(0, 1);
+#undef GPBO_FPS_D
+#undef GPBO_FPS
+    const int64_t tot = Ns * d;
+    hipLaunchKernelGGL(gather_obs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, (int)d, perm_out, Ns, Xsub_out);
+    GPBO_CHECK_LAUNCH();
+    if (hipMemsetAsync(ysub, 0, sizeof(double) * Ns, st) != hipSuccess) return GPBO_ERR_LAUNCH;
+    // the subset's own factor: K_SS + jitter as the full problem's, Ns is its own padded size (every row is a member)
+    return gpbo_factorise_f64(Xsub_out, ysub, Ns, d, ls_host, jitter1, jitter2, Ns, Ksub, Usub_out, asub, info, w + L.fact_off,
+                              L.fact_bytes, stream);
+}

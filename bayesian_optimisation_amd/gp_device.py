@@ -143,6 +143,7 @@ class DeviceGP:
                 self._work_fact = None
             self._u32_valid = False
             self._u8_valid = False
+            self._bound_subset = None  # the prefix bound's observation subset belongs to one factorisation
             wbytes = int(self.lib.gpbo_factorise_workspace_bytes(Np))
             if self._work_fact is None or self._work_fact.numel() * 8 < wbytes:
                 self._work_fact = torch.empty(wbytes // 8, dtype=torch.float64, device=self.device)
@@ -222,6 +223,7 @@ class DeviceGP:
                 torch.cuda.current_stream(self.device).synchronize()  # xn / yn / work must outlive the kernels
             self.N = N + 1
             self.n_appended += 1
+            self._bound_subset = None
             del work
         return self
 
@@ -501,9 +503,40 @@ class DeviceGP:
     BOUND_PREFIX_FRACTION = 16  # first pass over the first Np / 16 observations' columns (1/256 of the variance product);
                                 # survivors get a second bound from four times as many before the fp64 kernels see them
 
+    def _ensure_bound_subset(self, J: int, J2: int):
+        """(Xsub, Usub, Ns): the observation subset of the prefix bound for this factorisation - J members by farthest-point
+        sampling in length-scale units, extended to J2 by index order (csrc/subset.hip), with its own factor
+        chol(K_SS)^-T.  Built once per factorisation and (J, J2); None when the subset would not fit (Ns > N)."""
+        torch = self.torch
+        Ns = max(J, J2)
+        if Ns > self.N:
+            return None
+        cur = getattr(self, "_bound_subset", None)
+        if cur is not None and cur[0] == (J, J2):
+            return cur[1]
+        with torch.cuda.device(self.device):
+            perm = torch.empty(Ns, dtype=torch.int64, device=self.device)
+            Xsub = torch.empty((Ns, self.d), dtype=torch.float64, device=self.device)
+            Usub = torch.empty((Ns, Ns), dtype=torch.float64, device=self.device)
+            info = torch.zeros(1, dtype=torch.int32, device=self.device)
+            wbytes = int(self.lib.gpbo_bound_subset_workspace_bytes(self.N, Ns))
+            if wbytes < 0:
+                raise _lib.GpboError("gpbo_bound_subset_workspace_bytes: invalid sizes")
+            if getattr(self, "_work_subset", None) is None or self._work_subset.numel() * 8 < wbytes:
+                self._work_subset = torch.empty((wbytes + 7) // 8, dtype=torch.float64, device=self.device)
+            st = self.lib.gpbo_bound_subset_f64(self._ptr(self.X), self.N, self.d, self.ls_h.ctypes.data_as(C.c_void_p),
+                                                self.jitter1, self.jitter2, J, J2, self._ptr(perm), self._ptr(Xsub),
+                                                self._ptr(Usub), self._ptr(info), self._ptr(self._work_subset), wbytes,
+                                                self._stream())
+            _lib.check(st, "gpbo_bound_subset_f64")
+        sub = (Xsub, Usub, Ns, perm, info)
+        self._bound_subset = ((J, J2), sub)
+        return sub
+
     def score_async_bound(self, Xs, acquisition: str = "lcb", explore: float = 4.0, f_best: Optional[float] = None,
                           xi: float = 0.0, dense: bool = False, idx_offset: int = 0, diag_add: float = 0.0,
-                          prior_var: float = PRIOR_VAR, prefix: Optional[int] = None, prefix2: Optional[int] = None):
+                          prior_var: float = PRIOR_VAR, prefix: Optional[int] = None, prefix2: Optional[int] = None,
+                          subset: str = "fps"):
         """The selected point WITHOUT the variance of every candidate - exact, all fp64.  The squared norm of the first J
         components of v_c = U^T k_c is the variance reduction from the first J observations alone, so
         sqrt(prior_var - |v_c[:J]|^2) >= cov_func_c and (both acquisitions increase with sigma) an UPPER bound of the
@@ -512,6 +545,8 @@ class DeviceGP:
         (gpbo_posterior_prefix_f64 + gpbo_bound_select_f64).  The mean is still computed for every candidate.
         Falls back to score_async when the bound cannot be used (dense outputs wanted, LCB with a negative weight, the
         N == M diagonal quirk, fewer than 3 column blocks) or does not separate the candidates (flat mean, ties).
+        subset="fps" (default): "the first J observations" are J members chosen by farthest-point sampling, so the bound
+        does not depend on the order in which the observations arrived; subset="arrival": the literal prefix (round 2).
         Synchronises; `last_screen` keeps the statistics."""
         torch = self.torch
         Xsd = self._dev(Xs)
@@ -545,12 +580,25 @@ class DeviceGP:
             if getattr(self, "_bound_ub", None) is None or self._bound_ub.numel() < M:
                 self._bound_ub = torch.empty(M, dtype=torch.float64, device=self.device)
             lsp = self.ls_h.ctypes.data_as(C.c_void_p)
-            st = self.lib.gpbo_posterior_prefix_f64(
-                self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d, lsp, self._ptr(self.U),
-                self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), chunk, J, None, None,
-                self._ptr(self._bound_ub), self._ptr(self._result), self._ptr(self._work_post), wbytes,
-                self._profile if self.profile_active else None, self._stream())
-            _lib.check(st, "gpbo_posterior_prefix_f64")
+            if subset not in ("fps", "arrival"):
+                raise ValueError("subset must be 'fps' or 'arrival'")
+            sub = self._ensure_bound_subset(J, J2) if subset == "fps" else None
+            if sub is not None and int(sub[4].item()) != 0:
+                sub = None  # K_SS not positive definite at this jitter (duplicated members): the literal prefix instead
+            if sub is not None:
+                st = self.lib.gpbo_posterior_prefix_subset_f64(
+                    self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d, lsp, self._ptr(self.U),
+                    self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), chunk, J, self._ptr(sub[0]), sub[2],
+                    sub[2], self._ptr(sub[1]), None, None, self._ptr(self._bound_ub), self._ptr(self._result),
+                    self._ptr(self._work_post), wbytes, self._profile if self.profile_active else None, self._stream())
+                _lib.check(st, "gpbo_posterior_prefix_subset_f64")
+            else:
+                st = self.lib.gpbo_posterior_prefix_f64(
+                    self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d, lsp, self._ptr(self.U),
+                    self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), chunk, J, None, None,
+                    self._ptr(self._bound_ub), self._ptr(self._result), self._ptr(self._work_post), wbytes,
+                    self._profile if self.profile_active else None, self._stream())
+                _lib.check(st, "gpbo_posterior_prefix_f64")
             cap = self.screen_cap if self.screen_cap else max(4096, min(M, max(M // 16, 1 << 16)))
             chunk64 = self.SCREEN_CHUNK64
             rbytes = int(self.lib.gpbo_rescore_workspace_bytes(self.Np, cap, chunk64))
@@ -560,13 +608,21 @@ class DeviceGP:
                 self._work_rescore = torch.empty((rbytes + 7) // 8, dtype=torch.float64, device=self.device)
             stats = _lib.ScreenStats()
             stride = max(1, M // self.SCREEN_SAMPLE)
-            st = self.lib.gpbo_bound_select_f64(
-                self._ptr(Xsd), M, self._ptr(self._bound_ub), self._ptr(self.X), self.N, self.Np, self.d, lsp,
-                self._ptr(self.U), self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), stride, cap,
-                chunk64, J2, self._ptr(self._result), C.byref(stats), self._ptr(self._work_rescore), rbytes,
-                self._stream())
-            _lib.check(st, "gpbo_bound_select_f64")
-            self.last_screen = dict(mode="bound", prefix=J, prefix2=J2, survivors=int(stats.survivors), rescored=int(stats.rescored),
+            if sub is not None:
+                st = self.lib.gpbo_bound_select_subset_f64(
+                    self._ptr(Xsd), M, self._ptr(self._bound_ub), self._ptr(self.X), self.N, self.Np, self.d, lsp,
+                    self._ptr(self.U), self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), stride, cap,
+                    chunk64, J2, self._ptr(sub[0]), sub[2], sub[2], self._ptr(sub[1]), self._ptr(self._result),
+                    C.byref(stats), self._ptr(self._work_rescore), rbytes, self._stream())
+                _lib.check(st, "gpbo_bound_select_subset_f64")
+            else:
+                st = self.lib.gpbo_bound_select_f64(
+                    self._ptr(Xsd), M, self._ptr(self._bound_ub), self._ptr(self.X), self.N, self.Np, self.d, lsp,
+                    self._ptr(self.U), self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), stride, cap,
+                    chunk64, J2, self._ptr(self._result), C.byref(stats), self._ptr(self._work_rescore), rbytes,
+                    self._stream())
+                _lib.check(st, "gpbo_bound_select_f64")
+            self.last_screen = dict(mode="bound", subset="fps" if sub is not None else "arrival", prefix=J, prefix2=J2, survivors=int(stats.survivors), rescored=int(stats.rescored),
                                     rounds=int(stats.rounds), fallback=bool(stats.fallback), threshold=float(stats.tau),
                                     candidates=M)
         self._keep = Xsd

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../bayesian_optimisation_amd/csrc"
 mkdir -p ../../ab_libs build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $EXTRA -c $FILE.hip -o build/${FILE}_$NAME.o
 objs=""
-for f in api kernel_build kstar_mfma gemm_f64 factor cholinv update sigma_acq ard posterior_f32 rescore ozaki host_api; do
+for f in api kernel_build kstar_mfma gemm_f64 factor cholinv subset update sigma_acq ard posterior_f32 rescore ozaki host_api; do
   if [ $f = $FILE ]; then objs="$objs build/${FILE}_$NAME.o"; else objs="$objs build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab_libs/$NAME.so $objs

@@ -53,7 +53,7 @@ while time.time() < t_end:
             args = {}
         if args.get("prefix2", 0) > gp.Np:
             args["prefix2"] = 0
-        r = gp.score_bound(Xs, idx_offset=5, **kw, **args)
+        r = gp.score_bound(Xs, idx_offset=5, subset=str(rng.choice(["fps", "fps", "arrival"])), **kw, **args)
         st = dict(gp.last_screen)
         r64 = gp.score(Xs, idx_offset=5, **kw)
         n_fallback += bool(st.get("fallback"))
