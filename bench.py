@@ -39,6 +39,7 @@ I8C_SLICE_PRODUCTS = 6     # the coarse screen: three digits per operand, diagon
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak = fp64 vector peak (half the 157.3 TF fp32 rate
 #                               listed in MI355X_MICROARCH.md; AMD data sheet value)
 HBM_PEAK_GBS = 8000.0
+VALU_F64_PEAK_TLANE = 33.0  # fp64 vector lane-instructions/s (x1e12) the chip sustains: tools/valu_f64_peak.hip (66 TFLOP/s FMA)
 
 
 def parse_args(argv=None):
@@ -322,16 +323,31 @@ def main():
         if ks_launches:
             ks_avg = ks_ms / ks_launches
             bytes_per_cand = {"f32": 4.0, "i8": 5.0, "i8c": 3.0}.get(args.dtype, 8.0) * N + 8.0 * d
-            if bnd:   # K*^T is stored for the first J observations only: the kernel is fp64-VALU-bound, not HBM-bound
-                bytes_per_cand = 8.0 * float((gp.last_screen or {}).get("prefix", N)) + 8.0 * d
-            gbs = bytes_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e9
-            kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                                  frac=round(gbs / HBM_PEAK_GBS, 4),
-                                  kernel={"f32": "kstar_mu_kernel<..., float>", "i8": "kstar_slices_kernel<..., 5>",
-                                          "i8c": "kstar_slices_kernel<..., 3>",
-                                          "f64b": "kstar_mu_mfma_kernel"}.get(args.dtype, "kstar_mu_kernel"),
-                                  launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
-                                  bytes_per_candidate=bytes_per_cand)
+            if bnd:
+                # The prefix-bound route's K(X*,X) interval = kstar_mu_mfma_kernel (the mean of all N observations: 19 fp64
+                # VALU instructions per (candidate, observation) pair beside 2 fp64 MFMAs per 256 pairs) +
+                # kstar_mu_kernel on the J stored rows (41 per pair).  It writes J rows, not N: the bound is the vector
+                # fp64 issue rate (33 T lane-instructions/s measured by tools/valu_f64_peak.hip), not HBM.  The MFMAs do not
+                # run beside fp64 VALU on gfx950 (32 of the ~108 cycles per pair and lane), so frac cannot reach 1.
+                Jp = float((gp.last_screen or {}).get("prefix", N))
+                lane_instr_per_cand = 19.0 * N + 41.0 * Jp
+                tli = lane_instr_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e12
+                kstar_roofline = dict(bound="valu", achieved=round(tli, 2), peak=VALU_F64_PEAK_TLANE,
+                                      unit="T lane-instructions/s (fp64 VALU)", frac=round(tli / VALU_F64_PEAK_TLANE, 4),
+                                      kernel="kstar_mu_mfma_kernel + kstar_mu_kernel on the stored rows",
+                                      launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
+                                      lane_instructions_per_candidate=lane_instr_per_cand,
+                                      note="static instruction counts per pair (ISA of the two kernels); the 2 fp64 MFMAs per 256 "
+                                           "pairs of the first kernel occupy the SIMD for 32 of ~108 cycles per pair and lane and "
+                                           "do not overlap with fp64 VALU on gfx950")
+            else:
+                gbs = bytes_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e9
+                kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                      frac=round(gbs / HBM_PEAK_GBS, 4),
+                                      kernel={"f32": "kstar_mu_kernel<..., float>", "i8": "kstar_slices_kernel<..., 5>",
+                                              "i8c": "kstar_slices_kernel<..., 3>"}.get(args.dtype, "kstar_mu_kernel"),
+                                      launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
+                                      bytes_per_candidate=bytes_per_cand)
 
     # time of the scoring part alone (factorisation excluded), for the record
     fence()
@@ -405,9 +421,22 @@ def main():
                 gp.score_async_bound(Xsd, **kwb)
                 v, i, n, info = D.allreduce_status(gp.status)
             ms = (time.perf_counter() - t) / reps2 * 1e3
+            # how many candidates the bound fails to dispose of, by acquisition (one untimed call each): the route's speed
+            # depends on the data and on the exploration weight - LCB with a large weight is the hard case
+            surv = {}
+            for name, kwx in (("lcb_explore_1", dict(acquisition="lcb", explore=1.0)),
+                              ("lcb_explore_4", dict(acquisition="lcb", explore=4.0)),
+                              ("lcb_explore_10", dict(acquisition="lcb", explore=10.0)),
+                              ("ei", dict(acquisition="ei", f_best=f_best, xi=0.0))):
+                rb = gp.score_bound(Xsd, idx_offset=lo, **kwx)
+                r6 = gp.score(Xsd, idx_offset=lo, **kwx)
+                ls_ = gp.last_screen or {}
+                surv[name] = dict(survivors_first_level=ls_.get("survivors"), rescored_in_fp64=ls_.get("rescored"),
+                                  fallback=ls_.get("fallback"), same_point_as_plain_pass=bool(rb.best_idx == r6.best_idx))
+            gp.score_async_bound(Xsd, **kwb)
             res["prefix_bound_screen_same_workload"] = dict(
-                value=(hi - lo) / (ms * 1e-3), unit="candidates/s", ms_per_step=ms, argmax_index=i,
-                argmax_matches_fp64=bool(i == best[1]), steps=reps2, screen=gp.last_screen,
+                value=(hi - lo) / (ms * 1e-3), unit="candidates disposed/s", ms_per_step=ms, argmax_index=i,
+                argmax_matches_fp64=bool(i == best[1]), steps=reps2, screen=gp.last_screen, survivors_by_acquisition=surv,
                 note="fp64 throughout, exact: the mean of every candidate, an UPPER bound of its acquisition from |v|^2 over the "
                      "first N/16 components (1/256 of the variance product; N/4 for the survivors), the fp64 kernels on every "
                      "candidate whose bound reaches the best exact value seen; pruned candidates provably cannot be the "
@@ -427,8 +456,10 @@ def main():
                     v, i, n, info = D.allreduce_status(gp.status)
                 ms = (time.perf_counter() - t) / reps2 * 1e3
                 res["prefix_bound_screen_ei_same_workload"] = dict(
-                    value=(hi - lo) / (ms * 1e-3), unit="EI evaluations/s", ms_per_step=ms, argmax_index=i,
-                    argmax_matches_fp64=bool(i == i64), steps=reps2, screen=gp.last_screen)
+                    value=(hi - lo) / (ms * 1e-3), unit="candidates disposed/s", ms_per_step=ms, argmax_index=i,
+                    argmax_matches_fp64=bool(i == i64), steps=reps2, screen=gp.last_screen,
+                    note="EI is EVALUATED for the candidates the fp64 kernels re-score (screen.rescored) and bounded from above "
+                         "for all the others - a rate of candidates disposed of, exactly, not of EI evaluations")
         g1 = os.path.join(REPO, "tests", "golden", "g1_m32.npz")
         if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb") and os.path.exists(g1):
             # BASELINE configs[0] (d=2, N=32, M=32x32 grid, 50x50 ARD search - the sizes the reference's DAG runs): the

@@ -52,6 +52,9 @@ def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
     pb = line["also"]["prefix_bound_screen_same_workload"]
     assert pb["argmax_matches_fp64"] is True and not pb["screen"]["fallback"] and pb["value"] > 0
     assert pb["screen"]["mode"] == "bound" and pb["screen"]["rescored"] < (1 << 21) // 16
+    assert pb["unit"] == "candidates disposed/s" and pb["screen"]["subset"] == "fps"
+    assert set(pb["survivors_by_acquisition"]) == {"lcb_explore_1", "lcb_explore_4", "lcb_explore_10", "ei"}
+    assert all(v["same_point_as_plain_pass"] for v in pb["survivors_by_acquisition"].values())
     pe = line["also"]["prefix_bound_screen_ei_same_workload"]
     assert pe["argmax_matches_fp64"] is True and not pe["screen"]["fallback"] and pe["value"] > 0
 
@@ -81,3 +84,5 @@ def test_prefix_bound_screen_as_the_main_workload():
     assert line["roofline"]["kernel"] == "sigma_acq_kernel" and 0.05 < line["roofline"]["frac"] <= 1.0
     assert line["cpu_baseline"]["argmax_match_on_sample"] is True
     assert line["screen"]["mode"] == "bound" and not line["screen"]["fallback"]
+    kr = line["kstar_roofline"]   # the K(X*,X) interval of this route is bound by fp64 VALU issue, not by HBM
+    assert kr["bound"] == "valu" and kr["peak"] == 33.0 and 0.05 < kr["frac"] <= 1.0
