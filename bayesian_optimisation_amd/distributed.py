@@ -109,6 +109,48 @@ def gather_concat(local, total: int, group=None):
     return out
 
 
+def gather_concat_tensors(locals_, total: int, group=None):
+    """The dense outputs of a sharded call (mean_func / cov_func / acq_func_eval, which
+    /root/reference/select_parameters.py:167-169,303-305 reads) gathered WITHOUT leaving the device: `locals_` is a list of
+    k one-dimensional tensors of this rank's shard (same length, same dtype, the shard shard_bounds gives this rank);
+    they travel as one [k x padded] block per rank through all_gather_into_tensor (RCCL on nccl: device memory to
+    device memory; gloo: CPU tensors) and every rank gets k tensors of `total` rows, bytes unchanged.  Round 2 pickled
+    the host copies through all_gather_object: 3 x 134 MB per call at BASELINE config 3's M = 2^24."""
+    import torch
+    import torch.distributed as dist
+
+    locals_ = [t.contiguous() for t in locals_]
+    n = int(locals_[0].shape[0])
+    if any(t.dim() != 1 or int(t.shape[0]) != n or t.dtype != locals_[0].dtype for t in locals_):
+        raise ValueError("gather_concat_tensors: the shards must be one-dimensional, of one length and one dtype")
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if n != total:
+            raise ValueError("gather_concat_tensors: shard does not cover the whole array")
+        return locals_
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(total, world, rank)
+    if hi - lo != n:
+        raise ValueError(f"gather_concat_tensors: rank {rank} holds {n} rows, shard_bounds gives {hi - lo}")
+    pad = -(-total // world)  # the longest shard
+    on_device = dist.get_backend(group) == "nccl"
+    k = len(locals_)
+    dev = locals_[0].device if on_device else torch.device("cpu")
+    mine = torch.zeros((k, pad), dtype=locals_[0].dtype, device=dev)
+    for j, t in enumerate(locals_):
+        mine[j, :n] = t if on_device else t.cpu()
+    flat = torch.empty(world * k * pad, dtype=mine.dtype, device=dev)   # (flat in, flat out: what every backend accepts)
+    dist.all_gather_into_tensor(flat, mine.view(-1), group=group)
+    out = flat.view(world, k, pad)
+    full = []
+    for j in range(k):
+        parts = []
+        for r in range(world):
+            a, b = shard_bounds(total, world, r)
+            parts.append(out[r, j, : b - a])
+        full.append(torch.cat(parts))
+    return full
+
+
 def all_agree(flag: bool, group=None) -> bool:
     """True iff `flag` is true on EVERY rank (a collective decision: e.g. append-or-refactorise must be taken the same
     way everywhere, or the ranks' factors differ at rounding level and the lowest-index tie rule no longer holds).

@@ -190,10 +190,9 @@ class PointSelector:
             self._screen_ctx = None
             res = gp.score(Xs[lo:hi], acquisition="lcb", explore=4.0, dense=True, idx_offset=lo, diag_add=diag_add)
         self._mu_dev, self._sigma_dev = res.mu, res.sigma
-        mu, sigma, acq = res.mu.cpu().numpy(), res.sigma.cpu().numpy(), res.acq.cpu().numpy()
         best = D.allreduce_argmax(res.best_val, res.best_idx, res.nan_count)
-        if world > 1:
-            mu, sigma, acq = (self._gather(v, M, world) for v in (mu, sigma, acq))
+        # sharded: the three dense arrays are gathered on the device (one collective), then copied to the host once
+        mu, sigma, acq = (t.cpu().numpy() for t in D.gather_concat_tensors([res.mu, res.sigma, res.acq], M))
         fd = [int(v) for v in self.feature_domain]
         self.mean_func = mu.reshape(fd)                                   # :97
         self.cov_func = sigma.reshape(fd)                                 # :98 (a standard deviation)
@@ -368,11 +367,8 @@ class PointSelector:
             else:
                 res = self._gp.acquisition_on_posterior(self._mu_dev, self._sigma_dev, acquisition=kind,
                                                         idx_offset=lo, **kw)
-            acq = res.acq.cpu().numpy()
             best = D.allreduce_argmax(res.best_val, res.best_idx, res.nan_count)
-            world, _ = self._world()
-            if world > 1:
-                acq = self._gather(acq, int(np.prod(fd)), world)
+            acq = D.gather_concat_tensors([res.acq], int(np.prod(fd)))[0].cpu().numpy()
             self._cached[key] = (acq.reshape(fd), best)
         acq, (best_val, best_idx, nan_count) = self._cached[key]
         self.acq_func_eval = acq
@@ -405,10 +401,8 @@ class PointSelector:
         world, rank = self._world()
         blo, bhi = D.shard_bounds(M // 8, world, rank)          # whole batches per rank, contiguous
         res = self._gp.score_qei(Xs[blo * 8: bhi * 8], Z, f_best, xi=float(xi), dense=True, batch_offset=blo)
-        qei = res.acq.cpu().numpy()
         best_val, best_idx, nan_count = D.allreduce_argmax(res.best_val, res.best_idx, res.nan_count)
-        if world > 1:
-            qei = self._gather(qei, M // 8, world)
+        qei = D.gather_concat_tensors([res.acq], M // 8)[0].cpu().numpy()
         self.acq_func_eval = qei
         if nan_count > 0 or best_idx >= M // 8:
             raise IndexError("index 0 is out of bounds for axis 0 with size 0 (acquisition contains NaN)")

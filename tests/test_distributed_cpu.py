@@ -67,6 +67,18 @@ def _worker(rank, world, port, q):
 
         import torch
 
+        # the tensor form of the dense gather (what the sharded drop-in class uses: one collective for mu / sigma / acq,
+        # uneven shards - 1001 rows over 2 ranks - padded in transit and cut back, bit patterns unchanged)
+        t3 = [torch.from_numpy(np.sin(np.arange(M) * c)[lo:hi].copy()) for c in (0.11, 0.23, 0.31)]
+        g3 = D.gather_concat_tensors(t3, M)
+        ok_gather = ok_gather and all(torch.equal(g, torch.from_numpy(np.sin(np.arange(M) * c)))
+                                      for g, c in zip(g3, (0.11, 0.23, 0.31)))
+        try:
+            D.gather_concat_tensors([t3[0][:-1]], M)
+            ok_gather = False
+        except ValueError:
+            pass
+
         bits = struct.unpack("<q", struct.pack("<d", float(loc[j])))[0]
         status = torch.tensor([bits, lo + j, 0, 0, 0 if rank == 0 else 17], dtype=torch.int64)
         ok_gather = ok_gather and D.allreduce_status(status) == (5.0, 100, 0, 17)
@@ -92,6 +104,18 @@ def test_two_process_gloo_exchange():
         assert ok_gather
         assert out == (5.0, 100, 1)
         assert out2 == (float(np.nextafter(1.0, 2.0)), 0, 0)
+
+
+def test_gather_concat_tensors_without_a_process_group():
+    import torch
+
+    a, b = torch.arange(7.0, dtype=torch.float64), torch.ones(7, dtype=torch.float64)
+    out = D.gather_concat_tensors([a, b], 7)
+    assert torch.equal(out[0], a) and torch.equal(out[1], b)
+    with pytest.raises(ValueError):
+        D.gather_concat_tensors([a, b], 8)
+    with pytest.raises(ValueError):
+        D.gather_concat_tensors([a, b[:5]], 7)
 
 
 def test_gather_concat_without_a_process_group():

@@ -518,6 +518,64 @@ def test_dropin_sharded_over_two_ranks_matches_single_process():
         assert qpts == ref_qpts and np.array_equal(qei, ref_qei)
 
 
+def _sharded_big_worker(rank, world, port, q):
+    import hashlib
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, y, Xs, ls = make_problem(256, 1 << 22, 4)
+        ps = PointSelector(device="cuda:0")
+        ps.measured_pts, ps.measured_vals = X, y
+        ps.feature_domain, ps.predicted_pts = [1 << 22], Xs
+        ps.set_kernel_params(ls)
+        ps.update_surrogate()
+        idx = ps.lower_confidence_bound()
+        h = [hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() for a in (ps.mean_func, ps.cov_func, ps.acq_func_eval)]
+        q.put((rank, idx.tolist(), h, ps.mean_func.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dropin_sharded_at_m_2e22_gathers_the_dense_outputs_as_tensors():
+    """M = 2^22 candidates over two ranks (one GPU, gloo): the three dense attributes the
+    reference's caller reads (select_parameters.py:167-169) come back through ONE tensor collective per call
+    (distributed.gather_concat_tensors), identical to the single-process arrays bit for bit."""
+    import hashlib
+    import socket
+
+    import torch.multiprocessing as mp
+
+    X, y, Xs, ls = make_problem(256, 1 << 22, 4)
+    ps = PointSelector()
+    ps.measured_pts, ps.measured_vals = X, y
+    ps.feature_domain, ps.predicted_pts = [1 << 22], Xs
+    ps.set_kernel_params(ls)
+    ps.update_surrogate()
+    ref_idx = ps.lower_confidence_bound().tolist()
+    ref_h = [hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() for a in (ps.mean_func, ps.cov_func, ps.acq_func_eval)]
+    del ps
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_big_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, idx, h, shape in res:
+        assert idx == ref_idx and h == ref_h and tuple(shape) == (1 << 22,)
+
+
 def test_dropin_q_expected_improvement():
     X, y, Xs, ls = make_problem(30, 1600, 2)
     ps = PointSelector()
