@@ -16,7 +16,8 @@ ACQ_LCB = 0
 ACQ_EI = 1
 NPAD = 128
 CHUNK_GRANULE = 512
-MAX_D = 16
+MAX_D = 16          # every route
+MAX_D_ANY = 1024    # fp64 route (factorise, score): any d up to this, slow path beyond MAX_D
 I8_MAX_N = 16384
 
 _p = C.c_void_p

@@ -57,6 +57,9 @@ int gpbo_kstar_mu_mfma(const double *Xs, int64_t Mc, int64_t N, int64_t Np, int3
 int gpbo_kstar_mu_rows(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
                        const double *ls_host, const double *alpha, double diag_add, int64_t cand_base, double *KsT,
                        int64_t ldk, double *mu_part, int64_t store_rows, void *stream);
+int gpbo_kstar_mu_anyd(const double *Xs, int64_t Mc, const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host,
+                       const double *alpha, double diag_add, int64_t cand_base, double *KsT, int64_t ldk, double *mu_part,
+                       void *stream);
 int gpbo_kstar_mu_mixed(const double *Xs, int64_t Mc, const double *Xsc, int64_t N, int64_t Np, int32_t d,
                         const double *ls_host, const double *alpha, double diag_add, int64_t cand_base, float *KsT,
                         int64_t ldk, double *mu_part, void *stream);

@@ -54,7 +54,7 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
                                          double *sigma_out, double *acq_out, double *cov_meas_out, gpbo_result *result,
                                          int32_t *info) {
     if (!X || !y || !ls || !Xs || !result || !info) return GPBO_ERR_ARG;
-    if (N < 1 || M < 1 || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
+    if (N < 1 || M < 1 || d < 1 || d > GPBO_MAX_D_ANY) return GPBO_ERR_ARG;
     if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
     if (chunk == 0) chunk = (int64_t)1 << 17;
     if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
@@ -85,7 +85,7 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
     // A caller that asks for the next point only (no dense arrays) gets it by branch and bound on the exact prefix bound
     // (same point, same NaN count, the plain pass when the bound does not separate the candidates); the same
     // rule and the same prefix lengths as DeviceGP.score_bound.
-    const bool bound_route = !dense && diag_add == 0.0 && M >= 32768 && Np >= 1024 &&
+    const bool bound_route = !dense && diag_add == 0.0 && M >= 32768 && Np >= 1024 && d <= GPBO_MAX_D &&
                              (acq_kind == GPBO_ACQ_EI || p0 >= 0.0);
     const int64_t J1 = (Np / 16) / 128 * 128 < 128 ? 128 : (Np / 16) / 128 * 128, J2 = (8 * J1 <= Np) ? 4 * J1 : 0;
     int64_t bcap = M / 16;   // most survivors the fp64 kernels re-score before the plain pass takes over

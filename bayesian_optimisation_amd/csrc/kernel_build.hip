@@ -12,6 +12,7 @@
 #include "gpbo_internal.h"
 
 #include <cstdlib>
+#include <vector>
 
 struct LsArgs {
     double il2[GPBO_MAX_D];  // 1 / ls_k^2, computed on the host in fp64
@@ -248,6 +249,111 @@ __global__ __launch_bounds__(256) void scale_points_kernel(const double *__restr
     Xsc[e] = (n < N) ? X[e] * ls.isc[k] : 0.0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Any feature count (d > GPBO_MAX_D): the reference's class is "agnostic to the dimensionality of the feature space"
+// (/root/reference/point_selector.py:22, the broadcast at :180-189).  Slow path: coordinates are re-read from memory in
+// every distance instead of living in unrolled registers, the length scales come from device memory, exp() is the
+// library's.  Same layouts and semantics as kxx_kernel / kstar_mu_kernel; serves the fp64 route (factorise, score).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kxx_anyd_kernel(const double *__restrict__ X, int N, int d,
+                                                       const double *__restrict__ il2, double j1, double j2,
+                                                       double *__restrict__ K, int Np, double *__restrict__ K2, int ld2,
+                                                       int32_t *__restrict__ info0) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (info0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *info0 = 0;
+    if (j >= Np) return;
+    const int i0 = blockIdx.y * 8;
+    for (int i = i0; i < i0 + 8; ++i) {
+        double v;
+        if (i < N) {
+            double acc = 0.0;
+            if (j < N) {
+                for (int k = 0; k < d; ++k) {
+                    const double diff = X[(int64_t)j * d + k] - X[(int64_t)i * d + k];
+                    acc = fma(diff * diff, il2[k], acc);
+                }
+            }
+            v = exp(-0.5 * acc);
+            if (i == j) v = (v + j1) + j2;
+            if (j >= N) v = 0.0;
+        } else {
+            v = (i == j) ? 1.0 : 0.0;
+        }
+        K[(int64_t)i * Np + j] = v;
+        if (K2) {
+            K2[(int64_t)i * ld2 + j] = v;
+            if (ld2 >= 2 * Np) K2[(int64_t)i * ld2 + Np + j] = 0.0;
+        }
+    }
+}
+
+// grid (used / 256, Np / 64), block 256: thread = one candidate, blockIdx.y = slice of 64 observations
+__global__ __launch_bounds__(256) void kstar_mu_anyd_kernel(const double *__restrict__ Xs, int64_t Mc,
+                                                            const double *__restrict__ X, int N, int d,
+                                                            const double *__restrict__ isc,
+                                                            const double *__restrict__ alpha, double diag_add,
+                                                            int64_t cand_base, double *__restrict__ KsT, int64_t ldk,
+                                                            double *__restrict__ mu_part) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n0 = blockIdx.y * KS_SLICE;
+    const bool valid = c < Mc;
+    double mu = 0.0;
+    for (int n = n0; n < n0 + KS_SLICE; ++n) {
+        double kv = 0.0;
+        if (n < N && valid) {
+            double t = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double df = (Xs[c * d + k] - X[(int64_t)n * d + k]) * isc[k];   // NaN coordinates poison the row
+                t = fma(df, df, t);
+            }
+            kv = exp(-t);
+            if (diag_add != 0.0 && (int64_t)n == cand_base + c) kv += diag_add;
+            mu = fma(kv, alpha[n], mu);
+        }
+        KsT[(int64_t)n * ldk + c] = kv;
+    }
+    mu_part[(int64_t)blockIdx.y * ldk + c] = mu;
+}
+
+// length-scale factors of an any-d call in a stream-ordered device allocation: [0, d) = 1 / ls^2, [d, 2 d) = 1 / (ls sqrt 2)
+static int make_ls_anyd(const double *ls_host, int d, hipStream_t st, double **dev_out) {
+    if (!ls_host || d < 1 || d > GPBO_MAX_D_ANY) return GPBO_ERR_ARG;
+    std::vector<double> h(2 * (size_t)d);
+    for (int k = 0; k < d; ++k) {
+        const double l = ls_host[k];
+        if (!(l > 0.0)) return GPBO_ERR_ARG;
+        h[k] = 1.0 / (l * l);
+        h[d + k] = 1.0 / (l * 1.4142135623730950488);
+    }
+    double *p = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&p), sizeof(double) * 2 * d, st) != hipSuccess) return GPBO_ERR_LAUNCH;
+    // (pageable source: the runtime stages the bytes before the call returns, so `h` may go out of scope)
+    if (hipMemcpyAsync(p, h.data(), sizeof(double) * 2 * d, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipFreeAsync(p, st);
+        return GPBO_ERR_LAUNCH;
+    }
+    *dev_out = p;
+    return GPBO_OK;
+}
+
+int gpbo_kstar_mu_anyd(const double *Xs, int64_t Mc, const double *X, int64_t N, int64_t Np, int32_t d, const double *ls_host,
+                       const double *alpha, double diag_add, int64_t cand_base, double *KsT, int64_t ldk, double *mu_part,
+                       void *stream) {
+    if (!Xs || !X || !alpha || !KsT || !mu_part) return GPBO_ERR_ARG;
+    if (Mc < 1 || N < 1 || Np < N || Np % 128 != 0 || ldk % GPBO_CHUNK_GRANULE != 0 || Mc > ldk) return GPBO_ERR_ARG;
+    hipStream_t st = gpbo_stream(stream);
+    double *lsd = nullptr;
+    int rc = make_ls_anyd(ls_host, d, st, &lsd);
+    if (rc != GPBO_OK) return rc;
+    const int64_t used = (Mc + GPBO_CHUNK_GRANULE - 1) / GPBO_CHUNK_GRANULE * GPBO_CHUNK_GRANULE;
+    hipLaunchKernelGGL(kstar_mu_anyd_kernel, dim3((unsigned)(used / 256), (unsigned)(Np / KS_SLICE)), dim3(256), 0, st, Xs, Mc, X,
+                       (int)N, (int)d, lsd + d, alpha, diag_add, cand_base, KsT, ldk, mu_part);
+    const bool ok = hipGetLastError() == hipSuccess;
+    (void)hipFreeAsync(lsd, st);
+    return ok ? GPBO_OK : GPBO_ERR_LAUNCH;
+}
+
 static int make_ls(const double *ls_host, int d, LsArgs *out) {
     if (!ls_host || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
     for (int k = 0; k < GPBO_MAX_D; ++k) out->il2[k] = out->isc[k] = 0.0;
@@ -285,6 +391,18 @@ int gpbo_kxx_launch(const double *X, int64_t N, int32_t d, const double *ls_host
                     double *Kp, int64_t Np, double *K2, int64_t ld2, int32_t *info0, void *stream) {
     if (!X || !Kp || N < 1 || Np < N || Np % 64 != 0 || Np > (1 << 20)) return GPBO_ERR_ARG;
     if (K2 && (ld2 < Np || ld2 > (1 << 21))) return GPBO_ERR_ARG;
+    if (d > GPBO_MAX_D) {  // any feature count: the slow path
+        hipStream_t st = gpbo_stream(stream);
+        double *lsd = nullptr;
+        int rc0 = make_ls_anyd(ls_host, d, st, &lsd);
+        if (rc0 != GPBO_OK) return rc0;
+        dim3 g((unsigned)((Np + 255) / 256), (unsigned)(Np / 8));
+        hipLaunchKernelGGL(kxx_anyd_kernel, g, dim3(256), 0, st, X, (int)N, (int)d, lsd, jitter1, jitter2, Kp, (int)Np, K2,
+                           (int)ld2, info0);
+        const bool ok = hipGetLastError() == hipSuccess;
+        (void)hipFreeAsync(lsd, st);
+        return ok ? GPBO_OK : GPBO_ERR_LAUNCH;
+    }
     LsArgs ls;
     int rc = make_ls(ls_host, d, &ls);
     if (rc != GPBO_OK) return rc;

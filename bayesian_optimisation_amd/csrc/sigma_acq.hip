@@ -799,7 +799,11 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
     const bool use_sub = sub && kstar_mfma;
     const double *Uv = use_sub ? sub->U : U;
     const int64_t Npv = use_sub ? sub->Np : Np, Nv = use_sub ? sub->N : N;
-    {
+    const bool anyd = d > GPBO_MAX_D;   // slow path of the fp64 route: no unrolled registers, no pre-scaled copy
+    if (anyd && (n_prefix > 0 || d > GPBO_MAX_D_ANY)) return GPBO_ERR_ARG;
+    if (anyd) {
+        if (hipMemsetAsync(nan_count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
+    } else {
         // observations / (ls sqrt 2), once per call; the same launch clears the NaN counter.  With a subset the scaled
         // points serve the stored rows only (the mean's launch has its own operands), so they are the subset's.
         int rc0 = gpbo_scale_points_launch(use_sub ? sub->X : X, Nv, Npv, d, ls_host, Xsc, nan_count, stream);
@@ -865,6 +869,9 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
             //  slab that the prefix mode neither writes nor reads, [n_prefix, n_prefix + n_prefix / 64))
             rc = gpbo_kstar_mu_rows(Xs + s * d, Mc, Xsc, nrow, n_prefix, d, ls_host, alpha, 0.0, idx_offset + s, KsT[b], chunk,
                                     KsT[b] + n_prefix * chunk, n_prefix, ks);
+        } else if (anyd) {
+            rc = gpbo_kstar_mu_anyd(Xs + s * d, Mc, X, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT[b], chunk,
+                                    mu_part[b], ks);
         } else {
             rc = gpbo_kstar_mu_rows(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, diag_add, idx_offset + s, KsT[b], chunk,
                                     mu_part[b], n_prefix ? n_prefix : Np, ks);

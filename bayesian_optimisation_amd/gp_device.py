@@ -119,8 +119,8 @@ class DeviceGP:
         if Xd.dim() != 2:
             raise ValueError("X must be (N, d)")
         N, d = int(Xd.shape[0]), int(Xd.shape[1])
-        if d > _lib.MAX_D:
-            raise ValueError(f"d = {d} > {_lib.MAX_D} is not supported by the compiled kernels")
+        if d > _lib.MAX_D_ANY:
+            raise ValueError(f"d = {d} > {_lib.MAX_D_ANY} is not supported")
         yd = self._dev(y).reshape(-1)
         if yd.numel() != N:
             raise ValueError("y must have one value per row of X")
@@ -161,6 +161,13 @@ class DeviceGP:
                         "the reference's np.linalg.inv would raise or return garbage here")
         return self
 
+    def _need_unrolled_d(self, what: str):
+        """d > 16 runs on the slow any-d kernels, which serve factorise() and score() only (point_selector.py:22: the
+        reference's class takes any feature count; its call path is exactly those two)."""
+        if self.d > _lib.MAX_D:
+            raise ValueError(f"{what} needs d <= {_lib.MAX_D} (d = {self.d}): beyond that only factorise() and the plain fp64 "
+                             "score() are available")
+
     # -- one more observation without refactorising (SURVEY.md §8f rank 4) ---------------------------------
     def _grow(self, Np_new: int):
         """Re-pad the factors into [Np_new x Np_new] buffers (identity on the new part of the diagonal)."""
@@ -185,6 +192,7 @@ class DeviceGP:
         An appended column goes through the explicit inverse factor (l = U^T k), so it carries cond(L) eps of
         relative error where the blocked Cholesky is backward stable: `n_appended` counts the columns built this way
         since the last full factorisation, for callers that want to refresh after a while (PointSelector does)."""
+        self._need_unrolled_d("append()")
         torch = self.torch
         if self.N < 1:
             raise _lib.GpboError("append() needs a factorised surrogate")
@@ -376,6 +384,7 @@ class DeviceGP:
     SCREEN_TAU0_I8C = 1e-3      # coarse int8 screen (three digits per operand): |var64 - var| ~ 2e-4 at N = 4096
 
     def _score_screened(self, mode, Xs, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var):
+        self._need_unrolled_d(f"the {mode} screen")
         """A reduced-cost pass over all rows of Xs (mode "f32": fp32 matrix cores; "i8": int8 slices on the integer
         matrix cores), then the fp64 decision (gpbo_rescore_f64): the result record holds the fp64 kernels' maximum and
         its lowest index.  Dense outputs (mu exactly the fp64 path's; sigma / acq with the screen's variance) are
@@ -549,6 +558,9 @@ class DeviceGP:
         does not depend on the order in which the observations arrived; subset="arrival": the literal prefix (round 2).
         Synchronises; `last_screen` keeps the statistics."""
         torch = self.torch
+        if self.d > _lib.MAX_D:   # the slow any-d kernels serve the plain pass only
+            self.last_screen = dict(mode="bound", fallback=True, reason="d > 16")
+            return self.score_async(Xs, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var)
         Xsd = self._dev(Xs)
         if Xsd.dim() != 2 or int(Xsd.shape[1]) != self.d:
             raise ValueError("Xs must be (M, d) with the same d as X")
@@ -640,6 +652,7 @@ class DeviceGP:
                         prior_var: float = PRIOR_VAR):
         """Enqueue qEI over consecutive batches of 8 rows of Xs; Z = [S x 8] base samples; no host sync.
         Returns (result_tensor, qei or None); the result's best_idx is a BATCH index."""
+        self._need_unrolled_d("qEI")
         torch = self.torch
         Xsd, Zd = self._dev(Xs), self._dev(Z)
         M, S = int(Xsd.shape[0]), int(Zd.shape[0])

@@ -27,14 +27,15 @@
 extern "C" {
 #endif
 
-#define GPBO_VERSION 122 /* 0.2.0: fp32 screen + fp64 re-score (gpbo_rescore_f64), gpbo_posterior_acq_f32 changed */
+#define GPBO_VERSION 130 /* 0.3.0: fused Cholesky + inverse factor (gpbo_cholinv_*), bound on an observation subset (gpbo_*_subset_f64), any d on the fp64 route */
 
 #define GPBO_OK 0
 #define GPBO_ERR_ARG (-1)      /* null pointer, bad size/alignment, unsupported d */
 #define GPBO_ERR_LAUNCH (-2)   /* HIP reported a launch/runtime error */
 #define GPBO_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define GPBO_MAX_D 16          /* compile-time-unrolled feature counts 1..16 */
+#define GPBO_MAX_D 16          /* compile-time-unrolled feature counts 1..16 (every route) */
+#define GPBO_MAX_D_ANY 1024    /* fp64 route only (kxx, factorise, posterior_acq_f64, select_next_host): any d up to this, slow path */
 #define GPBO_NPAD 128          /* observation padding granule (column-block width of the variance kernel) */
 #define GPBO_CHUNK_GRANULE 512 /* candidate-chunk granule */
 #define GPBO_CHUNK_MAX (1 << 24) /* largest chunk (16-row tile offsets inside K*^T are 32-bit element offsets) */

@@ -22,7 +22,7 @@ def _header_functions():
 def test_library_is_built_and_loads_without_gpu():
     assert os.path.exists(_lib.LIB_PATH), "run bayesian_optimisation_amd/csrc/build.sh (or __graft_entry__.build())"
     lib = _lib.load()
-    assert lib.gpbo_version() == 122
+    assert lib.gpbo_version() == 130
     assert lib.gpbo_padded_n(1) == 128 and lib.gpbo_padded_n(128) == 128 and lib.gpbo_padded_n(129) == 256
     assert b"workspace" in lib.gpbo_strerror(-3)
 
@@ -163,3 +163,31 @@ def test_loader_refuses_a_second_hip_runtime():
     assert out.returncode == 0, out.stderr[-1500:]
     # either PyTorch is absent / shares the system runtime (one copy mapped: fine) or the clash is reported
     assert out.stdout.strip() in ("refused", "loaded 1"), out.stdout
+
+
+def test_build_from_a_clean_tree(tmp_path):
+    """The build recipe of __graft_entry__.build() (csrc/build.sh) on a tree that has neither objects nor a library:
+    every translation unit compiles for gfx950 and the fresh library exports every symbol of include/gpbo.h."""
+    import shutil
+    import subprocess
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc in this environment")
+    src = os.path.join(REPO, "bayesian_optimisation_amd", "csrc")
+    dst = tmp_path / "bayesian_optimisation_amd" / "csrc"
+    dst.mkdir(parents=True)
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h", ".sh")):
+            shutil.copy(os.path.join(src, f), dst / f)
+    (tmp_path / "include").mkdir()
+    shutil.copy(os.path.join(REPO, "include", "gpbo.h"), tmp_path / "include" / "gpbo.h")
+    assert not (dst / "build").exists()
+    subprocess.run(["bash", str(dst / "build.sh")], check=True, capture_output=True, timeout=900)
+    lib = tmp_path / "bayesian_optimisation_amd" / "libgpbo.so"
+    assert lib.exists()
+    raw = ctypes.CDLL(str(lib))
+    for n in _header_functions():
+        assert hasattr(raw, n), n
+    raw.gpbo_version.restype = ctypes.c_int
+    assert raw.gpbo_version() == _lib.load().gpbo_version()

@@ -446,10 +446,51 @@ def test_every_feature_count(d):
     assert np.max(np.abs(r32.mu.cpu().numpy() - mu_o)) <= 5e-3 * max(1.0, np.abs(y).max())
 
 
+@pytest.mark.parametrize("N,M,d", [(60, 3000, 17), (300, 5000, 40), (33, 700, 130)])
+def test_any_feature_count_on_the_fp64_route(N, M, d):
+    """point_selector.py:22: the reference's class is agnostic to the dimensionality of the feature space.  Beyond the 16
+    unrolled feature counts the fp64 route runs on the slow any-d kernels: same tolerances against the oracle, same
+    selected point, chunk invariance; the other routes say so instead of mis-computing."""
+    rng = np.random.default_rng(d)
+    X = rng.uniform(0, 1, (N, d))
+    Xs = rng.uniform(0, 1, (M, d))
+    y = rng.standard_normal(N)
+    ls = np.exp(rng.uniform(np.log(0.8), np.log(3.0), d)) * np.sqrt(d / 8.0)
+    gp = DeviceGP(chunk=1024).factorise(X, y, ls)
+    r = gp.score(Xs, dense=True, idx_offset=3)
+    mu, sig, acq = (t.cpu().numpy() for t in (r.mu, r.sigma, r.acq))
+    mu_o, sig_o = O.posterior_chol(X, y, Xs, ls)
+    acq_o = O.lcb(mu_o, sig_o, 4)
+    assert np.max(np.abs(mu - mu_o)) <= 1e-10 * max(1.0, np.abs(y).max()) and np.max(np.abs(sig - sig_o)) <= 1e-9
+    assert r.best_idx == 3 + _first_argmax(acq) and r.nan_count == 0
+    top2 = np.sort(acq_o)[-2:]
+    if top2[1] - top2[0] > 1e-7:
+        assert r.best_idx == 3 + _first_argmax(acq_o)
+    np.testing.assert_allclose(gp.cov_meas_host(), O.kernel_rbf(X, X, ls) + 1e-6 * np.eye(N), rtol=0, atol=5e-15)
+    r2 = DeviceGP(chunk=512).factorise(X, y, ls).score(Xs, dense=True, idx_offset=3)
+    assert np.array_equal(r2.acq.cpu().numpy(), acq) and r2.best_idx == r.best_idx
+    e = gp.score(Xs, acquisition="ei", f_best=float(y.min()), xi=0.0, dense=True)
+    ei_o = O.expected_improvement(mu_o, sig_o, float(y.min()), 0.0)
+    assert np.max(np.abs(e.acq.cpu().numpy() - ei_o)) <= 1e-8 * max(1.0, np.abs(y).max())
+    # the drop-in class on the same data (the reference's call path is exactly factorise + LCB)
+    ps = PointSelector()
+    ps.measured_pts, ps.measured_vals = X, y
+    ps.feature_domain, ps.predicted_pts = [M], Xs
+    ps.set_kernel_params(ls)
+    ps.update_surrogate()
+    assert ps.lower_confidence_bound()[0] == _first_argmax(acq) and np.array_equal(ps.mean_func, mu)
+    # routes that need the unrolled kernels refuse; the bound route hands over to the plain pass
+    for call in (lambda: gp.score_f32(Xs), lambda: gp.score_i8(Xs), lambda: gp.score_i8c(Xs), lambda: gp.append(X[0], 0.0)):
+        with pytest.raises(ValueError):
+            call()
+    rb = gp.score_bound(Xs, idx_offset=3)
+    assert rb.best_idx == r.best_idx and gp.last_screen["fallback"]
+
+
 def test_unsupported_feature_count_raises():
-    X, y, Xs, ls = make_problem(10, 20, 17)
+    X, y, Xs, ls = make_problem(10, 20, 2)
     with pytest.raises(ValueError):
-        DeviceGP().factorise(X, y, ls)
+        DeviceGP().factorise(np.zeros((10, 1100)), y, np.ones(1100))
 
 
 # ----------------------------------------------------------------------------------------------
