@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 int gpbo_gemm_launch(int transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
                      int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double beta, double *C,
@@ -243,8 +244,12 @@ struct LookAhead {
     hipEvent_t panel_done, rest_done;
 };
 
+// (round-2 chain only - gpbo_potrf_f64 and GPBO_FACTOR_OLD=1: ONE such factorisation per device at a time; two callers on
+//  different streams would re-record the same pair of events.  The fused factorisation of round 3 has no helper stream.)
 static LookAhead *lookahead_for_current_device() {
     static LookAhead *tab[64] = {nullptr};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!tab[dev]) {

@@ -286,6 +286,11 @@ class DeviceGP:
         try:
             with os.fdopen(fd, "wb") as f:
                 np.savez(f, **self.state_dict())
+            # mkstemp creates 0600; np.savez(path) honoured the umask - a follow-up job under another account of the
+            # group must still be able to read the state, as it could before the atomic rename was introduced
+            um = os.umask(0)
+            os.umask(um)
+            os.chmod(tmp, 0o666 & ~um)
             os.replace(tmp, path)
         except BaseException:
             if os.path.exists(tmp):
@@ -509,6 +514,7 @@ class DeviceGP:
         return ScoreResult(v, i, n, mu, sigma, acq)
 
     # -- prefix-bound screen: exact branch and bound, all fp64 ---------------------------------------------------
+    ARD_KEEP_WORKSPACE_BYTES = 1 << 28   # the batched ARD workspace is dropped after a call when larger than this
     BOUND_PREFIX_FRACTION = 16  # first pass over the first Np / 16 observations' columns (1/256 of the variance product);
                                 # survivors get a second bound from four times as many before the fp64 kernels see them
 
@@ -749,7 +755,12 @@ class DeviceGP:
                                                          float(jitter), self._ptr(out), self._ptr(self._work_ard), need,
                                                          self._stream())
                 _lib.check(st, "gpbo_nlml_grid_batched_f64")
-                return out.cpu().numpy()
+                res = out.cpu().numpy()   # synchronises: the workspace is no longer in use
+                # the sub-batch workspace can be GiBs (up to 8): kept between the calls of one search (a coordinate-wise
+                # ARD search calls this once per axis and sweep) only while it is small
+                if self._work_ard.numel() * 8 > self.ARD_KEEP_WORKSPACE_BYTES:
+                    self._work_ard = None
+                return res
         with torch.cuda.device(self.device):
             out = torch.empty(G, dtype=torch.float32, device=self.device)
             st = self.lib.gpbo_nlml_grid_f64(self._ptr(Xd), self._ptr(yd), N, d, self._ptr(cells), G, float(jitter),
