@@ -348,6 +348,22 @@ def main():
                                               "i8c": "kstar_slices_kernel<..., 3>"}.get(args.dtype, "kstar_mu_kernel"),
                                       launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
                                       bytes_per_candidate=bytes_per_cand)
+                # the other resource this kernel loads: vector issue.  SQ_INSTS_VALU of the committed PMC pass of this shape
+                # (a static property of the kernel and the shape, replayed like roofline.traffic), over THIS run's launch time
+                try:
+                    shapes = json.load(open(os.path.join(REPO, "profiles", "pmc_sigma_acq.json")))
+                    key = f"N={N},d={d},dtype={args.dtype},candidates_per_launch={int(ks_cands / ks_launches)}"
+                    wi = shapes.get(key, {}).get("kstar_valu_wave_instructions_per_launch")
+                    if wi:
+                        tli = wi * 64.0 / (ks_avg * 1e-3) / 1e12
+                        kstar_roofline["valu"] = dict(
+                            lane_instructions_per_s_T=round(tli, 2), fp64_issue_peak_T=VALU_F64_PEAK_TLANE,
+                            frac=round(tli / VALU_F64_PEAK_TLANE, 4), wave_instructions_per_launch=wi,
+                            source=f"SQ_INSTS_VALU of the committed PMC pass {shapes[key]['source']}, not this run",
+                            note="the kernel issues vector instructions at this share of the measured fp64 issue ceiling WHILE "
+                                 "streaming its stores: two nearly saturated resources that do not overlap perfectly")
+                except Exception:  # noqa: BLE001
+                    pass
 
     # time of the scoring part alone (factorisation excluded), for the record
     fence()

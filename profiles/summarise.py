@@ -31,7 +31,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 keep = ("sigma_acq_kernel", "kstar_mu_kernel", "sigma_acq_f32_kernel", "sigma_i8_kernel", "sigma_i8c_kernel", "kstar_slices_kernel", "kstar_mu_mfma_kernel", "bound_select_kernel",
         "split_finish_kernel", "u_slices_kernel", "u_colscale_kernel", "potrf_diag_kernel", "gemm_f64_kernel", "kxx_kernel", "utv_kernel",
-        "uv_kernel")
+        "uv_kernel", "cholinv_kernel", "transpose_w_kernel", "fps_kernel", "gather_obs_kernel")
 with open(os.path.join(here, f"{out}_pmc_summary.csv"), "w") as fo:
     fo.write("# rocprofv3 --pmc passes (one pass per counter group, profiles/collect.sh), bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also,\n")
     fo.write(f"# MI355X; per-launch means; a sigma/kstar launch = one chunk of {cands} candidates, N={N}, d={d}, {dtype}\n")
@@ -66,6 +66,11 @@ shapes[f"N={N},d={d},dtype={dtype},candidates_per_launch={cands}"] = {
     "candidates_per_launch": cands,
     "algorithmic_bytes_per_launch": cands * w * (N + 5),  # K*^T slab once + mu partial slices read + outputs
 }
+ks = agg.get({"i8": "kstar_slices_kernel", "i8c": "kstar_slices_kernel"}.get(dtype, "kstar_mu_kernel"), {})
+if "SQ_INSTS_VALU" in ks:
+    # the K(X*,X) build beside its stores: vector instructions issued per launch (wave instructions; x64 = lane instructions)
+    shapes[f"N={N},d={d},dtype={dtype},candidates_per_launch={cands}"]["kstar_valu_wave_instructions_per_launch"] = \
+        sum(ks["SQ_INSTS_VALU"]) / len(ks["SQ_INSTS_VALU"])
 json.dump(shapes, open(path, "w"), indent=1)
 if len(sys.argv) > 3:
     line = [l for l in open(sys.argv[3]) if l.startswith("{")][-1]
