@@ -261,21 +261,23 @@ __device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int 
 // 16 x 32.  Fragments come straight from global memory, 32 k at a time (24 loads in flight per lane), the next 32 k
 // are in flight while the current ones are multiplied.
 // ---------------------------------------------------------------------------------------------------------------
+template <bool HALF>  // HALF: 64 x 32 tile (wave tile 16 x 16), else 64 x 64 (wave tile 16 x 32)
 __device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, const CiTile &u) {
     const int row0 = u.row0, col0 = u.col0;
+    constexpr int WC = HALF ? 16 : 32;  // columns per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wrow = wid & 3, wcol = wid >> 2;
     const int l15 = lane & 15, l4 = lane >> 4;
     const double *ap = S + (int64_t)(u.k0 + l4) * ld + row0 + wrow * 16 + l15;
-    const double *bp = S + (int64_t)(u.k0 + l4) * ld + col0 + wcol * 32 + l15;
-    double *cp = S + (int64_t)(row0 + wrow * 16 + l4) * ld + col0 + wcol * 32 + l15;
+    const double *bp = S + (int64_t)(u.k0 + l4) * ld + col0 + wcol * WC + l15;
+    double *cp = S + (int64_t)(row0 + wrow * 16 + l4) * ld + col0 + wcol * WC + l15;
     d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
     double c0[4], c1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         c0[r] = cp[(int64_t)(4 * r) * ld];
-        c1[r] = cp[(int64_t)(4 * r) * ld + 16];
+        c1[r] = HALF ? 0.0 : cp[(int64_t)(4 * r) * ld + 16];
     }
     constexpr int CH = 8;  // k steps (of 4) per chunk
     double fa[2][CH], fb0[2][CH], fb1[2][CH];
@@ -285,14 +287,14 @@ __device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, co
             const int64_t o = (int64_t)(kbase + 4 * s) * ld;
             fa[set][s] = ap[o];
             fb0[set][s] = bp[o];
-            fb1[set][s] = bp[o + 16];
+            if (!HALF) fb1[set][s] = bp[o + 16];
         }
     };
     auto mult = [&](int set) {
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             acc0 = mfma_f64_16x16x4(fa[set][s], fb0[set][s], acc0);
-            acc1 = mfma_f64_16x16x4(fa[set][s], fb1[set][s], acc1);
+            if (!HALF) acc1 = mfma_f64_16x16x4(fa[set][s], fb1[set][s], acc1);
         }
     };
     const int nch = u.K / (4 * CH);
@@ -308,7 +310,7 @@ __device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, co
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         cp[(int64_t)(4 * r) * ld] = c0[r] - acc0[r];
-        cp[(int64_t)(4 * r) * ld + 16] = c1[r] - acc1[r];
+        if (!HALF) cp[(int64_t)(4 * r) * ld + 16] = c1[r] - acc1[r];
     }
 }
 
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(512) void cholinv_kernel(CiArgs a) {
 #ifdef GPBO_DIAGNOSTICS
         if (a.stamps && a.l.npair == 0) ts = a.stamps + 8 * (i & 1023);  // update-only launches: every tile
 #endif
-        if (t.kind == CI_UPD_SMALL) upd_small(a.S, a.ld, t);
+        if (t.kind == CI_UPD_SMALL) { if (t.w == 32) upd_small<true>(a.S, a.ld, t); else upd_small<false>(a.S, a.ld, t); }
         else if (t.kind == CI_UPD_BIG) upd_big<2>(a.S, a.ld, a.Np, t, smem, ts);
         else if (t.kind == CI_UPD_BIG256) upd_big<4>(a.S, a.ld, a.Np, t, smem, ts);
     }
@@ -700,10 +702,10 @@ struct DevPlan {
 
 static const DevPlan *plan_for(int Np, const CiPlanOptions &o) {
     static std::mutex mu;
-    static std::map<std::array<int, 7>, DevPlan *> cache;
+    static std::map<std::array<int, 8>, DevPlan *> cache;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    const std::array<int, 7> key = {dev, Np, o.win, o.far_k, o.far_kind, o.defer, o.group_from};
+    const std::array<int, 8> key = {dev, Np, o.win, o.far_k, o.far_kind, o.defer, o.group_from, o.small_w};
     std::lock_guard<std::mutex> g(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
@@ -730,7 +732,7 @@ static bool ci_sizes_ok(const double *S, int64_t ld, int64_t Np) {
 // S: [Np x ld] row-major, ld >= 2 Np, columns [0, Np) = the symmetric positive definite matrix, [Np, 2 Np) = zeros.
 // On return columns [Np, 2 Np) hold inv(L) (lower triangular); the upper block triangle of [0, Np) holds L^T except its
 // 128 x 128 diagonal blocks.  *info (cleared by the caller on this stream) receives the 1-based index of the first bad
-// pivot.  opt: NULL or int32[6] {win, far_k, far_kind, defer + 1, max_launches, group_from + 1}, 0 = default.
+// pivot.  opt: NULL or int32[7] {win, far_k, far_kind, defer + 1, max_launches, group_from + 1, small_w}, 0 = default.
 int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int *opt, hipStream_t st) {
     if (!ci_sizes_ok(S, ld, Np) || !info) return GPBO_ERR_ARG;
     const CiPlanOptions o = ci_options_from((int)Np, opt);
@@ -805,7 +807,7 @@ extern "C" int gpbo_cholinv_plan(int64_t Np, const int32_t *opt, int64_t *n_laun
         if (*n_tile < (int64_t)P.tiles.size()) return GPBO_ERR_WORKSPACE;
         for (size_t i = 0; i < P.tiles.size(); ++i) {
             const CiTile &t = P.tiles[i];
-            const int32_t v[8] = {t.kind, t.k0, t.K, t.row0, t.col0, t.r1, t.wlim, 0};
+            const int32_t v[8] = {t.kind, t.k0, t.K, t.row0, t.col0, t.r1, t.wlim, t.w};
             for (int q = 0; q < 8; ++q) tiles[8 * i + q] = v[q];
         }
     }
@@ -833,12 +835,13 @@ extern "C" int gpbo_cholinv_tiles_f64(double *S, int64_t ld, int64_t Np, int32_t
     std::vector<CiTile> h((size_t)ntile);
     for (int64_t i = 0; i < ntile; ++i) {
         const int32_t *v = tiles + 8 * i;
-        CiTile t = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], 0};
+        CiTile t = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
         const int th = t.kind == CI_UPD_SMALL ? 64 : t.kind == CI_UPD_BIG ? 128 : t.kind == CI_UPD_BIG256 ? 256 : 0;
-        const int tw = t.kind == CI_UPD_SMALL ? 64 : 128;
+        if (t.kind == CI_UPD_SMALL && t.w != 0 && t.w != 32 && t.w != 64) return GPBO_ERR_ARG;
+        const int tw = t.kind == CI_UPD_SMALL ? (t.w == 32 ? 32 : 64) : 128;
         if (!th || t.K < (th == 64 ? 32 : 128) || t.K % 32 || t.k0 < 0 || t.k0 + t.K > t.row0 || t.row0 % 64 || t.col0 % tw ||
             t.row0 >= Np || t.col0 < 0 || t.col0 + tw > 2 * Np || t.r1 > Np || t.r1 <= t.row0 || t.wlim < 0 || t.wlim > Np ||
-            (th == 64 && (t.col0 < t.row0 || t.col0 + 64 > Np + t.wlim || t.row0 + 64 > t.r1)))
+            (th == 64 && (t.col0 < t.row0 || t.col0 + tw > Np + t.wlim || t.row0 + 64 > t.r1)))
             return GPBO_ERR_ARG;
         h[(size_t)i] = t;
     }

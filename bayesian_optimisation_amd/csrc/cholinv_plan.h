@@ -32,9 +32,9 @@ enum { CI_NONE = 0, CI_PAIR = 1, CI_UPD_SMALL = 2, CI_UPD_BIG = 3, CI_UPD_BIG256
 
 // out[rows row0.., cols col0..] -= sum_{k in [k0, k0+K)} S[k][row0 + m] * S[k][col0 + n], stores masked to rows < r1 and
 // to the live columns (col < Np: col >= 64 floor(row / 64);  col >= Np: col < Np + wlim).  SMALL: 64 x 64 (never masked),
-// BIG: 128 x 128, BIG256: 256 x 128.
+// BIG: 128 x 128, BIG256: 256 x 128.  w: width of a SMALL tile, 64 or 32 (0 = 64).
 struct CiTile {
-    int32_t kind, k0, K, row0, col0, r1, wlim, pad;
+    int32_t kind, k0, K, row0, col0, r1, wlim, w;
 };
 
 // workgroups [0, npair) = PAIR(pair) (column tile = workgroup index), then ceil(ntile / group) workgroups that take
@@ -60,6 +60,7 @@ struct CiPlanOptions {
                    // share of all the filler work of the factorisation (a dry run counts it) - the same load on every launch
     int ncu;       // compute units the packer plans for
     int group_from;  // launches with at least this many tiles per compute unit give each workgroup two tiles (0: never)
+    int small_w;     // width of the NEAR tiles: 64, or 32 (twice as many workgroups, each half as long: NEAR is on the critical path)
 };
 
 inline CiPlanOptions ci_default_options(int Np) {
@@ -69,6 +70,7 @@ inline CiPlanOptions ci_default_options(int Np) {
     o.far_kind = CI_UPD_BIG;
     o.defer = 2;
     o.ncu = 256;
+    o.small_w = (Np >= 6144) ? 64 : 32;  // measured: 32 gains 4-5 % at N <= 4096 (NEAR is on the critical path), costs 2 % at 8192
     o.group_from = 0;  // measured on MI355X: two tiles per workgroup cost N = 8192 7 % (coarser tail), gain nothing elsewhere
     return o;
 }
@@ -76,11 +78,11 @@ inline CiPlanOptions ci_default_options(int Np) {
 inline bool ci_options_ok(const CiPlanOptions &o) {
     return o.win >= 1 && o.win <= 64 && o.far_k >= 128 && o.far_k <= 1024 && o.far_k % 128 == 0 &&
            (o.far_kind == CI_UPD_BIG || o.far_kind == CI_UPD_BIG256) && o.defer >= 0 && o.defer <= 3 && o.ncu >= 1 &&
-           o.ncu <= 4096 && o.group_from >= 0;
+           o.ncu <= 4096 && o.group_from >= 0 && (o.small_w == 32 || o.small_w == 64);
 }
 
-// opt: NULL or int32[6] {win, far_k, far_kind, defer + 1, (max_launches: not a plan option), group_from + 1}; 0 keeps
-// the default
+// opt: NULL or int32[7] {win, far_k, far_kind, defer + 1, (max_launches: not a plan option), group_from + 1, small_w};
+// 0 keeps the default
 inline CiPlanOptions ci_options_from(int Np, const int32_t *opt) {
     CiPlanOptions o = ci_default_options(Np);
     if (opt) {
@@ -89,6 +91,7 @@ inline CiPlanOptions ci_options_from(int Np, const int32_t *opt) {
         if (opt[2] > 0) o.far_kind = opt[2];
         if (opt[3] > 0) o.defer = opt[3] - 1;
         if (opt[5] > 0) o.group_from = opt[5] - 1;
+        if (opt[6] > 0) o.small_w = opt[6];
     }
     return o;
 }
@@ -130,11 +133,12 @@ struct CiListSched {
 inline int ci_pair_ntiles(int Np) { return Np / 64; }
 
 // tiles of one update: target rows [row0, row0 + rows), sources [k0, k0 + K)
-inline void ci_emit_update(std::vector<CiTile> &out, int kind, int Np, int row0, int rows, int k0, int K) {
+inline void ci_emit_update(std::vector<CiTile> &out, int kind, int Np, int row0, int rows, int k0, int K, int small_w = 64) {
     const int wlim = k0 + K;  // W columns beyond the sources' own extent are zero in the source rows
     if (kind == CI_UPD_SMALL) {
         for (int b = row0 / 64; b < (row0 + rows) / 64; ++b)
-            for (int c = 64 * b; c < Np + wlim; c += 64) out.push_back(CiTile{kind, k0, K, 64 * b, c, row0 + rows, wlim, 0});
+            for (int c = 64 * b; c < Np + wlim; c += small_w)
+                out.push_back(CiTile{kind, k0, K, 64 * b, c, row0 + rows, wlim, small_w});
         return;
     }
     const int th = (kind == CI_UPD_BIG256) ? 256 : 128;
@@ -163,7 +167,7 @@ inline CiPlan ci_plan(int Np, const CiPlanOptions &o) {
     for (int p = 0; p < np; ++p) {
         if (p > 0) {  // NEAR: whatever pair p still lacks (128 rows when the fillers kept up)
             CiLaunch l = {-1, 0, (int)P.tiles.size(), 0, 1};
-            ci_emit_update(P.tiles, CI_UPD_SMALL, Np, 128 * p, 128, applied[p], 128 * p - applied[p]);
+            ci_emit_update(P.tiles, CI_UPD_SMALL, Np, 128 * p, 128, applied[p], 128 * p - applied[p], o.small_w);
             applied[p] = 128 * p;
             l.ntile = (int)P.tiles.size() - l.tile0;
             P.launches.push_back(l);

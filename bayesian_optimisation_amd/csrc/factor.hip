@@ -449,11 +449,11 @@ extern "C" int gpbo_factorise_f64(const double *X, const double *y, int64_t N, i
         double *S = L;  // [Np x 2 Np]: the same 2 Np^2 doubles
         int rc = gpbo_kxx_launch(X, N, d, ls_host, jitter1, jitter2, Kp, Np, S, 2 * Np, info, stream);
         if (rc != GPBO_OK) return rc;
-        // GPBO_CI_OPTS="win,far_k,far_kind,defer+1,group_from+1": schedule choices of the plan for A/B runs (cholinv_plan.h)
-        static int env_opt[6] = {0, 0, 0, 0, 0, 0};
+        // GPBO_CI_OPTS="win,far_k,far_kind,defer+1,group_from+1,small_w": schedule choices of the plan for A/B runs (cholinv_plan.h)
+        static int env_opt[7] = {0, 0, 0, 0, 0, 0, 0};
         static const bool have_env_opt = [] {
             const char *e = getenv("GPBO_CI_OPTS");
-            return e && sscanf(e, "%d,%d,%d,%d,%d", &env_opt[0], &env_opt[1], &env_opt[2], &env_opt[3], &env_opt[5]) >= 1;
+            return e && sscanf(e, "%d,%d,%d,%d,%d,%d", &env_opt[0], &env_opt[1], &env_opt[2], &env_opt[3], &env_opt[5], &env_opt[6]) >= 1;
         }();
         rc = gpbo_cholinv_run(S, 2 * Np, Np, info, have_env_opt ? env_opt : nullptr, gpbo_stream(stream));
         if (rc != GPBO_OK) return rc;

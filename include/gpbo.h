@@ -96,14 +96,14 @@ int gpbo_trtri_f64(const double *L, const double *dinv, int64_t Np, double *U, d
  * In: columns [0, Np) = the symmetric positive definite matrix (both triangles), columns [Np, 2 Np) = zeros.
  * Out: columns [Np, 2 Np) = inv(L), lower triangular (U of gpbo_trtri_f64 is its transpose); the upper block triangle
  * of columns [0, Np) holds L^T except on its 128 x 128 diagonal blocks, which keep their last Schur complements.
- * info as gpbo_potrf_f64.  Np: a multiple of 128.  opt: NULL, or int32[6] {win, far_k, far_kind (3: 128 x 128 tiles,
- * 4: 256 x 128), defer + 1, max_launches, group_from + 1}, 0 = default: schedule choices (csrc/cholinv_plan.h) and, for tests, the
+ * info as gpbo_potrf_f64.  Np: a multiple of 128.  opt: NULL, or int32[7] {win, far_k, far_kind (3: 128 x 128 tiles,
+ * 4: 256 x 128), defer + 1, max_launches, group_from + 1, small_w (64 or 32)}, 0 = default: schedule choices (csrc/cholinv_plan.h) and, for tests, the
  * first max_launches launches of the plan only.  The first call for a size uploads its plan (synchronous). */
 int gpbo_cholinv_f64(double *S, int64_t ld, int64_t Np, int32_t *info, const int32_t *opt, void *stream);
 /* The launch plan of gpbo_cholinv_f64 as data (no GPU needed; tests/test_cholinv_plan_cpu.py executes it with NumPy).
  * opt: as above (max_launches ignored).  *n_launch / *n_tile: in = capacity of launches[] / tiles[] in entries (ignored
  * when the array is NULL), out = entries of the plan.  launches: 5 words each {pair or -1, workgroups of PAIR(pair),
- * first tile, tiles, tiles per workgroup}; tiles: 8 words each {kind (2: 64 x 64, 3: 128 x 128, 4: 256 x 128), k0, K, row0, col0, r1, wlim, 0}:
+ * first tile, tiles, tiles per workgroup}; tiles: 8 words each {kind (2: 64 x w, 3: 128 x 128, 4: 256 x 128), k0, K, row0, col0, r1, wlim, w (kind 2: 64 or 32)}:
  * S[row0.., col0..] -= sum over source rows [k0, k0 + K) of S[k, row0..]^T S[k, col0..], rows < r1, live columns only. */
 int gpbo_cholinv_plan(int64_t Np, const int32_t *opt, int64_t *n_launch, int64_t *n_tile, int32_t *launches, int32_t *tiles);
 /* One launch = the PAIR workgroups of `pair` (< 0: none) + the given tiles (host array, format above; `group`

@@ -14,7 +14,7 @@ TILE_ROWS = {SMALL: 64, BIG: 128, BIG256: 256}
 def get_plan(Np, opt=None):
     """(launches [n x 5]: pair, npair, tile0, ntile, tiles per workgroup;  tiles [m x 8]: kind, k0, K, row0, col0, r1, wlim, 0)"""
     lib = _lib.load()
-    o = (C.c_int32 * 6)(*((list(opt or []) + [0] * 6)[:6]))
+    o = (C.c_int32 * 7)(*((list(opt or []) + [0] * 7)[:7]))
     nl, nt = C.c_int64(0), C.c_int64(0)
     assert lib.gpbo_cholinv_plan(Np, C.cast(o, C.c_void_p), C.byref(nl), C.byref(nt), None, None) == 0
     L = np.zeros((nl.value, 5), dtype=np.int32)
@@ -48,9 +48,9 @@ class Tracker:
 
 def run_tile(S, Np, tile, tr, tile_id, pending):
     """The semantics of one update workgroup (csrc/cholinv.hip: upd_small / upd_big)."""
-    kind, k0, K, row0, col0, r1, wlim, _ = (int(v) for v in tile)
+    kind, k0, K, row0, col0, r1, wlim, w = (int(v) for v in tile)
     H = TILE_ROWS[kind]
-    Wd = 64 if kind == SMALL else 128
+    Wd = (32 if w == 32 else 64) if kind == SMALL else 128
     assert K >= (32 if kind == SMALL else 128) and K % 32 == 0 and k0 + K <= row0 and col0 % Wd == 0
     assert col0 + Wd <= 2 * Np and row0 + H <= 2 * Np and r1 <= Np
     A = S[k0:k0 + K, row0:row0 + H]      # may run into the W half: in bounds, masked below
@@ -62,11 +62,15 @@ def run_tile(S, Np, tile, tr, tile_id, pending):
         rr = row0 + 64 * rb
         if rr >= r1:
             continue
+        if kind == SMALL:   # never masked; a 32-wide tile is half a 64 x 64 block (the tracker works on blocks: two
+            # 32-wide tiles of one launch share a block they do not share any element of)
+            pending.append((rr, col0, S[rr:rr + 64, col0:col0 + Wd] - P[64 * rb:64 * rb + 64, :]))
+            if Wd == 64 or col0 % 64 == 0:
+                tr.write(tile_id, rr, col0 // 64 * 64)
+            continue
         for cb in range(Wd // 64):
             cc = col0 + 64 * cb
             live = (cc >= rr) if cc < Np else (cc < Np + wlim)
-            if kind == SMALL:
-                assert live
             if live:
                 pending.append((rr, cc, S[rr:rr + 64, cc:cc + 64] - P[64 * rb:64 * rb + 64, 64 * cb:64 * cb + 64]))
                 tr.write(tile_id, rr, cc)
@@ -120,7 +124,7 @@ def run_plan(S, Np, plan, first=0, count=None):
             run_tile(S, Np, t, tr, tile_id, pending)
         tr.check()
         for r, c, v in pending:
-            S[r:r + 64, c:c + 64] = v
+            S[r:r + 64, c:c + v.shape[1]] = v
     return S
 
 

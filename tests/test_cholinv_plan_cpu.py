@@ -17,7 +17,7 @@ from bayesian_optimisation_amd import _lib
 from cholinv_sim import BIG, BIG256, SMALL, get_plan, run_plan, spd
 
 OPTS = [(128, None), (256, None), (384, None), (512, None), (640, [1, 128, 3, 1]), (896, None), (896, [2, 256, 4, 2]),
-        (1024, [3, 384, 3, 2]), (1152, [1, 256, 4, 1]), (1536, [2, 512, 4, 3]), (1664, None), (1664, [3, 256, 4, 3]), (2048, [1, 128, 3, 1, 0, 2])]
+        (1024, [3, 384, 3, 2]), (1152, [1, 256, 4, 1]), (1536, [2, 512, 4, 3]), (1664, None), (1664, [3, 256, 4, 3]), (2048, [1, 128, 3, 1, 0, 2]), (768, [1, 256, 3, 3, 0, 0, 64])]
 
 
 @pytest.mark.parametrize("Np,opt", OPTS)
@@ -62,5 +62,5 @@ def test_plan_shape_at_the_benchmark_sizes(Np):
     lib = _lib.load()
     n1, n2 = C.c_int64(0), C.c_int64(0)
     assert lib.gpbo_cholinv_plan(Np + 64, None, C.byref(n1), C.byref(n2), None, None) == -1
-    bad = (C.c_int32 * 6)(0, 200, 0, 0, 0, 0)  # far rank not a multiple of 128
+    bad = (C.c_int32 * 7)(0, 200, 0, 0, 0, 0, 0)  # far rank not a multiple of 128
     assert lib.gpbo_cholinv_plan(Np, C.cast(bad, C.c_void_p), C.byref(n1), C.byref(n2), None, None) == -1

@@ -35,7 +35,7 @@ def run_gpu(env, A, opt=None):
     S[:, :Np] = A
     dS = t.from_numpy(S).to(env.dev)
     info = t.full((1,), -7, dtype=t.int32, device=env.dev)
-    o = (C.c_int32 * 6)(*((list(opt or []) + [0] * 6)[:6]))
+    o = (C.c_int32 * 7)(*((list(opt or []) + [0] * 7)[:7]))
     st = env.lib.gpbo_cholinv_f64(env.p(dS), 2 * Np, Np, env.p(info), C.cast(o, C.c_void_p), env.stream())
     assert st == 0
     t.cuda.synchronize()
@@ -57,11 +57,13 @@ def test_every_launch_matches_the_cpu_execution_of_the_plan(env, Np, opt):
         assert err <= tol, f"launch {n} of {len(plan[0])} ({plan[0][n - 1]}): max |diff| {err} > {tol}"
 
 
-@pytest.mark.parametrize("kind,K", [(SMALL, 32), (SMALL, 128), (SMALL, 352), (BIG, 128), (BIG, 400 // 16 * 16), (BIG256, 128),
+@pytest.mark.parametrize("kind,K", [(SMALL, 32), (SMALL, 128), (SMALL, 352), (-SMALL, 128), (-SMALL, 224), (BIG, 128), (BIG, 400 // 16 * 16), (BIG256, 128),
                                     (BIG256, 512)])
 def test_one_tile_kind_against_numpy(env, kind, K):
     """A handful of tiles of one kind with sources [k0, k0 + K): live masks, ragged last row tile, W-side columns."""
     K = K // 32 * 32
+    half = kind < 0          # 64 x 32 tiles
+    kind = abs(kind)
     t = env.torch
     Np = 1152
     rng = np.random.default_rng(K + kind)
@@ -73,7 +75,11 @@ def test_one_tile_kind_against_numpy(env, kind, K):
     tiles = []
     if kind == SMALL:
         for c in sorted({r0, r0 + 64, Np - 64, Np, Np + wlim - 64}):
-            tiles.append([kind, k0, K, r0, c, r0 + 64, wlim, 0])
+            if half:
+                tiles.append([kind, k0, K, r0, c, r0 + 64, wlim, 32])
+                tiles.append([kind, k0, K, r0, c + 32, r0 + 64, wlim, 32])
+            else:
+                tiles.append([kind, k0, K, r0, c, r0 + 64, wlim, 0])
     else:
         for row0 in (r0, Np - 128):  # the second one is ragged for 256-row tiles
             for c in sorted({row0, min(row0 + 128, Np - 128), Np - 128, Np, Np + (wlim + 127) // 128 * 128 - 128}):
@@ -84,7 +90,7 @@ def test_one_tile_kind_against_numpy(env, kind, K):
     for i, tl in enumerate(T):
         run_tile(ref, Np, tl, tr, i + 1, pending)
     for r, c, v in pending:
-        ref[r:r + 64, c:c + 64] = v
+        ref[r:r + 64, c:c + v.shape[1]] = v
     dS = t.from_numpy(S).to(env.dev)
     info = t.zeros(1, dtype=t.int32, device=env.dev)
     st = env.lib.gpbo_cholinv_tiles_f64(env.p(dS), 2 * Np, Np, env.p(info), -1, T.ctypes.data_as(C.c_void_p), len(T), 2, 1, env.stream())
