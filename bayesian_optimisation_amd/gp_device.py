@@ -544,7 +544,8 @@ class DeviceGP:
                                                 self._ptr(Usub), self._ptr(info), self._ptr(self._work_subset), wbytes,
                                                 self._stream())
             _lib.check(st, "gpbo_bound_subset_f64")
-        sub = (Xsub, Usub, Ns, perm, info)
+            info_h = int(info.item())  # once per factorisation (synchronises): K_SS positive definite at these jitters?
+        sub = (Xsub, Usub, Ns, perm, info_h)
         self._bound_subset = ((J, J2), sub)
         return sub
 
@@ -601,7 +602,7 @@ class DeviceGP:
             if subset not in ("fps", "arrival"):
                 raise ValueError("subset must be 'fps' or 'arrival'")
             sub = self._ensure_bound_subset(J, J2) if subset == "fps" else None
-            if sub is not None and int(sub[4].item()) != 0:
+            if sub is not None and sub[4] != 0:
                 sub = None  # K_SS not positive definite at this jitter (duplicated members): the literal prefix instead
             if sub is not None:
                 st = self.lib.gpbo_posterior_prefix_subset_f64(
