@@ -526,6 +526,22 @@ def main():
             ms = (time.perf_counter() - t) / 20 * 1e3
             res["configs[1]"] = dict(workload="d=8, N=512, M=2^20, fp64, LCB(explore=4)", value=m2 / (ms * 1e-3),
                                      unit="candidates/s", ms_per_step=ms, argmax_index=i, steps=20)
+        if not qei:
+            # the once-per-step part by itself: K(X,X) + fused Cholesky / inverse factor + alpha (gpbo_factorise_f64), on the
+            # matrix-core roofline that bounds it (2 N^3 / 3 flop: Cholesky + triangular inverse)
+            for _ in range(3):
+                gp.factorise(Xd, yd, ls, check=False)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for _ in range(20):
+                gp.factorise(Xd, yd, ls, check=False)
+            torch.cuda.synchronize(dev)
+            fms = (time.perf_counter() - t) / 20 * 1e3
+            ftf = 2.0 * float(N) ** 3 / 3.0 / (fms * 1e-3) / 1e12
+            res["factorisation"] = dict(ms_per_call=fms, flop=2.0 * float(N) ** 3 / 3.0, achieved_tflops=round(ftf, 2),
+                                        peak=FP64_MFMA_PEAK_TFLOPS, frac=round(ftf / FP64_MFMA_PEAK_TFLOPS, 4),
+                                        kernel="cholinv_kernel (+ kxx_kernel, transpose_w_kernel, utv / uv)", steps=20,
+                                        note="latency-bound below N ~ 4096: 2 dependent launches per 128 rows (DESIGN.md 4e)")
         return res
 
     cfg_name = {(512, 8, "f64", "lcb"): "configs[1]", (4096, 8, "f64", "lcb"): "configs[2] (per-GPU shard)",

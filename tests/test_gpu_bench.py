@@ -42,6 +42,8 @@ def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
     #  red on a slow or shared box - tools/ab.sh compares routes on one box)
     assert 0.5 < line["roofline"]["frac"] <= 1.0
     assert line["also"]["configs[1]"]["value"] > 0 and line["also"]["ei_same_workload"]["value"] > 0
+    fz = line["also"]["factorisation"]
+    assert 0.0 < fz["frac"] <= 1.0 and fz["peak"] == 78.6 and abs(fz["achieved_tflops"] - fz["flop"] / fz["ms_per_call"] / 1e9) < 0.05
     c0 = line["also"]["configs[0]"]
     assert c0["index_matches_reference"] is True and c0["cpu_port_index_matches"] is True and c0["ms_per_step"] < 50
     i8 = line["also"]["int8_sliced_same_workload"]
