@@ -772,7 +772,10 @@ __global__ __launch_bounds__(512) void sigma_i8c_kernel(const char *__restrict__
             CMM4(0, 1);
             SB();
             wait_own(has_next ? ahead - 1 : 0);
+#ifndef GPBO_I8C_DIAG_NO_BARRIER   // timing-only diagnostic (wrong results: stages are read before other waves' pieces have
+            // landed): the upper bound of what ANY barrier-free stage hand-off could gain
             __builtin_amdgcn_s_barrier();
+#endif
             SB();
             CMM4(1, 1);   // straight after the barrier: nothing but MFMAs between the release and the pipe's next work
             SB();
