@@ -68,43 +68,7 @@ __global__ __launch_bounds__(256) void kxx_kernel(const double *__restrict__ X, 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// exp(-t) for t >= 0 in fp64, <= 1 ulp: 2^(n/32) table (LDS) x degree-6 polynomial, scaled through the
-// exponent field.  12 full-rate fp64 instructions against ~24 (some quarter-rate) for the library exp.
-// ---------------------------------------------------------------------------------------------
-__device__ const double kExp2Tab[32] = {
-    1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237,
-    1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775,
-    1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332,
-    1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832,
-    1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228,
-    1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965,
-    1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072,
-    1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002};
-
-__device__ __forceinline__ double exp_neg(double t, const double *tab /* LDS, 32 entries */) {
-    // n = rint(-t * 32/ln2) by the 1.5*2^52 trick: the integer sits in the low dword of z, and z - magic is
-    // exact.  (v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64 issue at a quarter of the fp64 FMA rate on gfx950;
-    // this form needs none of them.)
-    const double u = -t;
-    const double z = fma(u, 46.16624130844683, 6755399441055744.0);
-    const int ni = __double2loint(z);
-    const double fn = z - 6755399441055744.0;
-    double r = fma(fn, -0.02166084939249829, u);   // u - n * (ln2/32), hi part
-    r = fma(fn, -7.247021293269686e-19, r);        //                 , lo part
-    const double T = tab[ni & 31];
-    double q = fma(r, 1.0 / 720.0, 1.0 / 120.0);
-    q = fma(r, q, 1.0 / 24.0);
-    q = fma(r, q, 1.0 / 6.0);
-    q = fma(r, q, 0.5);
-    q = fma(r, q, 1.0);
-    const double v = fma(T * r, q, T);             // in [1, 2): scale by 2^(n >> 5) through the exponent field
-    const double s = __hiloint2double(__double2hiint(v) + ((ni >> 5) << 20), __double2loint(v));
-    // t <= 708: the result is a normal number.  Above, the reference's np.exp returns values below DBL_MIN
-    // (denormals, then 0); they are flushed to 0 here - invisible at every tolerance of the path.
-    // (a NaN argument also lands in the 0 arm: callers poison their outputs when an input coordinate is NaN)
-    return (t <= 708.0) ? s : 0.0;
-}
+#include "exp_neg.h"
 
 // ---------------------------------------------------------------------------------------------
 // K2+K5: KsT[n][c] = k(x_n, x*_c) for one candidate chunk, plus per-slice partial means.
@@ -144,8 +108,8 @@ __global__ __launch_bounds__(256) void kstar_mu_kernel(const double *__restrict_
                                                        int store_rows /* rows n >= store_rows are not stored (multiple of 64):
                                                                          the prefix-bound screen needs the mean of all N
                                                                          observations but K*^T of the first few only */) {
-    __shared__ double tab[32];
-    if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
+    __shared__ double tab[GPBO_EXP_E];
+    if (threadIdx.x < GPBO_EXP_E) tab[threadIdx.x] = kExp2Tab256[threadIdx.x * (256 / GPBO_EXP_E)];
     const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
     const int n0 = blockIdx.y * KS_SLICE;
     double xa[D], xb[D];

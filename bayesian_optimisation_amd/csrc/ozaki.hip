@@ -69,34 +69,8 @@ __device__ __forceinline__ void glds16b_s(const char *base, unsigned lane_off, u
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(base) : "memory");
 }
 
-// ---- exp(-t), t >= 0 (same algorithm as kernel_build.hip: 2^(n/32) table x degree-6 polynomial, <= 1 ulp) ----------
-__device__ const double kExp2TabI8[32] = {
-    1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237,
-    1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775,
-    1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332,
-    1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832,
-    1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228,
-    1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965,
-    1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072,
-    1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002};
-
-__device__ __forceinline__ double exp_neg_i8(double t, const double *tab) {
-    const double u = -t;
-    const double z = fma(u, 46.16624130844683, MAGIC);
-    const int ni = __double2loint(z);
-    const double fn = z - MAGIC;
-    double r = fma(fn, -0.02166084939249829, u);
-    r = fma(fn, -7.247021293269686e-19, r);
-    const double T = tab[ni & 31];
-    double q = fma(r, 1.0 / 720.0, 1.0 / 120.0);
-    q = fma(r, q, 1.0 / 24.0);
-    q = fma(r, q, 1.0 / 6.0);
-    q = fma(r, q, 0.5);
-    q = fma(r, q, 1.0);
-    const double v = fma(T * r, q, T);
-    const double s = __hiloint2double(__double2hiint(v) + ((ni >> 5) << 20), __double2loint(v));
-    return (t <= 708.0) ? s : 0.0;
-}
+// ---- exp(-t), t >= 0: the one definition shared with kernel_build.hip (bit-identical entries and means) --------------
+#include "exp_neg.h"
 
 // ---- balanced base-256 digits of four fixed-point values at once --------------------------------------------------
 // In: z[q] = x_q 2^46 + MAGIC (q = 0..3).  Out: P[a] (a = 0 most significant) = the a-th digits of the four values,
@@ -210,8 +184,8 @@ __global__ __launch_bounds__(256) void kstar_slices_kernel(const double *__restr
                                                            const double *__restrict__ Xsc, int N, LsArgsI8 ls,
                                                            const double *__restrict__ alpha, char *__restrict__ A8,
                                                            int64_t RT, double *__restrict__ mu_part, int64_t ldk) {
-    __shared__ double tab[32];
-    if (threadIdx.x < 32) tab[threadIdx.x] = kExp2TabI8[threadIdx.x];
+    __shared__ double tab[GPBO_EXP_E];
+    if (threadIdx.x < GPBO_EXP_E) tab[threadIdx.x] = kExp2Tab256[threadIdx.x * (256 / GPBO_EXP_E)];
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double x[D];
     bool nan_c = false;
@@ -242,7 +216,7 @@ __global__ __launch_bounds__(256) void kstar_slices_kernel(const double *__restr
                         const double dd = x[k] - xo[k];
                         s = fma(dd, dd, s);
                     }
-                    kv = exp_neg_i8(s, tab);
+                    kv = exp_neg(s, tab);
                     mu = fma(kv, alpha[n], mu);
                 }
                 z[q] = fma(kv, TWO38, MAGIC);
