@@ -22,6 +22,7 @@
 
 #include <cstdlib>
 #include <limits>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -461,7 +462,9 @@ __global__ __launch_bounds__(256) void acq_argmax_kernel(const double *__restric
 }
 
 // Helper stream + events for the K(X*,X) / variance overlap, one set per device, created on first use and
-// kept for the life of the process (nothing is retained about the caller's buffers).
+// kept for the life of the process (nothing is retained about the caller's buffers).  Opt-in only (GPBO_OVERLAP=1, a
+// measured null result kept for A/B runs): with it, ONE scoring call per device at a time - two callers on different
+// streams would re-record the same events.  The table itself is created under a lock.
 struct Helper {
     hipStream_t stream;
     hipEvent_t fork, kdone[2], sdone[2];
@@ -469,6 +472,8 @@ struct Helper {
 
 Helper *helper_for_current_device() {
     static Helper *tab[64] = {nullptr};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!tab[dev]) {
