@@ -21,6 +21,8 @@ Differences from the reference, all deliberate:
     |cov_func - fp64| <= SCREEN_SIGMA_TOL[precision] (5e-3 for fp32 and i8c, 2e-9 for i8; also in `last_screen`), so the
     arg-max of `acq_func_eval` itself can differ from the returned index when two candidates are closer than that.
     A caller that plots or post-processes these arrays at the reference's 1e-8 should stay with precision="fp64".
+    The screens' tolerance is verified per call on every re-scored candidate and a strided sample, not proven for each
+    candidate: the route that is exact by construction is `dense_outputs=False` (the prefix bound).
     Also extra: `expected_improvement(xi)`,
     `q_expected_improvement()`, `dense_outputs=False` (next point only: the dense attributes stay None and the acquisition
     calls go through the exact prefix bound), `kernel_params` may be preset (then no
