@@ -100,7 +100,8 @@ def test_one_tile_kind_against_numpy(env, kind, K):
 
 
 @pytest.mark.parametrize("Np,opt", [(128, None), (384, None), (1024, None), (1024, [1, 128, 3, 1]), (2176, None),
-                                    (2176, [3, 512, 4, 2]), (4096, None), (4224, [2, 256, 4, 3])])
+                                    (2176, [3, 512, 4, 2]), (4096, None), (4224, [2, 256, 4, 3]),
+                                    (6144, None), (8192, None)])   # from 6144 up: far rank 384, 64-wide NEAR tiles
 def test_inverse_factor_vs_lapack(env, Np, opt):
     A = spd(Np, Np)
     got, info = run_gpu(env, A, (opt + [0]) if opt else None)
