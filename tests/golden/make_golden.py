@@ -110,7 +110,12 @@ def nlml_grid_reference(X, y, length_scales):
     return g
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]   # e.g. `make_golden.py g9`: write only fixtures with that prefix
+
+
 def save(name, **arrs):
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **VERS, **arrs)
     print(f"wrote {name}.npz  ({os.path.getsize(path)/1024:.1f} KiB)")
@@ -205,6 +210,12 @@ def main():
     out, _ = run_reference(X, y, Xs, [128], preset_ls=ls, expect_error=True)
     save("g8_nan", X=X, y=y, Xs=Xs, ls=ls, feature_domain=np.array([128]), **out)
 
+    # ---- G9: more features than the unrolled kernels hold (d = 24 > 16): the class is "agnostic to the dimensionality of
+    # the feature space" (point_selector.py:22, the broadcast at :180-189); the drop-in serves it with its any-d kernels
+    X, y, Xs, ls = make_problem(96, 512, 24)
+    out, _ = run_reference(X, y, Xs, [512], preset_ls=ls)
+    save("g9_d24_n96_m512", N=np.array(96), M=np.array(512), d=np.array(24), ls=ls, y=y, **out)
+
 
 def copy_state_file():
     """The DAG's state file as shipped by the reference (opto_log_clean.JSON: data, not code) - the driver
@@ -219,4 +230,5 @@ def copy_state_file():
 
 if __name__ == "__main__":
     main()
-    copy_state_file()
+    if not ONLY:
+        copy_state_file()

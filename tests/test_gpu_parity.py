@@ -30,7 +30,8 @@ def _first_argmax(a):
     return int(np.flatnonzero(a == a.max())[0])
 
 
-@pytest.mark.parametrize("name", ["g5_d8_n64_m1024", "g5_d8_n512_m4096", "g5_d8_n2048_m4096", "g6_d16_n256_m2048"])
+@pytest.mark.parametrize("name", ["g5_d8_n64_m1024", "g5_d8_n512_m4096", "g5_d8_n2048_m4096", "g6_d16_n256_m2048",
+                                  "g9_d24_n96_m512"])   # the last: 24 features, the any-d kernels (point_selector.py:22)
 def test_fused_path_vs_reference_golden(golden, name):
     g = golden(name)
     X, y, Xs, ls = make_problem(int(g["N"]), int(g["M"]), int(g["d"]))

@@ -57,7 +57,7 @@ def test_duplicated_rows(golden):
 
 
 @pytest.mark.parametrize("name", ["g5_d8_n64_m1024", "g5_d8_n512_m4096", "g5_d8_n2048_m4096",
-                                  "g6_d16_n256_m2048"])
+                                  "g6_d16_n256_m2048", "g9_d24_n96_m512"])
 @pytest.mark.parametrize("route", ["literal", "chol"])
 def test_preset_ls_high_dim(golden, name, route):
     g = golden(name)
