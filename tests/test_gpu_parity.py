@@ -154,9 +154,12 @@ def test_dropin_full_path_with_ard(golden, name):
         np.testing.assert_allclose(ps.nlogml, g["nlogml"], rtol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["g4_tie_tiny_ls", "g4_dup_rows", "g7_n_eq_m"])
+@pytest.mark.parametrize("name", ["g4_tie_tiny_ls", "g4_dup_rows", "g7_n_eq_m", "g9_d24_n96_m512"])
 def test_dropin_preset_length_scales(golden, name):
     g = golden(name)
+    if "X" not in g:   # G5/G6/G9 store the generator's arguments, not the arrays
+        g["X"], _, g["Xs"], _ = make_problem(int(g["N"]), int(g["M"]), int(g["d"]))
+        g["feature_domain"] = np.array([int(g["M"])])
     ps, idx = _run_dropin(g, preset=True)
     _check_against(ps.mean_func.ravel(), ps.cov_func.ravel(), ps.acq_func_eval.ravel(),
                    int(np.ravel_multi_index(tuple(idx), g["mean_func"].shape)), g)
