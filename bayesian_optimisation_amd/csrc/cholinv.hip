@@ -84,6 +84,7 @@ struct CiArgs {
 template <int MI>
 __device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int Np, const CiTile &u, double *smem,
                                         unsigned long long *stamps) {
+    const bool nt = Np >= 6144;
 #ifdef GPBO_DIAGNOSTICS
     int nst = 0;
 #define CI_TSTAMP() do { if (stamps && threadIdx.x == 0) stamps[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -174,7 +175,11 @@ __device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int 
         const double *cp = cbp + (int64_t)(16 * mi) * ld;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
+#ifdef GPBO_CI_DIAG_NO_CLOAD   // timing only (wrong results): the C tile is not read
+            if (false) {
+#else
             if (live_at(mi, ni)) {
+#endif
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cb[ni][r] = cp[(int64_t)(4 * r) * ld + 32 * ni];
             } else {
@@ -242,10 +247,21 @@ __device__ __forceinline__ void upd_big(double *__restrict__ S, int64_t ld, int 
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
+#ifdef GPBO_CI_DIAG_NO_STORE   // timing only (wrong results): one lane in 64 stores
+            if (live_at(mi, ni) && lane == 0) {
+#else
             if (live_at(mi, ni)) {
+#endif
                 double *cp = cbp + (int64_t)(16 * mi) * ld + 32 * ni;
+                // nt: the stacked matrix is far beyond the 256-MiB Infinity Cache (N >= 6144: >= 600 MB) - the hint saves 1.1 % of
+                // the factorisation at N = 8192; at N <= 4096 (268 MB) the next update finds its target on chip without it
+                if (nt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cp[(int64_t)(4 * r) * ld] = -acc[mi][ni][r];
+                    for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(-acc[mi][ni][r], cp + (int64_t)(4 * r) * ld);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cp[(int64_t)(4 * r) * ld] = -acc[mi][ni][r];
+                }
             }
         }
     CI_TSTAMP();

@@ -38,9 +38,10 @@ def far_tiles(kind, K, n):
         rr += th
     return out
 
-for kind, nm, th in ((BIG, "big128", 128), (BIG256, "big256", 256)):
+NBS = [int(x) for x in os.environ.get('CI_NTILES', '128,256,512').split(',')]   # CI_NTILES=1,8,32,...: how a tile's time grows
+for kind, nm, th in ((BIG, "big128", 128), (BIG256, "big256", 256)):                 # with the number of tiles beside it
     for K in (128, 256, 384, 512):
-        for nb in (128, 256, 512):
+        for nb in NBS:
             tl = far_tiles(kind, K, nb)
             if len(tl) < nb:
                 continue
