@@ -345,7 +345,14 @@ __device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, co
 // Returns (wave 0 only) the 1-based column of the first non-positive / non-finite pivot, or 0.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename BG>
-__device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int lane, bool has_bg, BG &&bg) {
+__device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int lane, bool has_bg, BG &&bg,
+                                        unsigned long long *fst = nullptr /* GPBO_CI_F64_STAMPS builds: wave 0's stamps */) {
+#ifdef GPBO_CI_F64_STAMPS
+    int fn = 0;
+#define F64_STAMP() do { if (fst && w == 0 && lane == 0 && fn < 8) fst[fn++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define F64_STAMP() do { } while (0)
+#endif
     const int l15 = lane & 15, l4 = lane >> 4;
     auto rowp = [&](int R) { return (R < NB) ? Mtop + R * LDM : Mbot + (R - NB) * LDM; };  // row R of the stack
     int first_bad = 0;
@@ -361,6 +368,8 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
             const bool ok = (piv > 0.0) && (piv < 1.0e300);
             first_bad = (!ok && first_bad == 0) ? PB * s + c + 1 : first_bad;
             x[c] *= rsqrt_refined(piv);
+            // (issue-bound, ~7 cycles per instruction of this lone wave: starting the next pivot's reciprocal square root right
+            //  after the first update and issuing its eight links between the others gained nothing - 24.9k against 23.9k cycles)
 #pragma unroll
             for (int k = c + 1; k < PB; ++k) x[k] = fma(-x[c], readlane_f64(x[c], k), x[k]);
         }
@@ -396,18 +405,25 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
         for (int r = 0; r < 4; ++r) rowp(R0 + l4 + 4 * r)[PB * c + l15] = acc[r];
     };
     constexpr int NS = NB / PB;  // 4
+    F64_STAMP();
     if (w == 0) eliminate(0);
+    F64_STAMP();
     __syncthreads();
+    F64_STAMP();
     for (int s = 0; s < NS; ++s) {
         if (w < NS - 1) {  // (2): D row blocks s+1..3 and identity-part row blocks 0..s-1 - always three
             const int nA = NS - 1 - s;
             panel(w < nA ? PB * (s + 1 + w) : NB + PB * (w - nA), s);
         }
+        if (s == 0) F64_STAMP();
         __syncthreads();
+        if (s == 0) F64_STAMP();
         if (s == NS - 1) break;
         if (w == 0) {  // (3)
             trail(PB * (s + 1), s + 1, s);
+            if (s == 0) F64_STAMP();
             eliminate(s + 1);
+            if (s == 0) F64_STAMP();
         } else if (has_bg && w >= 4) {
             bg(s);
         } else {
@@ -426,7 +442,9 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
             }
         }
         __syncthreads();
+        if (s == 0) F64_STAMP();
     }
+#undef F64_STAMP
     return first_bad;
 }
 
@@ -455,7 +473,11 @@ __device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, in
     const int r0 = 128 * p;
 #ifdef GPBO_DIAGNOSTICS
     int nst = 0;
+#ifdef GPBO_CI_F64_STAMPS
+#define CI_STAMP() do { (void)nst; } while (0)
+#else
 #define CI_STAMP() do { if (stamps && pt == 0 && tid == 0) stamps[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #else
 #define CI_STAMP() do { } while (0)
 #endif
@@ -518,7 +540,11 @@ __device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, in
     }
     __syncthreads();
     CI_STAMP();
+#ifdef GPBO_CI_F64_STAMPS
+    const int bad1 = factor64(B0, B1, w, lane, false, [](int) {}, (stamps && pt == 0) ? stamps : nullptr);
+#else
     const int bad1 = factor64(B0, B1, w, lane, false, [](int) {});   // ends with a barrier after the last panel step
+#endif
     CI_STAMP();
     // R12 = inv(L11) A12: inv(L11)[r][k] = B1[k][r], zero for k > r.  Wave w: column tile w & 3 of the row tiles
     // {w >> 2, 3 - (w >> 2)} (4 (mi + 1) k steps each: 20 per wave); read completely before the barrier, written after.
