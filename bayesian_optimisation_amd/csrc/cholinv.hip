@@ -370,8 +370,11 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
             x[c] *= rsqrt_refined(piv);
             // (issue-bound, ~7 cycles per instruction of this lone wave: starting the next pivot's reciprocal square root right
             //  after the first update and issuing its eight links between the others gained nothing - 24.9k against 23.9k cycles)
+            double m[PB];  // the multipliers first (wave-uniform: scalar registers), then the updates: no hazard slots between
 #pragma unroll
-            for (int k = c + 1; k < PB; ++k) x[k] = fma(-x[c], readlane_f64(x[c], k), x[k]);
+            for (int k = c + 1; k < PB; ++k) m[k] = readlane_f64(x[c], k);
+#pragma unroll
+            for (int k = c + 1; k < PB; ++k) x[k] = fma(-x[c], m[k], x[k]);
         }
         if (lane < 2 * PB) {
 #pragma unroll
