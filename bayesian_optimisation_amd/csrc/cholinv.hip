@@ -340,10 +340,16 @@ __device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, co
 //   (3) the trailing 16 x 16 blocks are updated on the matrix cores - wave 0 takes the next diagonal sub-block first
 //       and goes straight on to (1) while the other seven waves do the rest.
 // All 8 waves call it (barriers inside); the caller has synchronised after filling Mtop / Mbot.
-// has_bg: waves 4..7 do not help with (3) but run bg(s) there, s = 0, 1, 2 - work of the caller that touches neither Mtop
+// has_bg: the background waves (ci_is_bg_wave) do not help with (3) but run bg(s) there, s = 0, 1, 2 - work of the caller that touches neither Mtop
 // nor Mbot and contains no barrier (wave 0's elimination is ~3000 cycles during which they would otherwise wait).
 // Returns (wave 0 only) the 1-based column of the first non-positive / non-finite pivot, or 0.
 // ---------------------------------------------------------------------------------------------------------------
+// The waves that carry a caller's background work through an elimination: 1, 5, 6, 7 - none of them on wave 0's SIMD (waves
+// w and w + 4 share one; fp64 MFMAs and fp64 vector instructions of a SIMD do not overlap, and wave 0's sixteen-column
+// phase is bound by instruction issue: with the X strips on waves 4..7 the second elimination took 30.0k cycles against the
+// first one's 22.0k).  Waves 2 and 3 keep the few trailing products; wave 4 does nothing during an elimination.
+__device__ __forceinline__ bool ci_is_bg_wave(int w) { return w == 1 || w >= 5; }
+
 template <typename BG>
 __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int lane, bool has_bg, BG &&bg,
                                         unsigned long long *fst = nullptr /* GPBO_CI_F64_STAMPS builds: wave 0's stamps */) {
@@ -427,19 +433,21 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
             if (s == 0) F64_STAMP();
             eliminate(s + 1);
             if (s == 0) F64_STAMP();
-        } else if (has_bg && w >= 4) {
+        } else if (has_bg && ci_is_bg_wave(w)) {
             bg(s);
         } else {
-            const int nh = has_bg ? 3 : 7;  // helper waves 1 .. nh
+            // helper waves: 1, 2, 3, 5, 6, 7 - or 2, 3 beside the background waves; wave 4 (wave 0's SIMD) stays idle
+            const int nh = has_bg ? 2 : 6;
+            const int hw = (w == 4) ? -1 : has_bg ? w - 2 : (w < 4 ? w - 1 : w - 2);   // this wave's rank among them
             int q = 0;
             for (int c = s + 1; c < NS; ++c) {
                 for (int R = c; R < NS; ++R) {
                     if (R == s + 1 && c == s + 1) continue;
-                    if (q % nh == w - 1) trail(PB * R, c, s);
+                    if (q % nh == hw) trail(PB * R, c, s);
                     ++q;
                 }
                 for (int m = 0; m <= s; ++m) {
-                    if (q % nh == w - 1) trail(NB + PB * m, c, s);
+                    if (q % nh == hw) trail(NB + PB * m, c, s);
                     ++q;
                 }
             }
@@ -461,7 +469,7 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
 // and then applies inv(L) = [inv(L11) 0; -inv(L22) L21 inv(L11)  inv(L22)] to its own 64 columns X = [X1; X2] of the
 // two block rows as three products that never leave the registers:
 //     X1' = inv(L11) X1 ;   X2 <- X2 - R12^T X1' ;   X2' = inv(L22) X2
-// (waves 4..7, one 16-column strip each: the fp64 16x16x4 MFMA's C layout - row = lane/16 + 4 r - IS the B operand
+// (waves 1, 5, 6, 7, one 16-column strip each: the fp64 16x16x4 MFMA's C layout - row = lane/16 + 4 r - IS the B operand
 // layout of the next product, k = lane/16 within k step r; the first two products run beside the second elimination).  W's diagonal block of the pair is the same computation
 // on X = I.  The pair's diagonal block of A is left alone: nothing reads it later, other workgroups are reading it now.
 // LDS: four [64][LDM] blocks - B0: D11 -> L11, then D22 -> L22;  B1: I -> inv(L11)^T (kept);  B2: I -> inv(L22)^T;
@@ -494,7 +502,7 @@ __device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, in
 
     // Everything the workgroup reads from global memory is requested here, in the order it is needed: D11 and A12
     // (eight elements per thread each: registers first, LDS after - one round trip, not eight), the wave's tiles of D22
-    // in MFMA C layout, and the X strip of waves 4..7 as B-operand fragments (consumed after the first elimination).
+    // in MFMA C layout, and the X strip of waves 1, 5, 6, 7 as B-operand fragments (consumed after the first elimination).
     double dv[8], av[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -517,9 +525,10 @@ __device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) d22[q][r] = Dg[(int64_t)(64 + 16 * mi + l4 + 4 * r) * ld + 64 + 16 * ni + l15];
     }
-    const int xs = w & 3;  // strip of the X waves (4..7)
+    const bool xw = ci_is_bg_wave(w);   // the X waves: 1, 5, 6, 7
+    const int xs = (w == 1) ? 0 : w - 4;  // their strips: 0, 1, 2, 3
     double x1[16], x2[16];
-    if (w >= 4) {
+    if (xw) {
         const double *xp = S + (int64_t)(r0 + l4) * ld + c0 + 16 * xs + l15;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -620,7 +629,7 @@ __device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, in
     }
     __syncthreads();
     CI_STAMP();
-    // Second elimination, and beside it (waves 4..7, while wave 0 eliminates): X1' = inv(L11) X1, then
+    // Second elimination, and beside it (waves 1, 5, 6, 7, while wave 0 eliminates): X1' = inv(L11) X1, then
     // X2 <- X2 - R12^T X1' in two halves - both only need B1 and B3, which the elimination does not touch.
     double y1[16];
     double *xp = S + (int64_t)(r0 + l4) * ld + c0 + 16 * xs + l15;
@@ -674,7 +683,7 @@ __device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, in
         const int bad = bad1 ? r0 + bad1 : (bad2 ? r0 + 64 + bad2 : 0);
         if (bad) atomicCAS(info, 0, bad);
     }
-    if (w >= 4) {  // X2' = inv(L22) X2
+    if (xw) {  // X2' = inv(L22) X2
         d4_t acc[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks)
