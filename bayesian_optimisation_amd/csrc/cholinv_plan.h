@@ -97,7 +97,10 @@ inline CiPlanOptions ci_options_from(int Np, const int32_t *opt) {
 }
 
 // Cost model of the packer (microseconds of one workgroup with the whole chip busy, tools/bench_ci_jobs.py on MI355X).
-inline double ci_cost_pair() { return 37.0; }
+#ifndef GPBO_CI_COST_PAIR
+#define GPBO_CI_COST_PAIR 37.0
+#endif
+inline double ci_cost_pair() { return GPBO_CI_COST_PAIR; }
 inline double ci_cost_tile(int kind, int K) {
     if (kind == CI_UPD_SMALL) return 4.0 + 0.03 * K;
     if (kind == CI_UPD_BIG) return 14.0 + 0.122 * K;
