@@ -63,6 +63,13 @@ __device__ __forceinline__ double rsqrt_refined(double p) {
     return fma(y, e, y);
 }
 
+// A launch whose tiles are ONE regular rank-K update in 64 x w tiles (the NEAR launch of every pair) carries its shape in the
+// kernel arguments: the workgroup forms its tile from blockIdx instead of reading the tile table - a dependent scalar load
+// from memory (~1 us) before the first fragment can be requested, on the critical path of every pair.
+struct CiNear {
+    int32_t on, k0, K, row0, wlim, w, n0, r1;  // tile i: row block i >= n0, column row0 + 64 (i >= n0) + w (i - n0 (i >= n0))
+};
+
 struct CiArgs {
     double *S;
     int64_t ld;
@@ -71,6 +78,7 @@ struct CiArgs {
     unsigned long long *stamps;  // GPBO_DIAGNOSTICS builds: cycle stamps of the first PAIR workgroup of a launch
     const CiTile *tab;           // the plan's tile table (device)
     CiLaunch l;
+    CiNear near;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -294,6 +302,34 @@ __device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, co
     for (int r = 0; r < 4; ++r) {
         c0[r] = cp[(int64_t)(4 * r) * ld];
         c1[r] = HALF ? 0.0 : cp[(int64_t)(4 * r) * ld + 16];
+    }
+    if (u.K == 128) {
+        // the NEAR launch of every pair (rank 128, on the critical path): ALL fragments are requested at once - one memory
+        // round trip instead of three (64 / 96 loads per lane in flight) - and every sum runs as two chains (k step parity)
+        double ga[32], gb0[32], gb1[HALF ? 1 : 32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int64_t o = (int64_t)(4 * s) * ld;
+            ga[s] = ap[o];
+            gb0[s] = bp[o];
+            if (!HALF) gb1[s] = bp[o + 16];
+        }
+        d4_t acc0b = {0.0, 0.0, 0.0, 0.0}, acc1b = acc0b;
+#pragma unroll
+        for (int s = 0; s < 32; s += 2) {
+            acc0 = mfma_f64_16x16x4(ga[s], gb0[s], acc0);
+            acc0b = mfma_f64_16x16x4(ga[s + 1], gb0[s + 1], acc0b);
+            if (!HALF) {
+                acc1 = mfma_f64_16x16x4(ga[s], gb1[s], acc1);
+                acc1b = mfma_f64_16x16x4(ga[s + 1], gb1[s + 1], acc1b);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cp[(int64_t)(4 * r) * ld] = c0[r] - (acc0[r] + acc0b[r]);
+            if (!HALF) cp[(int64_t)(4 * r) * ld + 16] = c1[r] - (acc1[r] + acc1b[r]);
+        }
+        return;
     }
     constexpr int CH = 8;  // k steps (of 4) per chunk
     double fa[2][CH], fb0[2][CH], fb1[2][CH];
@@ -706,6 +742,14 @@ __global__ __launch_bounds__(512) void cholinv_kernel(CiArgs a) {
         pair_body(a.S, a.ld, a.Np, a.l.pair, b, a.info, smem, a.stamps);
         return;
     }
+    if (a.near.on) {  // (npair == 0, group == 1)
+        const int hi = b >= a.near.n0;
+        const int r = a.near.row0 + 64 * hi;
+        const CiTile t = {CI_UPD_SMALL, a.near.k0, a.near.K, r, r + a.near.w * (b - (hi ? a.near.n0 : 0)), a.near.r1, a.near.wlim, a.near.w};
+        if (t.w == 32) upd_small<true>(a.S, a.ld, t);
+        else upd_small<false>(a.S, a.ld, t);
+        return;
+    }
     const int first = (b - a.l.npair) * a.l.group;
     const int last = (first + a.l.group < a.l.ntile) ? first + a.l.group : a.l.ntile;
     for (int i = first; i < last; ++i) {
@@ -752,7 +796,27 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const double *__restri
 struct DevPlan {
     CiPlan plan;
     CiTile *dtiles = nullptr;
+    std::vector<CiNear> near;  // per launch; on = 0 where the tiles are not one regular 64 x w update
 };
+
+// the closed form the kernel uses, checked against the plan's own tiles: any difference and the launch reads the table
+static CiNear near_of(const CiPlan &P, const CiLaunch &l) {
+    CiNear z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (l.npair != 0 || l.ntile <= 0 || l.group != 1) return z;
+    const CiTile *T = P.tiles.data() + l.tile0;
+    if (T[0].kind != CI_UPD_SMALL || (T[0].w != 32 && T[0].w != 64)) return z;
+    CiNear n = {1, T[0].k0, T[0].K, T[0].row0, T[0].wlim, T[0].w, 0, T[0].r1};
+    while (n.n0 < l.ntile && T[n.n0].row0 == n.row0) ++n.n0;
+    for (int i = 0; i < l.ntile; ++i) {
+        const int hi = i >= n.n0, r = n.row0 + 64 * hi;
+        const CiTile e = {CI_UPD_SMALL, n.k0, n.K, r, r + n.w * (i - (hi ? n.n0 : 0)), n.r1, n.wlim, n.w};
+        const CiTile &t = T[i];
+        if (t.kind != e.kind || t.k0 != e.k0 || t.K != e.K || t.row0 != e.row0 || t.col0 != e.col0 || t.r1 != e.r1 ||
+            t.wlim != e.wlim || t.w != e.w)
+            return z;
+    }
+    return n;
+}
 
 static const DevPlan *plan_for(int Np, const CiPlanOptions &o) {
     static std::mutex mu;
@@ -765,6 +829,7 @@ static const DevPlan *plan_for(int Np, const CiPlanOptions &o) {
     if (it != cache.end()) return it->second;
     DevPlan *dp = new DevPlan;
     dp->plan = ci_plan(Np, o);
+    for (const CiLaunch &l : dp->plan.launches) dp->near.push_back(near_of(dp->plan, l));
     const size_t bytes = dp->plan.tiles.size() * sizeof(CiTile);
     if (bytes) {
         if (hipMalloc(&dp->dtiles, bytes) != hipSuccess) { delete dp; return nullptr; }
@@ -808,7 +873,9 @@ int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int
     if (want_stamps && !dstamps && hipMalloc(&dstamps, 8 * 8 * 1024) != hipSuccess) return GPBO_ERR_LAUNCH;
     int npair = 0;
 #endif
+    size_t li = 0;
     for (const CiLaunch &l : dp->plan.launches) {
+        a.near = dp->near[li++];
         if (left-- <= 0) break;
         a.l = l;
         const int nblk = ci_launch_blocks(l);
@@ -913,6 +980,7 @@ extern "C" int gpbo_cholinv_tiles_f64(double *S, int64_t ld, int64_t Np, int32_t
     a.stamps = nullptr;
     a.tab = d;
     a.l = CiLaunch{pair, pair >= 0 ? ci_pair_ntiles((int)Np) : 0, 0, (int32_t)ntile, group};
+    a.near = CiNear{0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef GPBO_DIAGNOSTICS
     unsigned long long *dst = nullptr;
     const bool want_stamps = getenv("GPBO_CI_STAMPS") && atoi(getenv("GPBO_CI_STAMPS")) && pair < 0;
