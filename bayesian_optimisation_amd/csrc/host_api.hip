@@ -88,10 +88,9 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
     const bool bound_route = !dense && diag_add == 0.0 && M >= 32768 && Np >= 1024 && d <= GPBO_MAX_D &&
                              (acq_kind == GPBO_ACQ_EI || p0 >= 0.0);
     const int64_t J1 = (Np / 16) / 128 * 128 < 128 ? 128 : (Np / 16) / 128 * 128, J2 = (8 * J1 <= Np) ? 4 * J1 : 0;
-    int64_t bcap = M / 16;   // most survivors the fp64 kernels re-score before the plain pass takes over
-    if (bcap < 65536) bcap = 65536;
-    if (bcap > M) bcap = M;
-    if (bcap < 4096) bcap = 4096;
+    // every first-level survivor may go on to the second-level bound (1/16 of a plain pass per candidate); the plain pass
+    // takes over when more than M / 8 reach the fp64 kernels (rescore.hip)
+    const int64_t bcap = M < 4096 ? 4096 : M;
     const int64_t bchunk = 1 << 14;
     const int64_t wresc = bound_route ? gpbo_rescore_workspace_bytes(Np, bcap, bchunk) : 0;
     if (wresc < 0) return GPBO_ERR_ARG;

@@ -622,6 +622,8 @@ static int bound_select_impl(const double *Xs, int64_t M, const double *ub, cons
                 K = K2;   // (never empty: the candidate that set the threshold has ub2 >= its exact value)
                 if (K == 0) return GPBO_ERR_LAUNCH;
             }
+            // the fp64 kernels on a list run in small chunks: beyond an eighth of the candidates the plain pass is cheaper
+            if ((int64_t)K > M / 8 && (int64_t)K > 4 * refine) break;
             rc = exact((int64_t)K, &h);
             if (rc != GPBO_OK) return rc;
             if (hipMemcpyAsync(result, &out->res, sizeof(gpbo_result), hipMemcpyDeviceToDevice, st) != hipSuccess)

@@ -618,7 +618,10 @@ class DeviceGP:
                     self._ptr(self._bound_ub), self._ptr(self._result), self._ptr(self._work_post), wbytes,
                     self._profile if self.profile_active else None, self._stream())
                 _lib.check(st, "gpbo_posterior_prefix_f64")
-            cap = self.screen_cap if self.screen_cap else max(4096, min(M, max(M // 16, 1 << 16)))
+            # every first-level survivor may go on to the second-level bound (N/4 rows: 1/16 of a plain pass per candidate -
+            # cheaper than falling back even if ALL of them survive); LCB(explore=10) on the headline workload leaves 256k
+            # of 2^21: 24 ms through the second level against 518 ms through the plain pass (tools/bound_cap_probe.py)
+            cap = self.screen_cap if self.screen_cap else max(4096, M)
             chunk64 = self.SCREEN_CHUNK64
             rbytes = int(self.lib.gpbo_rescore_workspace_bytes(self.Np, cap, chunk64))
             if rbytes < 0:

@@ -445,10 +445,14 @@ def main():
                               ("lcb_explore_10", dict(acquisition="lcb", explore=10.0)),
                               ("ei", dict(acquisition="ei", f_best=f_best, xi=0.0))):
                 rb = gp.score_bound(Xsd, idx_offset=lo, **kwx)
-                r6 = gp.score(Xsd, idx_offset=lo, **kwx)
+                tb = time.perf_counter()
+                rb = gp.score_bound(Xsd, idx_offset=lo, **kwx)   # (synchronous: reads the result back)
+                tb = (time.perf_counter() - tb) * 1e3
                 ls_ = gp.last_screen or {}
+                r6 = gp.score(Xsd, idx_offset=lo, **kwx)
                 surv[name] = dict(survivors_first_level=ls_.get("survivors"), rescored_in_fp64=ls_.get("rescored"),
-                                  fallback=ls_.get("fallback"), same_point_as_plain_pass=bool(rb.best_idx == r6.best_idx))
+                                  fallback=ls_.get("fallback"), ms_scoring=round(tb, 2),
+                                  same_point_as_plain_pass=bool(rb.best_idx == r6.best_idx))
             gp.score_async_bound(Xsd, **kwb)
             res["prefix_bound_screen_same_workload"] = dict(
                 value=(hi - lo) / (ms * 1e-3), unit="candidates disposed/s", ms_per_step=ms, argmax_index=i,
