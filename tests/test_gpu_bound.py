@@ -179,6 +179,29 @@ def test_weak_bounds_end_in_the_plain_pass_or_many_survivors_never_in_a_wrong_po
     assert g2.last_screen["fallback"] and r.best_idx == g2.score(Xsa).best_idx
 
 
+@pytest.mark.parametrize("explore", [10.0, 25.0, 1000.0])
+def test_large_exploration_weights_go_through_the_second_level_not_back_to_the_plain_pass(explore):
+    """The weaker the mean's grip, the more candidates survive the first-level bound: all of them may go on to the second
+    level (1/16 of a plain pass per candidate), and the plain pass takes over only when more than M/8 reach the fp64 kernels.
+    Whatever the route, the point is the plain pass's."""
+    N, M = 2048, 1 << 17
+    X, y, Xs, ls = make_problem(N, M, 8)
+    gp = DeviceGP().factorise(X, y, ls)
+    rb = gp.score_bound(Xs, explore=explore)
+    scr = dict(gp.last_screen)
+    _same(rb, gp.score(Xs, explore=explore))
+    assert scr["mode"] == "bound" and scr["prefix2"] > 0
+    if not scr["fallback"]:
+        assert scr["rescored"] <= max(M // 8, 4 * 4096)
+    if explore == 10.0:   # more first-level survivors than the old limit (M / 16) allowed, and still no plain pass
+        assert scr["survivors"] > M // 16 and not scr["fallback"], scr
+    # with the old limit forced, the same call ends in the plain pass - and in the same point
+    gp.screen_cap = M // 16
+    rc = gp.score_bound(Xs, explore=explore)
+    _same(rc, rb)
+    gp.screen_cap = None
+
+
 @pytest.mark.parametrize("name", ["g5_d8_n512_m4096", "g5_d8_n2048_m4096", "g6_d16_n256_m2048"])
 def test_bound_screen_selects_the_reference_point(golden, name):
     """Vectors produced by the reference itself (tests/golden/make_golden.py)."""
