@@ -10,7 +10,7 @@ REPS = 3
 rows = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))))
 t = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
-    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
     t[k][0] += 1; t[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 lines = [f"# N={N}: per factorisation (means over {REPS} calls of gpbo_factorise_f64), MI355X, rocprofv3 kernel trace"]
 tot = sum(v[1] for v in t.values()) / REPS
@@ -20,7 +20,7 @@ lines.append(f"kernel_time,TOTAL,,us={tot:.1f},")
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]) / REPS
 for k in ("cholinv_kernel", "kxx_kernel", "transpose_w_kernel"):
     for c, v in sorted(agg.get(k, {}).items()):
