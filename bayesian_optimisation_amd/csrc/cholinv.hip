@@ -739,8 +739,25 @@ __device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, in
 // result kept reproducible).  Its 128 accumulator registers push the WHOLE kernel to 256 VGPRs with spills and a scratch
 // segment; without it (every default plan) the kernel needs 225 registers and no scratch, and the same launches run 1.4 %
 // (N = 4096) / 2.1 % (N = 8192) faster.
+// The arguments are passed one by one, in the order the critical workgroups need them (PAIR: S, ld, Np, pair, npair; NEAR:
+// those and its eight shape words): build.sh compiles this file with -amdgpu-kernarg-preload-count=16, so that the first 16
+// dwords arrive in scalar registers WITH the wave instead of through a load from the argument buffer that every workgroup
+// used to wait for before it could form its first address.
 template <bool WITH256>
-__global__ __launch_bounds__(512) void cholinv_kernel(CiArgs a) {
+__global__ __launch_bounds__(512) void cholinv_kernel(double *S_, int64_t ld_, int32_t Np_, int32_t pair_, int32_t npair_,
+                                                      int32_t n_on, int32_t n_k0, int32_t n_K, int32_t n_row0, int32_t n_wlim,
+                                                      int32_t n_w, int32_t n_n0, int32_t n_r1, int32_t tile0_, int32_t ntile_,
+                                                      int32_t group_, const CiTile *tab_, int32_t *info_,
+                                                      unsigned long long *stamps_) {
+    CiArgs a;
+    a.S = S_;
+    a.ld = ld_;
+    a.Np = Np_;
+    a.info = info_;
+    a.stamps = stamps_;
+    a.tab = tab_;
+    a.l = CiLaunch{pair_, npair_, tile0_, ntile_, group_};
+    a.near = CiNear{n_on, n_k0, n_K, n_row0, n_wlim, n_w, n_n0, n_r1};
     __shared__ double smem[SMEM_D];
     const int b = blockIdx.x;
     if (b < a.l.npair) {
@@ -793,6 +810,9 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const double *__restri
 }
 
 }  // namespace
+
+#define CI_FLAT_ARGS(a) (a).S, (a).ld, (a).Np, (a).l.pair, (a).l.npair, (a).near.on, (a).near.k0, (a).near.K, (a).near.row0, (a).near.wlim, \
+    (a).near.w, (a).near.n0, (a).near.r1, (a).l.tile0, (a).l.ntile, (a).l.group, (a).tab, (a).info, (a).stamps
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 // The plan of a size is built once and its tile table kept on the device (per device, size and options), for the life of
@@ -890,8 +910,8 @@ int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int
 #ifdef GPBO_DIAGNOSTICS
         a.stamps = (want_stamps && l.npair > 0 && npair < 1024) ? dstamps + 8 * npair++ : nullptr;
 #endif
-        if (dp->has256) hipLaunchKernelGGL(cholinv_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL(cholinv_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, st, a);
+        if (dp->has256) hipLaunchKernelGGL(cholinv_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, st, CI_FLAT_ARGS(a));
+        else hipLaunchKernelGGL(cholinv_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, st, CI_FLAT_ARGS(a));
     }
     GPBO_CHECK_LAUNCH();
 #ifdef GPBO_DIAGNOSTICS
@@ -1000,8 +1020,8 @@ extern "C" int gpbo_cholinv_tiles_f64(double *S, int64_t ld, int64_t Np, int32_t
     bool any256 = false;
     for (const CiTile &t : h) any256 = any256 || t.kind == CI_UPD_BIG256;
     for (int r = 0; r < reps; ++r) {
-        if (any256) hipLaunchKernelGGL(cholinv_kernel<true>, dim3((unsigned)ci_launch_blocks(a.l)), dim3(512), 0, gpbo_stream(stream), a);
-        else hipLaunchKernelGGL(cholinv_kernel<false>, dim3((unsigned)ci_launch_blocks(a.l)), dim3(512), 0, gpbo_stream(stream), a);
+        if (any256) hipLaunchKernelGGL(cholinv_kernel<true>, dim3((unsigned)ci_launch_blocks(a.l)), dim3(512), 0, gpbo_stream(stream), CI_FLAT_ARGS(a));
+        else hipLaunchKernelGGL(cholinv_kernel<false>, dim3((unsigned)ci_launch_blocks(a.l)), dim3(512), 0, gpbo_stream(stream), CI_FLAT_ARGS(a));
     }
     const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(gpbo_stream(stream)) == hipSuccess;
 #ifdef GPBO_DIAGNOSTICS

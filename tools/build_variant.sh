@@ -5,7 +5,8 @@ set -euo pipefail
 NAME=$1; FILE=$2; EXTRA=${3:-}
 cd "$(dirname "$0")/../bayesian_optimisation_amd/csrc"
 mkdir -p ../../ab_libs build
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $EXTRA -c $FILE.hip -o build/${FILE}_$NAME.o
+X=""; [ $FILE = cholinv ] && X="-mllvm -amdgpu-kernarg-preload-count=16"   # as build.sh does
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $X $EXTRA -c $FILE.hip -o build/${FILE}_$NAME.o
 objs=""
 for f in api kernel_build kstar_mfma gemm_f64 factor cholinv subset update sigma_acq ard posterior_f32 rescore ozaki host_api; do
   if [ $f = $FILE ]; then objs="$objs build/${FILE}_$NAME.o"; else objs="$objs build/$f.o"; fi
