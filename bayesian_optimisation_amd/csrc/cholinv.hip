@@ -588,7 +588,7 @@ __device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, in
     }
     __syncthreads();
     CI_STAMP();
-#ifdef GPBO_CI_F64_STAMPS
+#if defined(GPBO_CI_F64_STAMPS) && GPBO_CI_F64_STAMPS == 1   // (= 2: the stamps of the SECOND elimination instead)
     const int bad1 = factor64(B0, B1, w, lane, false, [](int) {}, (stamps && pt == 0) ? stamps : nullptr);
 #else
     const int bad1 = factor64(B0, B1, w, lane, false, [](int) {});   // ends with a barrier after the last panel step
@@ -713,7 +713,11 @@ __device__ __forceinline__ void pair_body(double *__restrict__ S, int64_t ld, in
             }
         }
     };
+#if defined(GPBO_CI_F64_STAMPS) && GPBO_CI_F64_STAMPS == 2
+    const int bad2 = factor64(B0, B2, w, lane, true, x_bg, (stamps && pt == 0) ? stamps : nullptr);
+#else
     const int bad2 = factor64(B0, B2, w, lane, true, x_bg);
+#endif
     CI_STAMP();
     if (pt == 0 && tid == 0) {
         const int bad = bad1 ? r0 + bad1 : (bad2 ? r0 + 64 + bad2 : 0);
