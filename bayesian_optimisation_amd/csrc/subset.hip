@@ -47,6 +47,33 @@ __device__ __forceinline__ void block_argmax(double &v, int64_t &i, double *s_va
     __syncthreads();
 }
 
+// extension to J2 members: unchosen observations (mind > -inf) in index order; thread t of the FT owns a contiguous range
+__device__ __forceinline__ void fps_extend(int64_t N, int64_t J, int64_t J2, const double *__restrict__ mind,
+                                           int64_t *__restrict__ perm, long long *s_scan) {
+    const int tid = threadIdx.x;
+    const double ninf = -std::numeric_limits<double>::infinity();
+    if (J2 > J) {
+        const int64_t per = (N + FT - 1) / FT, lo = (int64_t)tid * per, hi = (lo + per < N) ? lo + per : N;
+        long long cnt = 0;
+        for (int64_t i = lo; i < hi; ++i) cnt += (mind[i] != ninf);
+        s_scan[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < FT; off <<= 1) {  // inclusive Hillis-Steele scan
+            const long long add = (tid >= off) ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += add;
+            __syncthreads();
+        }
+        long long pos = s_scan[tid] - cnt;
+        for (int64_t i = lo; i < hi; ++i) {
+            if (mind[i] != ninf) {
+                if (pos < J2 - J) perm[J + pos] = i;
+                ++pos;
+            }
+        }
+    }
+}
+
 // perm[0 .. J) = farthest-point sequence; perm[J .. J2) = the first J2 - J observations not among them, in index order.
 // One workgroup.  PTS > 0: every thread keeps its PTS observations (scaled coordinates) and their distances to the
 // member set in registers (N <= 1024 PTS) - a selection step is then d fmas per point and one block arg-max, ~1 us;
@@ -145,27 +172,126 @@ __global__ __launch_bounds__(FT) void fps_kernel(const double *__restrict__ X, i
         }
         __syncthreads();
     }
-    // extension to J2 members: unchosen observations (mind > -inf) in index order; thread t owns a contiguous range
-    if (J2 > J) {
-        const int64_t per = (N + FT - 1) / FT, lo = (int64_t)tid * per, hi = (lo + per < N) ? lo + per : N;
-        long long cnt = 0;
-        for (int64_t i = lo; i < hi; ++i) cnt += (mind[i] != ninf);
-        s_scan[tid] = cnt;
+    fps_extend(N, J, J2, mind, perm, s_scan);
+}
+
+// ---- the same selection as ONE LAUNCH PER STEP, for sizes whose points do not fit one workgroup's registers --------------
+// (8 points x 8 coordinates per thread of the 1024 spill: 12 us per step, 6.9 ms of sampling at N = 8192, d = 8; the
+// single-workgroup global-memory form is slower still.)  Every workgroup folds the newest member into the running minimum
+// of its own points and writes its best (value, index); the workgroup that finishes LAST - an atomic ticket, no waiting -
+// reduces the partials in workgroup order and publishes the next member.  Same arithmetic, same tie rule (lowest index),
+// hence the same sequence as fps_kernel; the cost is a kernel boundary per member (~2.5 us).
+constexpr int FG = 256;
+struct FpsState {
+    int64_t member;        // newest member (read by the next launch)
+    unsigned int ticket;   // workgroups of the current launch that have finished
+    unsigned int pad;
+    double centre[GPBO_MAX_D];   // scaled coordinates the next launch measures distances to
+};
+
+__global__ __launch_bounds__(FT) void fps_centroid_kernel(const double *__restrict__ X, int64_t N, int d, FpsLs ls,
+                                                          FpsState *__restrict__ stt) {
+    __shared__ double s_part[FT];
+    const int tid = threadIdx.x;
+    for (int k = 0; k < d; ++k) {   // the fixed-order reduction of fps_kernel
+        double s = 0.0;
+        for (int64_t i = tid; i < N; i += FT) s += X[i * d + k] * ls.isc[k];
+        s_part[tid] = s;
         __syncthreads();
-        for (int off = 1; off < FT; off <<= 1) {  // inclusive Hillis-Steele scan
-            const long long add = (tid >= off) ? s_scan[tid - off] : 0;
-            __syncthreads();
-            s_scan[tid] += add;
-            __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int q = 0; q < FT; ++q) t += s_part[q];
+            stt->centre[k] = t / (double)N;
         }
-        long long pos = s_scan[tid] - cnt;
-        for (int64_t i = lo; i < hi; ++i) {
-            if (mind[i] != ninf) {
-                if (pos < J2 - J) perm[J + pos] = i;
-                ++pos;
-            }
-        }
+        __syncthreads();
     }
+    if (tid == 0) { stt->member = -1; stt->ticket = 0; }
+}
+
+__global__ __launch_bounds__(FG) void fps_step_kernel(const double *__restrict__ X, int64_t N, int d, FpsLs ls,
+                                                      double *__restrict__ mind, FpsState *__restrict__ stt,
+                                                      double *__restrict__ pval, int64_t *__restrict__ pidx,
+                                                      int64_t *__restrict__ perm, int64_t j, int64_t J) {
+    __shared__ double s_val[FG / 64];
+    __shared__ int64_t s_idx[FG / 64];
+    __shared__ double s_c[GPBO_MAX_D];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const double ninf = -std::numeric_limits<double>::infinity();
+    const int64_t member = stt->member;
+    if (tid < d) s_c[tid] = stt->centre[tid];
+    __syncthreads();
+    double bv = ninf;
+    int64_t bi = std::numeric_limits<int64_t>::max();
+    for (int64_t i = (int64_t)blockIdx.x * FG + tid; i < N; i += (int64_t)gridDim.x * FG) {
+        double dist = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double df = X[i * d + k] * ls.isc[k] - s_c[k];
+            dist = fma(df, df, dist);
+        }
+        double m = dist;
+        if (member >= 0) {
+            m = fmin(mind[i], dist);
+            if (i == member) m = ninf;  // a member is never chosen again
+            mind[i] = m;
+        } else {
+            mind[i] = std::numeric_limits<double>::infinity();
+        }
+        if (gpbo_better(m, i, bv, bi)) { bv = m; bi = i; }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int64_t oi = __shfl_xor(bi, off);
+        if (gpbo_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { s_val[w] = bv; s_idx[w] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 1; q < FG / 64; ++q)
+            if (gpbo_better(s_val[q], s_idx[q], bv, bi)) { bv = s_val[q]; bi = s_idx[q]; }
+        pval[blockIdx.x] = bv;
+        pidx[blockIdx.x] = bi;
+        __threadfence();
+        s_last = (atomicAdd(&stt->ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last) {  // every workgroup's partial is visible: reduce them (the order does not matter: largest value, lowest
+        __threadfence();   // index among equals) and publish the next member
+        double v = ninf;
+        int64_t p = std::numeric_limits<int64_t>::max();
+        for (unsigned b = tid; b < gridDim.x; b += FG) {
+            const double ov = pval[b];
+            const int64_t oi = pidx[b];
+            if (gpbo_better(ov, oi, v, p)) { v = ov; p = oi; }
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double ov = __shfl_xor(v, off);
+            const int64_t oi = __shfl_xor(p, off);
+            if (gpbo_better(ov, oi, v, p)) { v = ov; p = oi; }
+        }
+        if (lane == 0) { s_val[w] = v; s_idx[w] = p; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int q = 1; q < FG / 64; ++q)
+                if (gpbo_better(s_val[q], s_idx[q], v, p)) { v = s_val[q]; p = s_idx[q]; }
+            if (j < J) perm[j] = p;
+            stt->member = p;
+            stt->ticket = 0;
+        }
+        __syncthreads();
+        if (tid == 0) s_idx[0] = p;
+        __syncthreads();
+        const int64_t pw = s_idx[0];
+        if (tid < d) stt->centre[tid] = X[pw * d + tid] * ls.isc[tid];
+    }
+}
+
+__global__ __launch_bounds__(FT) void fps_extend_kernel(int64_t N, int64_t J, int64_t J2, const double *__restrict__ mind,
+                                                        int64_t *__restrict__ perm) {
+    __shared__ long long s_scan[FT];
+    fps_extend(N, J, J2, mind, perm, s_scan);
 }
 
 __global__ void gather_obs_kernel(const double *__restrict__ X, int d, const int64_t *__restrict__ perm, int64_t n,
@@ -176,14 +302,16 @@ __global__ void gather_obs_kernel(const double *__restrict__ X, int d, const int
 }
 
 struct SubsetLayout {
-    int64_t mind_off, k_off, y_off, alpha_off, fact_off, fact_bytes, total;
+    int64_t mind_off, fps_off, k_off, y_off, alpha_off, fact_off, fact_bytes, total;
 };
+constexpr int FPS_MAXG = 256;  // workgroups of a selection step at most
 
 SubsetLayout subset_layout(int64_t N, int64_t Ns) {
     SubsetLayout L;
     int64_t off = 0;
     auto take = [&](int64_t bytes) { const int64_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     L.mind_off = take((int64_t)sizeof(double) * N);
+    L.fps_off = take((int64_t)sizeof(FpsState) + (int64_t)FPS_MAXG * (sizeof(double) + sizeof(int64_t)) + 256);
     L.k_off = take((int64_t)sizeof(double) * Ns * Ns);
     L.y_off = take((int64_t)sizeof(double) * Ns);
     L.alpha_off = take((int64_t)sizeof(double) * Ns);
@@ -222,7 +350,9 @@ extern "C" int gpbo_bound_subset_f64(const double *X, int64_t N, int32_t d, cons
     double *Ksub = reinterpret_cast<double *>(w + L.k_off);
     double *ysub = reinterpret_cast<double *>(w + L.y_off);
     double *asub = reinterpret_cast<double *>(w + L.alpha_off);
-    // registers hold up to 8 observations per thread at d <= 8 (4 at d <= 16); beyond: the global-memory form
+    // one workgroup with every thread's observations in registers while that is the faster form (measured at N = 8192 /
+    // 6000: 8 points per thread at d = 4 - 116 bytes of spills - 3.1 ms against 4.3 by launches; at d = 8 - 404 bytes -
+    // 6.9 against 4.4; at d = 6 2.5 against 2.2); beyond: one launch per member (fps_step_kernel)
 #define GPBO_FPS(P, DD) hipLaunchKernelGGL((fps_kernel<P, DD>), dim3(1), dim3(FT), 0, st, X, N, (int)d, ls, J, Ns, mind, perm_out)
     const int64_t pts = (N + FT - 1) / FT;
     bool launched = false;
@@ -230,12 +360,23 @@ extern "C" int gpbo_bound_subset_f64(const double *X, int64_t N, int32_t d, cons
     if (!launched && d == DD) {                                                          \
         if (pts <= 1) { GPBO_FPS(1, DD); launched = true; }                              \
         else if (pts <= 2) { GPBO_FPS(2, DD); launched = true; }                         \
-        else if (pts <= 4) { GPBO_FPS(4, DD); launched = true; }                         \
-        else if (pts <= 8 && DD <= 8) { GPBO_FPS(8, DD); launched = true; }              \
+        else if (pts <= 4 && DD <= 8) { GPBO_FPS(4, DD); launched = true; }              \
+        else if (pts <= 8 && DD <= 4) { GPBO_FPS(8, DD); launched = true; }              \
     }
     GPBO_FPS_D(1) GPBO_FPS_D(2) GPBO_FPS_D(3) GPBO_FPS_D(4) GPBO_FPS_D(5) GPBO_FPS_D(6) GPBO_FPS_D(7) GPBO_FPS_D(8)
     GPBO_FPS_D(9) GPBO_FPS_D(10) GPBO_FPS_D(11) GPBO_FPS_D(12) GPBO_FPS_D(13) GPBO_FPS_D(14) GPBO_FPS_D(15) GPBO_FPS_D(16)
-    if (!launched) GPBO_FPS(0, 1);
+    if (!launched) {
+        // one launch per member (the state block: FpsState, then the workgroups' partial values and indices)
+        FpsState *stt = reinterpret_cast<FpsState *>(w + L.fps_off);
+        double *pval = reinterpret_cast<double *>(w + L.fps_off + ((sizeof(FpsState) + 255) / 256) * 256);
+        int64_t *pidx = reinterpret_cast<int64_t *>(pval + FPS_MAXG);
+        int64_t G = (N + FG - 1) / FG;
+        if (G > FPS_MAXG) G = FPS_MAXG;
+        hipLaunchKernelGGL(fps_centroid_kernel, dim3(1), dim3(FT), 0, st, X, N, (int)d, ls, stt);
+        for (int64_t j = 0; j <= J; ++j)   // launch j: folds member j - 1 in and picks member j (the last one only folds)
+            hipLaunchKernelGGL(fps_step_kernel, dim3((unsigned)G), dim3(FG), 0, st, X, N, (int)d, ls, mind, stt, pval, pidx, perm_out, j, J);
+        hipLaunchKernelGGL(fps_extend_kernel, dim3(1), dim3(FT), 0, st, N, J, Ns, mind, perm_out);
+    }
 #undef GPBO_FPS_D
 #undef GPBO_FPS
     const int64_t tot = Ns * d;

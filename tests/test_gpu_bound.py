@@ -298,10 +298,11 @@ def _fps_reference(X, ls, J):
     return np.array(order)
 
 
-@pytest.mark.parametrize("N,d", [(1500, 5), (9300, 3), (700, 16)])
+@pytest.mark.parametrize("N,d", [(1500, 5), (9300, 3), (700, 16), (3000, 16), (5000, 8)])
 def test_subset_is_farthest_point_sampling_and_its_factor_is_the_subsets(N, d):
     """gpbo_bound_subset_f64 against NumPy: the members, their extension in index order, the gathered rows and
-    U_S = chol(K_SS + jitter)^-T of exactly those rows (register-resident kernel, and the any-N form at N = 9300)."""
+    U_S = chol(K_SS + jitter)^-T of exactly those rows (register-resident kernel; one launch per member where a thread's
+    points would not fit its registers: N = 9300, 3000 x 16, 5000 x 8)."""
     X, y, Xs, ls = make_problem(N, 512, d)
     gp = DeviceGP().factorise(X, y, ls)
     J, J2 = 128, 512
