@@ -250,19 +250,22 @@ __global__ __launch_bounds__(FG) void fps_step_kernel(const double *__restrict__
     if (tid == 0) {
         for (int q = 1; q < FG / 64; ++q)
             if (gpbo_better(s_val[q], s_idx[q], bv, bi)) { bv = s_val[q]; bi = s_idx[q]; }
-        pval[blockIdx.x] = bv;
-        pidx[blockIdx.x] = bi;
-        __threadfence();
-        s_last = (atomicAdd(&stt->ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+        // The partials travel as device-scope (sc1, write-through) atomic stores, acknowledged before the ticket is taken; the
+        // last workgroup reads them with device-scope atomic loads.  No __threadfence: a release at device scope writes the
+        // whole L2's dirty lines back (the running minima this launch has just stored - which only the NEXT launch reads,
+        // after the kernel boundary): two such fences were most of a 7-us step.
+        __hip_atomic_store(pval + blockIdx.x, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pidx + blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = (__hip_atomic_fetch_add(&stt->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
-    if (s_last) {  // every workgroup's partial is visible: reduce them (the order does not matter: largest value, lowest
-        __threadfence();   // index among equals) and publish the next member
-        double v = ninf;
+    if (s_last) {  // every workgroup's partial has been acknowledged: reduce them (the order does not matter: largest value,
+        double v = ninf;   // lowest index among equals) and publish the next member
         int64_t p = std::numeric_limits<int64_t>::max();
         for (unsigned b = tid; b < gridDim.x; b += FG) {
-            const double ov = pval[b];
-            const int64_t oi = pidx[b];
+            const double ov = __hip_atomic_load(pval + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t oi = __hip_atomic_load(pidx + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (gpbo_better(ov, oi, v, p)) { v = ov; p = oi; }
         }
 #pragma unroll

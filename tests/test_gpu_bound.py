@@ -315,6 +315,9 @@ def test_subset_is_farthest_point_sampling_and_its_factor_is_the_subsets(N, d):
     assert np.array_equal(perm[:J], ref)
     rest = np.setdiff1d(np.arange(N), ref)[: J2 - J]
     assert np.array_equal(perm[J:], rest) and len(set(perm.tolist())) == J2
+    for _ in range(3):   # the same members every time (the one-launch-per-member form hands partial results between workgroups)
+        gp._bound_subset = None
+        assert np.array_equal(gp._ensure_bound_subset(J, J2)[3].cpu().numpy(), perm)
     assert np.array_equal(Xsub.cpu().numpy(), X[perm])
     K = O.kernel_rbf(X[perm], X[perm], ls) + 1e-6 * np.eye(J2)   # kernel_rbf adds its own 1e-4 (same shapes)
     L = np.linalg.cholesky(K)
