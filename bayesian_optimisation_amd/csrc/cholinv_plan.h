@@ -66,7 +66,9 @@ struct CiPlanOptions {
 inline CiPlanOptions ci_default_options(int Np) {
     CiPlanOptions o;
     o.win = 1;
-    o.far_k = (Np >= 6144) ? 384 : 256;  // measured on MI355X, N = 8192: 9.51 ms at 384 against 9.75 - 9.86 at 256 / 512
+    // measured on MI355X (end of round 3): N = 8192: 9.10 ms at 384 against 9.26 / 9.28 at 256 / 512; 7168: 6.65 either way;
+    // 6144: 4.50 at 256 against 4.68 at 384; 5120: 3.05 against 3.29; 4096: 1.86 against 2.06 (and 2.48 at 128)
+    o.far_k = (Np >= 7680) ? 384 : 256;
     o.far_kind = CI_UPD_BIG;
     o.defer = 2;
     o.ncu = 256;

@@ -18,7 +18,7 @@ from cholinv_sim import BIG, BIG256, SMALL, get_plan, run_plan, spd
 
 OPTS = [(128, None), (256, None), (384, None), (512, None), (640, [1, 128, 3, 1]), (896, None), (896, [2, 256, 4, 2]),
         (1024, [3, 384, 3, 2]), (1152, [1, 256, 4, 1]), (1536, [2, 512, 4, 3]), (1664, None), (1664, [3, 256, 4, 3]), (2048, [1, 128, 3, 1, 0, 2]), (768, [1, 256, 3, 3, 0, 0, 64]),
-        (1536, [1, 384, 3, 3, 0, 0, 64])]   # the last: the options N >= 6144 runs with, at a size the CPU executes quickly
+        (1536, [1, 384, 3, 3, 0, 0, 64])]   # the last: the options N >= 7680 runs with, at a size the CPU executes quickly
 
 
 @pytest.mark.parametrize("Np,opt", OPTS)
