@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpbo.so")
+# GPBO_LIB=/path/to/variant.so: A/B and timing-only builds (tools/ab*.sh, tools/build_variant.sh) are loaded from where
+# they were built; the installed library is never overwritten by a tool.
+LIB_PATH = os.environ.get("GPBO_LIB") or os.path.join(_HERE, "libgpbo.so")
 
 GPBO_OK = 0
 ACQ_LCB = 0

@@ -875,8 +875,9 @@ static const DevPlan *plan_for(int Np, const CiPlanOptions &o) {
 }
 
 static bool ci_sizes_ok(const double *S, int64_t ld, int64_t Np) {
-    return S && Np >= 128 && Np % 128 == 0 && ld >= 2 * Np && (ld & 1) == 0 && Np <= 32768 &&
-           (int64_t)15 * ld + 256 <= 0x7fffffffLL;
+    // 16-byte alignment: upd_big fills LDS with 16-byte global_load_lds straight from S (ld even keeps every row aligned)
+    return S && ((uintptr_t)S & 15) == 0 && Np >= 128 && Np % 128 == 0 && ld >= 2 * Np && (ld & 1) == 0 &&
+           Np <= GPBO_CHOLINV_MAX_NP && (int64_t)15 * ld + 256 <= 0x7fffffffLL;
 }
 
 // S: [Np x ld] row-major, ld >= 2 Np, columns [0, Np) = the symmetric positive definite matrix, [Np, 2 Np) = zeros.
@@ -944,7 +945,7 @@ int gpbo_launch_transpose_w(const double *W, int64_t ldw, int64_t Np, double *U,
 // ---- plan introspection for the CPU simulator (no GPU needed) -----------------------------------------------------
 extern "C" int gpbo_cholinv_plan(int64_t Np, const int32_t *opt, int64_t *n_launch, int64_t *n_tile, int32_t *launches,
                                  int32_t *tiles) {
-    if (Np < 128 || Np % 128 || Np > 32768 || !n_launch || !n_tile) return GPBO_ERR_ARG;
+    if (Np < 128 || Np % 128 || Np > GPBO_CHOLINV_MAX_NP || !n_launch || !n_tile) return GPBO_ERR_ARG;
     const CiPlanOptions o = ci_options_from((int)Np, opt);
     if (!ci_options_ok(o)) return GPBO_ERR_ARG;
     const CiPlan P = ci_plan((int)Np, o);

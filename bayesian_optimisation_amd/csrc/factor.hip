@@ -445,7 +445,8 @@ extern "C" int gpbo_factorise_f64(const double *X, const double *y, int64_t N, i
     // half; U is its transpose.  The two-pass chain of round 2 (blocked Cholesky, then the block-recursive triangular
     // inverse) stays behind GPBO_FACTOR_OLD=1 for A/B runs and behind gpbo_potrf_f64 / gpbo_trtri_f64.
     static const bool old_chain = getenv("GPBO_FACTOR_OLD") && atoi(getenv("GPBO_FACTOR_OLD"));
-    if (!old_chain) {
+    // (the fused sweep's plan stops at Np = 32768 - 32-bit tile offsets; beyond, the two-pass chain, which has no such cap)
+    if (!old_chain && Np <= GPBO_CHOLINV_MAX_NP) {
         double *S = L;  // [Np x 2 Np]: the same 2 Np^2 doubles
         int rc = gpbo_kxx_launch(X, N, d, ls_host, jitter1, jitter2, Kp, Np, S, 2 * Np, info, stream);
         if (rc != GPBO_OK) return rc;

@@ -9,6 +9,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
 #define GPBO_NB 64 /* Cholesky / triangular-inverse block size */
+#define GPBO_CHOLINV_MAX_NP 32768 /* largest padded size the fused sweep's plan covers (cholinv_plan.h: 32-bit tile offsets) */
 #ifndef GPBO_KS_SLICE
 #define GPBO_KS_SLICE 64 /* observations per workgroup of the K(X*,X) kernel = rows per mu_part slice */
 #endif

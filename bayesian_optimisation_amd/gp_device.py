@@ -270,6 +270,7 @@ class DeviceGP:
             self.info.zero_()
             self._u32_valid = False
             self._u8_valid = False
+            self._bound_subset = None   # the prefix bound's subset (Xsub, chol(K_SS)^-T) belongs to the old observations
             self._work_post = None
         return self
 

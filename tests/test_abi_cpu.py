@@ -100,6 +100,30 @@ def test_size_contracts_are_checked_on_the_host():
     assert lib.gpbo_trtri_f64(p, p, 100, p, p, None) == -1
     # ARD grid: N beyond the in-LDS limit
     assert lib.gpbo_nlml_grid_f64(p, p, 177, 2, p, 4, 1e-4, p, None) == -1
+    # fused factorisation: S is read by 16-byte LDS-DMA pieces - an 8-byte-offset view is refused, as are an odd or short ld
+    p8 = C.c_void_p(p.value + 8)
+    assert lib.gpbo_cholinv_f64(p8, 512, 256, p, None, None) == -1
+    assert lib.gpbo_cholinv_f64(p, 511, 256, p, None, None) == -1
+    assert lib.gpbo_cholinv_f64(p, 510, 256, p, None, None) == -1
+    assert lib.gpbo_cholinv_f64(p, 2 * 32896, 32896, p, None, None) == -1   # beyond the plan's cap: factorise takes the chain
+
+
+def test_library_path_override(monkeypatch):
+    """GPBO_LIB=/path/to/variant.so makes _lib load that file: A/B tools never overwrite the installed library."""
+    import importlib
+    import subprocess
+    import sys
+
+    code = (f"import sys; sys.path.insert(0, {REPO!r}); import os; os.environ['GPBO_LIB'] = '/nonexistent/variant.so'\n"
+            "from bayesian_optimisation_amd import _lib\n"
+            "try:\n    _lib.load(); print('loaded')\nexcept _lib.GpboError as e:\n    print('refused', '/nonexistent/variant.so' in str(e))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip() == "refused True", out.stdout + out.stderr
+    for f in os.listdir(os.path.join(REPO, "tools")):
+        if f.endswith(".sh"):
+            txt = open(os.path.join(REPO, "tools", f)).read()
+            assert "bayesian_optimisation_amd/libgpbo.so" not in txt.replace("cp bayesian_optimisation_amd/libgpbo.so ab_libs/", ""), \
+                f"tools/{f} touches the installed library"
 
 
 def test_product_path_fails_loudly_without_gpu():
