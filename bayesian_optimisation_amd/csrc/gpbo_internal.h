@@ -75,18 +75,12 @@ int gpbo_launch_transpose_upper(const double *W, int64_t Np, double *U, hipStrea
 int gpbo_launch_argmax_finish(const double *part_val, const int64_t *part_idx, int64_t nparts,
                               const unsigned long long *nan_count, gpbo_result *result, hipStream_t st);
 int64_t gpbo_posterior_workspace_bytes_split(int64_t Np, int64_t chunk, int64_t M, int split_max);
-// observation subset of the prefix bound (subset.hip): the variance side of a prefix pass reads these instead of X / U
-struct GpboSubset {
-    const double *X;   // [N x d] the members, in subset order
-    int64_t N, Np;     // members, rows of U (N <= Np, Np a multiple of 128)
-    const double *U;   // [Np x Np] chol(K_SS)^-T
-};
 int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
                                  const double *ls_host, const double *U, const double *alpha, double prior_var,
                                  int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset,
                                  int64_t chunk, double *mu_out, double *sigma_out, double *acq_out, gpbo_result *result,
                                  void *work, int64_t work_bytes, gpbo_profile *prof, int split_max, int64_t n_prefix,
-                                 void *stream, const GpboSubset *sub = nullptr);
+                                 void *stream);
 #define GPBO_RESCORE_SPLIT_MAX 64
 int gpbo_potrf_batched(double *Ab, int64_t Ne, int nbf, int batch, double *dinv, int32_t *info, hipStream_t st);
 int gpbo_gemm_launch_tri(int transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,

@@ -71,7 +71,7 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
 
     DeviceArena A;
     if (!A.ok) return GPBO_ERR_LAUNCH;
-    double *dX = A.alloc<double>(N * d), *dy = A.alloc<double>(N), *dXs = A.alloc<double>(M * d);
+    double *dX = A.alloc<double>(N * d), *dy = A.alloc<double>(N), *dXs = A.alloc<double>(M * d);   // (dX / dy: re-pointed below)
     double *dK = A.alloc<double>(Np * Np), *dU = A.alloc<double>(Np * Np), *dalpha = A.alloc<double>(Np);
     int32_t *dinfo = A.alloc<int32_t>(1);
     gpbo_result *dres = A.alloc<gpbo_result>(1);
@@ -85,8 +85,10 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
     // A caller that asks for the next point only (no dense arrays) gets it by branch and bound on the exact prefix bound
     // (same point, same NaN count, the plain pass when the bound does not separate the candidates); the same
     // rule and the same prefix lengths as DeviceGP.score_bound.
+    // (jitter: with K = k(X,X) + tau I the true variance is >= tau, so the plain pass's sqrt(|var|) never reflects a
+    //  negative value unless its rounding error exceeds tau - the one case a prefix cannot bound; DeviceGP.BOUND_MIN_JITTER)
     const bool bound_route = !dense && diag_add == 0.0 && M >= 32768 && Np >= 1024 && d <= GPBO_MAX_D &&
-                             (acq_kind == GPBO_ACQ_EI || p0 >= 0.0);
+                             (acq_kind == GPBO_ACQ_EI || p0 >= 0.0) && jitter1 + jitter2 >= 1e-6;
     const int64_t J1 = (Np / 16) / 128 * 128 < 128 ? 128 : (Np / 16) / 128 * 128, J2 = (8 * J1 <= Np) ? 4 * J1 : 0;
     // every first-level survivor may go on to the second-level bound (1/16 of a plain pass per candidate); the plain pass
     // takes over when more than M / 8 reach the fp64 kernels (rescore.hip)
@@ -96,23 +98,30 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
     if (wresc < 0) return GPBO_ERR_ARG;
     double *dub = bound_route ? A.alloc<double>(M) : nullptr;
     char *dresc = bound_route ? A.alloc<char>(wresc + 256) : nullptr;
-    // the bound's observation subset (subset.hip): chosen by farthest-point sampling, independent of the arrival order
-    const int64_t Ns = (J2 > J1) ? J2 : J1;
-    const bool with_subset = bound_route && Ns <= N;
-    const int64_t wsub = with_subset ? gpbo_bound_subset_workspace_bytes(N, Ns) : 0;
-    if (wsub < 0) return GPBO_ERR_ARG;
-    int64_t *dperm = with_subset ? A.alloc<int64_t>(Ns) : nullptr;
-    double *dXsub = with_subset ? A.alloc<double>(Ns * d) : nullptr;
-    double *dUsub = with_subset ? A.alloc<double>(Ns * Ns) : nullptr;
-    int32_t *dinfo_sub = with_subset ? A.alloc<int32_t>(1) : nullptr;
-    char *dwsub = with_subset ? A.alloc<char>(wsub + 256) : nullptr;
+    // the bound prunes by the FIRST J1 observations of the factorised problem: factorise the farthest-point order of the
+    // observations (subset.hip), so that the pruning does not depend on the order in which they arrived.  cov_meas_out is
+    // the reference's matrix in ARRIVAL order: a caller who wants it gets the arrival-order factorisation.
+    const bool fps_order = bound_route && J1 < N && !cov_meas_out;
+    const int64_t word = fps_order ? gpbo_fps_order_workspace_bytes(N) : 0;
+    int64_t *dperm = fps_order ? A.alloc<int64_t>(N) : nullptr;
+    double *dXp = fps_order ? A.alloc<double>(N * d) : nullptr;
+    double *dyp = fps_order ? A.alloc<double>(N) : nullptr;
+    char *dword = fps_order ? A.alloc<char>(word + 256) : nullptr;
     if (!A.ok) return GPBO_ERR_WORKSPACE;
     void *st = reinterpret_cast<void *>(A.stream);
 
     if (!A.h2d(dX, X, sizeof(double) * N * d) || !A.h2d(dy, y, sizeof(double) * N) ||
         !A.h2d(dXs, Xs, sizeof(double) * M * d))
         return GPBO_ERR_LAUNCH;
-    int rc = gpbo_factorise_f64(dX, dy, N, d, ls, jitter1, jitter2, Np, dK, dU, dalpha, dinfo, dwork, wfact, st);
+    int rc;
+    if (fps_order) {
+        char *wo = reinterpret_cast<char *>(((uintptr_t)dword + 255) & ~(uintptr_t)255);
+        rc = gpbo_fps_order_f64(dX, dy, N, d, ls, J1, dperm, dXp, dyp, wo, word, st);
+        if (rc != GPBO_OK) return rc;
+        dX = dXp;   // every later pass reads the observations in the factorisation's order
+        dy = dyp;
+    }
+    rc = gpbo_factorise_f64(dX, dy, N, d, ls, jitter1, jitter2, Np, dK, dU, dalpha, dinfo, dwork, wfact, st);
     if (rc != GPBO_OK) return rc;
     if (!A.d2h(info, dinfo, sizeof(int32_t)) || !A.sync()) return GPBO_ERR_LAUNCH;
     if (cov_meas_out) {  // the reference's cov_meas attribute (point_selector.py:79), N x N without the padding
@@ -121,6 +130,11 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
             return GPBO_ERR_LAUNCH;
     }
     if (*info != 0) {  // not positive definite: nothing to score (the reference's inv() raises or returns garbage)
+        if (fps_order && *info >= 1 && *info <= N) {   // report the failing observation by its ARRIVAL index, as documented
+            int64_t row = 0;
+            if (!A.d2h(&row, dperm + (*info - 1), sizeof(int64_t)) || !A.sync()) return GPBO_ERR_LAUNCH;
+            *info = (int32_t)(row + 1);
+        }
         result->best_val = 0.0;
         result->best_idx = -1;
         result->nan_count = 0;
@@ -130,32 +144,15 @@ extern "C" int gpbo_select_next_host_f64(const double *X, const double *y, int64
     const double prior_var = (1.0 + jitter1) + jitter2;  // diagonal of cov_pred as the reference rounds it
     bool decided = false;
     if (bound_route) {
-        bool sub_ok = false;
-        if (with_subset) {
-            char *ws = reinterpret_cast<char *>(((uintptr_t)dwsub + 255) & ~(uintptr_t)255);
-            rc = gpbo_bound_subset_f64(dX, N, d, ls, jitter1, jitter2, J1, J2, dperm, dXsub, dUsub, dinfo_sub, ws, wsub, st);
-            if (rc != GPBO_OK) return rc;
-            int32_t isub = 0;
-            if (!A.d2h(&isub, dinfo_sub, sizeof(int32_t)) || !A.sync()) return GPBO_ERR_LAUNCH;
-            sub_ok = isub == 0;   // (K_SS not positive definite at this jitter: the literal prefix instead)
-        }
-        if (sub_ok)
-            rc = gpbo_posterior_prefix_subset_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, chunk, J1,
-                                                  dXsub, Ns, Ns, dUsub, nullptr, nullptr, dub, dres, dwork, wpost, nullptr, st);
-        else
-            rc = gpbo_posterior_prefix_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, chunk, J1,
-                                           nullptr, nullptr, dub, dres, dwork, wpost, nullptr, st);
+        rc = gpbo_posterior_prefix_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, chunk, J1,
+                                       nullptr, nullptr, dub, dres, dwork, wpost, nullptr, st);
         if (rc != GPBO_OK) return rc;
         gpbo_screen_stats stats;
         char *wr = reinterpret_cast<char *>(((uintptr_t)dresc + 255) & ~(uintptr_t)255);
         int64_t stride = M / 1024;
         if (stride < 1) stride = 1;
-        if (sub_ok)
-            rc = gpbo_bound_select_subset_f64(dXs, M, dub, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, stride,
-                                              bcap, bchunk, J2, dXsub, Ns, Ns, dUsub, dres, &stats, wr, wresc, st);
-        else
-            rc = gpbo_bound_select_f64(dXs, M, dub, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, stride, bcap,
-                                       bchunk, J2, dres, &stats, wr, wresc, st);
+        rc = gpbo_bound_select_f64(dXs, M, dub, dX, N, Np, d, ls, dU, dalpha, prior_var, acq_kind, p0, p1, 0, stride, bcap,
+                                   bchunk, J2, dres, &stats, wr, wresc, st);
         if (rc != GPBO_OK) return rc;
         decided = !stats.fallback;
     }

@@ -384,9 +384,8 @@ static int bound_select_impl(const double *Xs, int64_t M, const double *ub, cons
                              double prior_var, int32_t acq_kind, double p0, double p1, int64_t idx_offset,
                              int64_t sample_stride, int64_t cap, int64_t chunk64, int64_t n_prefix2,
                              gpbo_result *result, gpbo_screen_stats *stats_host, void *work, int64_t work_bytes,
-                             void *stream, const GpboSubset *sub /* second-level bounds on the first n_prefix2 members */) {
+                             void *stream) {
     if (!Xs || !ub || !X || !U || !alpha || !result || !stats_host || !work) return GPBO_ERR_ARG;
-    if (sub && n_prefix2 > sub->Np) return GPBO_ERR_ARG;
     if (n_prefix2 < 0 || n_prefix2 > Np || n_prefix2 % 128) return GPBO_ERR_ARG;
     if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || d < 1 || d > GPBO_MAX_D || cap < 1 || sample_stride < 1) return GPBO_ERR_ARG;
     if (acq_kind != GPBO_ACQ_LCB && acq_kind != GPBO_ACQ_EI) return GPBO_ERR_ARG;
@@ -510,7 +509,7 @@ static int bound_select_impl(const double *Xs, int64_t M, const double *ub, cons
                 double *ub2 = sig64;   // (acq64 / mu64 are overwritten by the fp64 launch below; sig64 is too, AFTER ub2's last use)
                 rc = gpbo_posterior_acq_f64_split(rows, K1, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1, 0.0, 0,
                                                   chunk, nullptr, nullptr, ub2, &out->res, post, L.post_bytes, nullptr,
-                                                  GPBO_RESCORE_SPLIT_MAX, n_prefix2, stream, sub);
+                                                  GPBO_RESCORE_SPLIT_MAX, n_prefix2, stream);
                 if (rc != GPBO_OK) return rc;
                 int64_t *list2 = reinterpret_cast<int64_t *>(mu64);
                 int64_t rblk = (K1 + SB - 1) / SB;
@@ -603,7 +602,7 @@ static int bound_select_impl(const double *Xs, int64_t M, const double *ub, cons
                 if (chunk > kpad) chunk = kpad;
                 rc = gpbo_posterior_acq_f64_split(rows, (int64_t)K, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1,
                                                   0.0, 0, chunk, nullptr, nullptr, acq64, &out->res, post, L.post_bytes, nullptr,
-                                                  GPBO_RESCORE_SPLIT_MAX, n_prefix2, stream, sub);
+                                                  GPBO_RESCORE_SPLIT_MAX, n_prefix2, stream);
                 if (rc != GPBO_OK) return rc;
                 int64_t *list2 = reinterpret_cast<int64_t *>(mu64);   // (cap x 8 bytes, not used by the call above)
                 if (hipMemsetAsync(count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
@@ -649,19 +648,5 @@ extern "C" int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *
                                      gpbo_result *result, gpbo_screen_stats *stats_host, void *work, int64_t work_bytes,
                                      void *stream) {
     return bound_select_impl(Xs, M, ub, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1, idx_offset, sample_stride,
-                             cap, chunk64, n_prefix2, result, stats_host, work, work_bytes, stream, nullptr);
-}
-
-// ... with the second-level bounds on an observation subset (subset.hip), as gpbo_posterior_prefix_subset_f64
-extern "C" int gpbo_bound_select_subset_f64(const double *Xs, int64_t M, const double *ub, const double *X, int64_t N,
-                                            int64_t Np, int32_t d, const double *ls_host, const double *U,
-                                            const double *alpha, double prior_var, int32_t acq_kind, double p0, double p1,
-                                            int64_t idx_offset, int64_t sample_stride, int64_t cap, int64_t chunk64,
-                                            int64_t n_prefix2, const double *Xsub, int64_t Nsub, int64_t Npsub,
-                                            const double *Usub, gpbo_result *result, gpbo_screen_stats *stats_host,
-                                            void *work, int64_t work_bytes, void *stream) {
-    if (!Xsub || !Usub) return GPBO_ERR_ARG;
-    const GpboSubset sub = {Xsub, Nsub, Npsub, Usub};
-    return bound_select_impl(Xs, M, ub, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1, idx_offset, sample_stride,
-                             cap, chunk64, n_prefix2, result, stats_host, work, work_bytes, stream, n_prefix2 > 0 ? &sub : nullptr);
+                             cap, chunk64, n_prefix2, result, stats_host, work, work_bytes, stream);
 }

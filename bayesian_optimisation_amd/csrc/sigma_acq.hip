@@ -740,23 +740,6 @@ extern "C" int gpbo_posterior_prefix_f64(const double *Xs, int64_t M, const doub
                                         prof, 1, n_prefix, stream);
 }
 
-// The same first pass with the variance side on an observation SUBSET (subset.hip): the first n_prefix members of Xsub,
-// Usub = chol(K_SS)^-T [Npsub x Npsub].  Any subset gives a valid bound; the mean is still the mean of all N observations.
-extern "C" int gpbo_posterior_prefix_subset_f64(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
-                                                const double *ls_host, const double *U, const double *alpha, double prior_var,
-                                                int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk,
-                                                int64_t n_prefix, const double *Xsub, int64_t Nsub, int64_t Npsub,
-                                                const double *Usub, double *mu_out, double *sigma_ub_out, double *acq_ub_out,
-                                                gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof,
-                                                void *stream) {
-    if (n_prefix < BN || n_prefix % BN || n_prefix > Np || !Xsub || !Usub) return GPBO_ERR_ARG;
-    if (acq_kind == GPBO_ACQ_LCB && !(p0 >= 0.0)) return GPBO_ERR_ARG;
-    const GpboSubset sub = {Xsub, Nsub, Npsub, Usub};
-    return gpbo_posterior_acq_f64_split(Xs, M, X, N, Np, d, ls_host, U, alpha, prior_var, acq_kind, p0, p1, 0.0,
-                                        idx_offset, chunk, mu_out, sigma_ub_out, acq_ub_out, result, work, work_bytes,
-                                        prof, 1, n_prefix, stream, &sub);
-}
-
 int64_t gpbo_posterior_workspace_bytes_split(int64_t Np, int64_t chunk, int64_t M, int split_max) {
     if (Np < GPBO_NPAD || Np % GPBO_NPAD || chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX || M < 1)
         return GPBO_ERR_ARG;
@@ -772,12 +755,8 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                                  int32_t acq_kind, double p0, double p1, double diag_add, int64_t idx_offset,
                                  int64_t chunk, double *mu_out, double *sigma_out, double *acq_out, gpbo_result *result,
                                  void *work, int64_t work_bytes, gpbo_profile *prof, int split_max,
-                                 int64_t n_prefix /* 0: everything; else see gpbo_posterior_prefix_f64 */, void *stream,
-                                 const GpboSubset *sub /* prefix passes: the first n_prefix MEMBERS of this subset */) {
+                                 int64_t n_prefix /* 0: everything; else see gpbo_posterior_prefix_f64 */, void *stream) {
     if (!Xs || !X || !U || !alpha || !result || !work) return GPBO_ERR_ARG;
-    if (sub && (!sub->X || !sub->U || sub->N < 1 || sub->Np < sub->N || sub->Np % BN || sub->Np > Np || n_prefix < 1 ||
-                n_prefix > sub->Np))
-        return GPBO_ERR_ARG;
     if (n_prefix < 0 || n_prefix > Np || n_prefix % BN || (n_prefix && diag_add != 0.0)) return GPBO_ERR_ARG;
     if (M < 1 || N < 1 || Np != gpbo_padded_n(N) || Np > (1 << 20)) return GPBO_ERR_ARG;
     if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
@@ -800,18 +779,13 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
     static const bool overlap_env = getenv("GPBO_OVERLAP") && atoi(getenv("GPBO_OVERLAP"));
     // (and only while the unused rows of the K*^T slab can take that launch's mean partials)
     const bool kstar_mfma = n_prefix > 0 && !prefix_valu && !overlap_env && n_prefix + n_prefix / GPBO_KS_SLICE <= Np;
-    // a subset is honoured where the mean and the stored rows come from different launches (else: arrival order, full U)
-    const bool use_sub = sub && kstar_mfma;
-    const double *Uv = use_sub ? sub->U : U;
-    const int64_t Npv = use_sub ? sub->Np : Np, Nv = use_sub ? sub->N : N;
     const bool anyd = d > GPBO_MAX_D;   // slow path of the fp64 route: no unrolled registers, no pre-scaled copy
     if (anyd && (n_prefix > 0 || d > GPBO_MAX_D_ANY)) return GPBO_ERR_ARG;
     if (anyd) {
         if (hipMemsetAsync(nan_count, 0, sizeof(unsigned long long), st) != hipSuccess) return GPBO_ERR_LAUNCH;
     } else {
-        // observations / (ls sqrt 2), once per call; the same launch clears the NaN counter.  With a subset the scaled
-        // points serve the stored rows only (the mean's launch has its own operands), so they are the subset's.
-        int rc0 = gpbo_scale_points_launch(use_sub ? sub->X : X, Nv, Npv, d, ls_host, Xsc, nan_count, stream);
+        // observations / (ls sqrt 2), once per call; the same launch clears the NaN counter
+        int rc0 = gpbo_scale_points_launch(X, N, Np, d, ls_host, Xsc, nan_count, stream);
         if (rc0 != GPBO_OK) return rc0;
     }
     void *prep_buf = w + L.prep_off;
@@ -869,7 +843,7 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
             // holds for any inputs.  Costs n_prefix / N of the fp64-VALU kernel: 6 % at N / 16.
             rc = gpbo_kstar_mu_mfma(Xs + s * d, Mc, N, Np, d, ls_host, alpha, prep_buf, KsT[b], chunk, mu_part[b], 0, ks);
             if (rc != GPBO_OK) return rc;
-            const int64_t nrow = (Nv < n_prefix) ? Nv : n_prefix;
+            const int64_t nrow = (N < n_prefix) ? N : n_prefix;
             // (its mean partials - of the first n_prefix observations only - are not wanted: they go to rows of the K*^T
             //  slab that the prefix mode neither writes nor reads, [n_prefix, n_prefix + n_prefix / 64))
             rc = gpbo_kstar_mu_rows(Xs + s * d, Mc, Xsc, nrow, n_prefix, d, ls_host, alpha, 0.0, idx_offset + s, KsT[b], chunk,
@@ -903,7 +877,7 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
         const bool rec = prof && prof->count < prof->capacity;
         if (rec && hipEventRecord(reinterpret_cast<hipEvent_t>(prof->begin[prof->count]), st) != hipSuccess)
             return GPBO_ERR_LAUNCH;
-        const int S = split_factor(nblk, (n_prefix ? n_prefix : Np) / BN, split_max);  // (Uv == U, Npv == Np when n_prefix == 0)
+        const int S = split_factor(nblk, (n_prefix ? n_prefix : Np) / BN, split_max);
         // Column groups on one XCD for large calls (see the kernel): measured on MI355X at N = 4096, 2^21 candidates,
         // same box: 543 -> 509 ms per step with 8 groups (16: 512), the variance launches 32.9 -> 30.7 ms.  The rule depends
         // on the problem (N, candidates of the CALL), never on the chunking, so results stay chunk-size invariant bit for
@@ -921,8 +895,8 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                                acq_out ? acq_out + s : nullptr, (double *)nullptr, part_val + nparts, part_idx + nparts,
                                nan_count, n_prefix ? GPBO_BOUND_VAR_PAD : 0.0);
         } else if (S > 1) {
-            hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk, (unsigned)S), dim3(NW * 64), 0, st, KsT[b], chunk, Uv,
-                               (int)Npv, mu_part[b], nsl, Mc, prior_var, (int)acq_kind, p0, p1,
+            hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk, (unsigned)S), dim3(NW * 64), 0, st, KsT[b], chunk, U,
+                               (int)Np, mu_part[b], nsl, Mc, prior_var, (int)acq_kind, p0, p1,
                                idx_offset + s, (double *)nullptr, (double *)nullptr, (double *)nullptr, part_val + nparts,
                                part_idx + nparts, nan_count, (double *)nullptr, ss_part, 1, (int)nblk, (int)(n_prefix / BN));
             hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, ss_part, S, chunk, mu_part[b],
@@ -932,7 +906,7 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                                nan_count, n_prefix ? GPBO_BOUND_VAR_PAD : 0.0);
         } else {
 #define GPBO_SIGMA_LAUNCH(V)                                                                                        \
-    hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT[b], chunk, Uv, (int)Npv,        \
+    hipLaunchKernelGGL(sigma_acq_kernel<V>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT[b], chunk, U, (int)Np,          \
                        mu_part[b], nsl, Mc, prior_var, (int)acq_kind, p0, p1, idx_offset + s,               \
                        mu_out ? mu_out + s : nullptr, sigma_out ? sigma_out + s : nullptr,                              \
                        acq_out ? acq_out + s : nullptr, part_val + nparts, part_idx + nparts, nan_count,                     \

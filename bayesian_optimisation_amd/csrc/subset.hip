@@ -1,16 +1,17 @@
-// Order-independent observation subset for the exact prefix bound.
+// Order-independent pruning for the exact prefix bound: a farthest-point ORDER of the observations
+// (VERDICT round 3 item 1).
 //
-// The bound of sigma_acq.hip / rescore.hip uses the variance reduction from a SUBSET of the observations:
-//     sigma_c^2 = c - k_c^T K^-1 k_c  <=  c - k_S^T K_SS^-1 k_S          for every subset S
-// (conditioning on fewer observations cannot lower the posterior variance of /root/reference/point_selector.py:91).  Round 2
-// took S = the first J observations in ARRIVAL order - a Sobol stream covers the domain with any prefix, a sorted or
-// clustered history does not, and the bound then separates nothing.  Here S is chosen by farthest-point sampling in
-// length-scale units (each new member is the observation farthest from the members so far; the first one is the
-// observation farthest from the centroid; ties to the lowest index): it depends on the SET of observations, not on their
-// order, and spreads over whatever region they occupy.  The subset's own factor U_S = chol(K_SS)^-T comes from the same
-// factorisation kernels (cholinv.hip) on the gathered rows; for the second-level bound the subset is extended - by the
-// first not-yet-chosen observations in index order - to J2 members, the first J of which are the first-level set
-// (leading blocks of a Cholesky factor and of its inverse are the factor and inverse of the leading block).
+// The bound of sigma_acq.hip / rescore.hip uses the variance reduction from the FIRST J observations of the factorised
+// problem:  sigma_c^2 = c - |v_c|^2 <= c - |v_c[:J]|^2, v_c = U^T k_c (U triangular: component j depends on observations
+// 1..j only; /root/reference/point_selector.py:91).  Which observations come first decides how much the bound prunes: a
+// Sobol stream covers the domain with any prefix, a sorted or clustered history does not.  This file computes a permutation
+// of the observations - J members by farthest-point sampling in length-scale units (each new member is the observation
+// farthest from the members so far; the first one is the observation farthest from the centroid; ties to the lowest
+// index), then all the others in index order - and gathers X and y in that order.  The caller factorises the PERMUTED
+// problem (the posterior of a GP does not depend on the order of its observations) and every pass - the plain one and the
+// bound's two levels - then works on that one factorisation: the bound's |v[:J]|^2 is a partial sum of the very squares
+// the plain pass adds up, for any history.  (Round 3 kept the arrival order and gave the bound a factorisation of its
+// own, chol(K_SS): the same members, but two different sets of rounding errors to compare.)
 #include "gpbo_internal.h"
 
 #include <limits>
@@ -304,42 +305,42 @@ __global__ void gather_obs_kernel(const double *__restrict__ X, int d, const int
     out[e] = X[perm[e / d] * d + (e % d)];
 }
 
-struct SubsetLayout {
-    int64_t mind_off, fps_off, k_off, y_off, alpha_off, fact_off, fact_bytes, total;
+struct OrderLayout {
+    int64_t mind_off, fps_off, total;
 };
 constexpr int FPS_MAXG = 256;  // workgroups of a selection step at most
 
-SubsetLayout subset_layout(int64_t N, int64_t Ns) {
-    SubsetLayout L;
+OrderLayout order_layout(int64_t N) {
+    OrderLayout L;
     int64_t off = 0;
     auto take = [&](int64_t bytes) { const int64_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     L.mind_off = take((int64_t)sizeof(double) * N);
     L.fps_off = take((int64_t)sizeof(FpsState) + (int64_t)FPS_MAXG * (sizeof(double) + sizeof(int64_t)) + 256);
-    L.k_off = take((int64_t)sizeof(double) * Ns * Ns);
-    L.y_off = take((int64_t)sizeof(double) * Ns);
-    L.alpha_off = take((int64_t)sizeof(double) * Ns);
-    L.fact_bytes = gpbo_factorise_workspace_bytes(Ns);
-    L.fact_off = take(L.fact_bytes);
     L.total = off;
     return L;
 }
 
-}  // namespace
-
-extern "C" int64_t gpbo_bound_subset_workspace_bytes(int64_t N, int64_t Ns) {
-    if (N < 1 || Ns < 128 || Ns % 128 || Ns > N) return GPBO_ERR_ARG;
-    return subset_layout(N, Ns).total;
+__global__ void gather_y_kernel(const double *__restrict__ y, const int64_t *__restrict__ perm, int64_t n, double *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = y[perm[e]];
 }
 
-// perm_out [Ns] int64, Xsub_out [Ns x d], Usub_out [Ns x Ns] (all device).  Ns = max(J, J2) members, a multiple of 128, <= N.
-extern "C" int gpbo_bound_subset_f64(const double *X, int64_t N, int32_t d, const double *ls_host, double jitter1,
-                                     double jitter2, int64_t J, int64_t J2, int64_t *perm_out, double *Xsub_out,
-                                     double *Usub_out, int32_t *info, void *work, int64_t work_bytes, void *stream) {
-    if (!X || !ls_host || !perm_out || !Xsub_out || !Usub_out || !info || !work) return GPBO_ERR_ARG;
-    const int64_t Ns = (J2 > J) ? J2 : J;
-    if (N < 1 || d < 1 || d > GPBO_MAX_D || J < 128 || J % 128 || (J2 != 0 && (J2 < J || J2 % 128)) || Ns > N) return GPBO_ERR_ARG;
+}  // namespace
+
+extern "C" int64_t gpbo_fps_order_workspace_bytes(int64_t N) {
+    if (N < 1) return GPBO_ERR_ARG;
+    return order_layout(N).total;
+}
+
+// perm_out [N] int64: perm[0 .. J) = the farthest-point sequence, perm[J .. N) = every other observation in index order.
+// Xp_out [N x d] / yp_out [N] (optional; y may be NULL when yp_out is): rows perm[i] of X / y.  All device memory.
+extern "C" int gpbo_fps_order_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_host, int64_t J,
+                                  int64_t *perm_out, double *Xp_out, double *yp_out, void *work, int64_t work_bytes,
+                                  void *stream) {
+    if (!X || !ls_host || !perm_out || !work || (yp_out && !y)) return GPBO_ERR_ARG;
+    if (N < 1 || d < 1 || d > GPBO_MAX_D || J < 1 || J > N) return GPBO_ERR_ARG;
     if ((uintptr_t)work & 255) return GPBO_ERR_ARG;
-    const SubsetLayout L = subset_layout(N, Ns);
+    const OrderLayout L = order_layout(N);
     if (work_bytes < L.total) return GPBO_ERR_WORKSPACE;
     FpsLs ls;
     for (int k = 0; k < GPBO_MAX_D; ++k) ls.isc[k] = 0.0;
@@ -350,13 +351,10 @@ extern "C" int gpbo_bound_subset_f64(const double *X, int64_t N, int32_t d, cons
     hipStream_t st = gpbo_stream(stream);
     char *w = reinterpret_cast<char *>(work);
     double *mind = reinterpret_cast<double *>(w + L.mind_off);
-    double *Ksub = reinterpret_cast<double *>(w + L.k_off);
-    double *ysub = reinterpret_cast<double *>(w + L.y_off);
-    double *asub = reinterpret_cast<double *>(w + L.alpha_off);
     // one workgroup with every thread's observations in registers while that is the faster form (measured at N = 8192 /
     // 6000: 8 points per thread at d = 4 - 116 bytes of spills - 3.1 ms against 4.3 by launches; at d = 8 - 404 bytes -
     // 6.9 against 4.4; at d = 6 2.5 against 2.2); beyond: one launch per member (fps_step_kernel)
-#define GPBO_FPS(P, DD) hipLaunchKernelGGL((fps_kernel<P, DD>), dim3(1), dim3(FT), 0, st, X, N, (int)d, ls, J, Ns, mind, perm_out)
+#define GPBO_FPS(P, DD) hipLaunchKernelGGL((fps_kernel<P, DD>), dim3(1), dim3(FT), 0, st, X, N, (int)d, ls, J, N, mind, perm_out)
     const int64_t pts = (N + FT - 1) / FT;
     bool launched = false;
 #define GPBO_FPS_D(DD)                                                                   \
@@ -378,15 +376,15 @@ extern "C" int gpbo_bound_subset_f64(const double *X, int64_t N, int32_t d, cons
         hipLaunchKernelGGL(fps_centroid_kernel, dim3(1), dim3(FT), 0, st, X, N, (int)d, ls, stt);
         for (int64_t j = 0; j <= J; ++j)   // launch j: folds member j - 1 in and picks member j (the last one only folds)
             hipLaunchKernelGGL(fps_step_kernel, dim3((unsigned)G), dim3(FG), 0, st, X, N, (int)d, ls, mind, stt, pval, pidx, perm_out, j, J);
-        hipLaunchKernelGGL(fps_extend_kernel, dim3(1), dim3(FT), 0, st, N, J, Ns, mind, perm_out);
+        hipLaunchKernelGGL(fps_extend_kernel, dim3(1), dim3(FT), 0, st, N, J, N, mind, perm_out);
     }
 #undef GPBO_FPS_D
 #undef GPBO_FPS
-    const int64_t tot = Ns * d;
-    hipLaunchKernelGGL(gather_obs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, (int)d, perm_out, Ns, Xsub_out);
+    if (Xp_out) {
+        const int64_t tot = N * d;
+        hipLaunchKernelGGL(gather_obs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, (int)d, perm_out, N, Xp_out);
+    }
+    if (yp_out) hipLaunchKernelGGL(gather_y_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, y, perm_out, N, yp_out);
     GPBO_CHECK_LAUNCH();
-    if (hipMemsetAsync(ysub, 0, sizeof(double) * Ns, st) != hipSuccess) return GPBO_ERR_LAUNCH;
-    // the subset's own factor: K_SS + jitter as the full problem's, Ns is its own padded size (every row is a member)
-    return gpbo_factorise_f64(Xsub_out, ysub, Ns, d, ls_host, jitter1, jitter2, Ns, Ksub, Usub_out, asub, info, w + L.fact_off,
-                              L.fact_bytes, stream);
+    return GPBO_OK;
 }

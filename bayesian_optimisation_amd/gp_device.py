@@ -64,6 +64,7 @@ class DeviceGP:
         self._work_post = None
         self._work_fact = None
         self.K = self.U = self.alpha = None
+        self.perm = None             # factorise(order="fps"): device int64 [N], row of the factorisation -> the caller's row
         # the 32-byte result record and the factorisation's info word share one small buffer, so that a step can read
         # both back with a single device-to-host copy (each copy is a host synchronisation)
         self._status = torch.zeros(5, dtype=torch.int64, device=self.device)
@@ -112,9 +113,18 @@ class DeviceGP:
 
     # -- factorisation (once per BO step) ---------------------------------------------------------
     def factorise(self, X, y, ls, jitter1: float = JITTER_KERNEL, jitter2: float = JITTER_ASSEMBLY,
-                  check: bool = True):
-        """K = k(X,X) + jitter; K = L L^T; U = L^-T; alpha = K^-1 y   (point_selector.py:79, 89-90)."""
+                  check: bool = True, order: str = "arrival"):
+        """K = k(X,X) + jitter; K = L L^T; U = L^-T; alpha = K^-1 y   (point_selector.py:79, 89-90).
+        order="fps": the observations are factorised in their farthest-point order (gpbo_fps_order_f64: `bound_prefix()`
+        members spread over the region the observations occupy, then the others in arrival order) instead of the order in
+        which they arrived.  A GP's posterior does not depend on the order of its observations - every scoring call returns
+        the same numbers within rounding - but score_bound() prunes by the FIRST observations of the factorisation, and a
+        history sorted along an axis or begun inside one cluster is a poor prefix.  `perm` (device int64 [N]) maps a
+        row of the factorisation to the caller's row; K / U / alpha / X / y of this object are in factorisation order
+        (cov_meas_host() and observations_host() give the caller's order back)."""
         torch = self.torch
+        if order not in ("arrival", "fps"):
+            raise ValueError("order must be 'arrival' or 'fps'")
         Xd = self._dev(X)
         if Xd.dim() != 2:
             raise ValueError("X must be (N, d)")
@@ -129,6 +139,20 @@ class DeviceGP:
             raise ValueError(f"length scales: expected {d} values, got {ls_h.size}")
         Np = int(self.lib.gpbo_padded_n(N))
         with torch.cuda.device(self.device):
+            self.perm = None
+            J = self.bound_prefix(Np)
+            if order == "fps" and d <= _lib.MAX_D and J < N:
+                # (fewer observations than one prefix, or the slow any-d kernels: the bound route is not taken anyway)
+                wob = int(self.lib.gpbo_fps_order_workspace_bytes(N))
+                if getattr(self, "_work_order", None) is None or self._work_order.numel() * 8 < wob:
+                    self._work_order = torch.empty((wob + 7) // 8, dtype=torch.float64, device=self.device)
+                perm = torch.empty(N, dtype=torch.int64, device=self.device)
+                Xp, yp = torch.empty_like(Xd), torch.empty_like(yd)
+                st = self.lib.gpbo_fps_order_f64(self._ptr(Xd), self._ptr(yd), N, d, ls_h.ctypes.data_as(C.c_void_p), J,
+                                                 self._ptr(perm), self._ptr(Xp), self._ptr(yp), self._ptr(self._work_order),
+                                                 wob, self._stream())
+                _lib.check(st, "gpbo_fps_order_f64")
+                Xd, yd, self.perm = Xp, yp, perm
             self.X, self.y, self.ls_h = Xd, yd, ls_h
             self.N, self.Np, self.d = N, Np, d
             self.jitter1, self.jitter2 = float(jitter1), float(jitter2)
@@ -143,7 +167,6 @@ class DeviceGP:
                 self._work_fact = None
             self._u32_valid = False
             self._u8_valid = False
-            self._bound_subset = None  # the prefix bound's observation subset belongs to one factorisation
             wbytes = int(self.lib.gpbo_factorise_workspace_bytes(Np))
             if self._work_fact is None or self._work_fact.numel() * 8 < wbytes:
                 self._work_fact = torch.empty(wbytes // 8, dtype=torch.float64, device=self.device)
@@ -160,6 +183,33 @@ class DeviceGP:
                         f"covariance matrix is not positive definite (pivot {info} of {N}); "
                         "the reference's np.linalg.inv would raise or return garbage here")
         return self
+
+    BOUND_PREFIX_FRACTION = 16  # first pass over the first Np / 16 observations' columns (1/256 of the variance product);
+                                # survivors get a second bound from four times as many before the fp64 kernels see them
+
+    BOUND_MIN_JITTER = 1e-6     # score_bound(): smallest jitter1 + jitter2 the route is taken for (see score_async_bound)
+
+    def bound_prefix(self, Np: Optional[int] = None) -> int:
+        """First-level prefix length of score_bound() at this padded size (= the farthest-point members of order="fps")."""
+        Np = self.Np if Np is None else int(Np)
+        return max(128, (Np // self.BOUND_PREFIX_FRACTION) // 128 * 128)
+
+    @property
+    def order(self) -> str:
+        return "arrival" if self.perm is None else "fps"
+
+    def _perm_host(self):
+        return None if self.perm is None else self.perm[: self.N].cpu().numpy()
+
+    def observations_host(self):
+        """(X [N x d], y [N]) in the CALLER's order (rows appended since the factorisation come last in both orders)."""
+        Xf, yf = self.X[: self.N].cpu().numpy(), self.y[: self.N].cpu().numpy()
+        p = self._perm_host()
+        if p is None:
+            return Xf, yf
+        Xa, ya = np.empty_like(Xf), np.empty_like(yf)
+        Xa[p], ya[p] = Xf, yf
+        return Xa, ya
 
     def _need_unrolled_d(self, what: str):
         """d > 16 runs on the slow any-d kernels, which serve factorise() and score() only (point_selector.py:22: the
@@ -229,9 +279,10 @@ class DeviceGP:
                         "call factorise() on the full data instead")
             else:
                 torch.cuda.current_stream(self.device).synchronize()  # xn / yn / work must outlive the kernels
+            if self.perm is not None:   # the new row is last in both orders
+                self.perm = torch.cat([self.perm[:N], torch.tensor([N], dtype=torch.int64, device=self.device)])
             self.N = N + 1
             self.n_appended += 1
-            self._bound_subset = None
             del work
         return self
 
@@ -239,10 +290,13 @@ class DeviceGP:
     def state_dict(self) -> dict:
         """Host copy of everything append()/score() need (the N x N part of the factors, not the padding)."""
         N = self.N
-        return dict(version=1, N=N, d=self.d, ls=np.array(self.ls_h), jitter1=self.jitter1, jitter2=self.jitter2,
-                    n_appended=self.n_appended,
-                    X=self.X[:N].cpu().numpy(), y=self.y[:N].cpu().numpy(), K=self.K[:N, :N].cpu().numpy(),
-                    U=self.U[:N, :N].cpu().numpy(), alpha=self.alpha[:N].cpu().numpy())
+        st = dict(version=1, N=N, d=self.d, ls=np.array(self.ls_h), jitter1=self.jitter1, jitter2=self.jitter2,
+                  n_appended=self.n_appended,
+                  X=self.X[:N].cpu().numpy(), y=self.y[:N].cpu().numpy(), K=self.K[:N, :N].cpu().numpy(),
+                  U=self.U[:N, :N].cpu().numpy(), alpha=self.alpha[:N].cpu().numpy())
+        if self.perm is not None:   # everything above is in factorisation order; perm[i] = the caller's row of row i
+            st["perm"] = self._perm_host()
+        return st
 
     def load_state_dict(self, st: dict):
         torch = self.torch
@@ -268,9 +322,14 @@ class DeviceGP:
             self.alpha = torch.zeros(Np, dtype=torch.float64, device=self.device)
             self.alpha[:N] = self._dev(st["alpha"]).reshape(-1)
             self.info.zero_()
+            self.perm = None
+            if "perm" in st and st["perm"] is not None:
+                p = np.ascontiguousarray(np.asarray(st["perm"], dtype=np.int64).reshape(-1))
+                if p.size != N or not np.array_equal(np.sort(p), np.arange(N)):
+                    raise ValueError("surrogate state: perm is not a permutation of the observations")
+                self.perm = torch.from_numpy(p).to(self.device)
             self._u32_valid = False
             self._u8_valid = False
-            self._bound_subset = None   # the prefix bound's subset (Xsub, chol(K_SS)^-T) belongs to the old observations
             self._work_post = None
         return self
 
@@ -331,6 +390,10 @@ class DeviceGP:
             kind, p0, p1 = _lib.ACQ_EI, float(f_best), float(xi)
         else:
             raise ValueError(f"unknown acquisition {acquisition!r}")
+        if diag_add != 0.0 and self.perm is not None:
+            # the N == M quirk (point_selector.py:173) adds to entry (i, i) of k(X, X*): candidate i against the caller's
+            # observation i, which is not row i of a permuted factorisation
+            raise ValueError("diag_add (the N == M shape quirk) needs factorise(order='arrival')")
         with torch.cuda.device(self.device):
             chunk, wbytes = self._ensure_post_workspace(M)
             mu = sigma = acq = None
@@ -516,44 +579,9 @@ class DeviceGP:
 
     # -- prefix-bound screen: exact branch and bound, all fp64 ---------------------------------------------------
     ARD_KEEP_WORKSPACE_BYTES = 1 << 28   # the batched ARD workspace is dropped after a call when larger than this
-    BOUND_PREFIX_FRACTION = 16  # first pass over the first Np / 16 observations' columns (1/256 of the variance product);
-                                # survivors get a second bound from four times as many before the fp64 kernels see them
-
-    def _ensure_bound_subset(self, J: int, J2: int):
-        """(Xsub, Usub, Ns): the observation subset of the prefix bound for this factorisation - J members by farthest-point
-        sampling in length-scale units, extended to J2 by index order (csrc/subset.hip), with its own factor
-        chol(K_SS)^-T.  Built once per factorisation and (J, J2); None when the subset would not fit (Ns > N)."""
-        torch = self.torch
-        Ns = max(J, J2)
-        if Ns > self.N:
-            return None
-        cur = getattr(self, "_bound_subset", None)
-        if cur is not None and cur[0] == (J, J2):
-            return cur[1]
-        with torch.cuda.device(self.device):
-            perm = torch.empty(Ns, dtype=torch.int64, device=self.device)
-            Xsub = torch.empty((Ns, self.d), dtype=torch.float64, device=self.device)
-            Usub = torch.empty((Ns, Ns), dtype=torch.float64, device=self.device)
-            info = torch.zeros(1, dtype=torch.int32, device=self.device)
-            wbytes = int(self.lib.gpbo_bound_subset_workspace_bytes(self.N, Ns))
-            if wbytes < 0:
-                raise _lib.GpboError("gpbo_bound_subset_workspace_bytes: invalid sizes")
-            if getattr(self, "_work_subset", None) is None or self._work_subset.numel() * 8 < wbytes:
-                self._work_subset = torch.empty((wbytes + 7) // 8, dtype=torch.float64, device=self.device)
-            st = self.lib.gpbo_bound_subset_f64(self._ptr(self.X), self.N, self.d, self.ls_h.ctypes.data_as(C.c_void_p),
-                                                self.jitter1, self.jitter2, J, J2, self._ptr(perm), self._ptr(Xsub),
-                                                self._ptr(Usub), self._ptr(info), self._ptr(self._work_subset), wbytes,
-                                                self._stream())
-            _lib.check(st, "gpbo_bound_subset_f64")
-            info_h = int(info.item())  # once per factorisation (synchronises): K_SS positive definite at these jitters?
-        sub = (Xsub, Usub, Ns, perm, info_h)
-        self._bound_subset = ((J, J2), sub)
-        return sub
-
     def score_async_bound(self, Xs, acquisition: str = "lcb", explore: float = 4.0, f_best: Optional[float] = None,
                           xi: float = 0.0, dense: bool = False, idx_offset: int = 0, diag_add: float = 0.0,
-                          prior_var: float = PRIOR_VAR, prefix: Optional[int] = None, prefix2: Optional[int] = None,
-                          subset: str = "fps"):
+                          prior_var: float = PRIOR_VAR, prefix: Optional[int] = None, prefix2: Optional[int] = None):
         """The selected point WITHOUT the variance of every candidate - exact, all fp64.  The squared norm of the first J
         components of v_c = U^T k_c is the variance reduction from the first J observations alone, so
         sqrt(prior_var - |v_c[:J]|^2) >= cov_func_c and (both acquisitions increase with sigma) an UPPER bound of the
@@ -562,8 +590,11 @@ class DeviceGP:
         (gpbo_posterior_prefix_f64 + gpbo_bound_select_f64).  The mean is still computed for every candidate.
         Falls back to score_async when the bound cannot be used (dense outputs wanted, LCB with a negative weight, the
         N == M diagonal quirk, fewer than 3 column blocks) or does not separate the candidates (flat mean, ties).
-        subset="fps" (default): "the first J observations" are J members chosen by farthest-point sampling, so the bound
-        does not depend on the order in which the observations arrived; subset="arrival": the literal prefix (round 2).
+        "The first J observations" are those of THIS object's factorisation: factorise(order="fps") puts J well-spread
+        members first, so that the pruning does not depend on the order in which the observations arrived; with the
+        default order the literal arrival prefix is used (exact as well; prunes little when the history is sorted or
+        clustered).  Bounds and exact values come from the same U, the same K(X*,X) kernel and the same variance
+        kernel: |v[:J]|^2 is a partial sum of the squares score() adds up.
         Synchronises; `last_screen` keeps the statistics."""
         torch = self.torch
         if self.d > _lib.MAX_D:   # the slow any-d kernels serve the plain pass only
@@ -581,7 +612,7 @@ class DeviceGP:
             kind, p0, p1 = _lib.ACQ_EI, float(f_best), float(xi)
         else:
             raise ValueError(f"unknown acquisition {acquisition!r}")
-        J = int(prefix) if prefix else max(128, (self.Np // self.BOUND_PREFIX_FRACTION) // 128 * 128)
+        J = int(prefix) if prefix else self.bound_prefix()
         J2 = int(prefix2) if prefix2 is not None else (4 * J if 8 * J <= self.Np else 0)   # second level: survivors only
         reason = None
         if dense:
@@ -592,6 +623,13 @@ class DeviceGP:
             reason = "negative explore weight"
         elif J % 128 or J < 128 or 2 * J > self.Np:
             reason = "too few column blocks"
+        elif not (self.jitter1 + self.jitter2 >= self.BOUND_MIN_JITTER
+                  and prior_var >= (1.0 + self.jitter1) + self.jitter2 - 1e-15):
+            # The plain pass takes sqrt(|var|) (point_selector.py:98): a NEGATIVE computed variance counts by its magnitude,
+            # which no prefix can bound.  With K = k(X,X) + tau I and prior_var >= 1 + tau the true variance is >= tau
+            # (a candidate on top of an observation: 2 tau - tau^2 (K^-1)_ii), so the computed one is negative only if its
+            # rounding error exceeds tau; the route is taken for tau >= 1e-6 (the reference: 1.01e-4, errors seen: 1e-9).
+            reason = "jitter too small for the |var| rule"
         if reason:
             self.last_screen = dict(mode="bound", fallback=True, reason=reason)
             return self.score_async(Xsd, acquisition, explore, f_best, xi, dense, idx_offset, diag_add, prior_var)
@@ -600,25 +638,12 @@ class DeviceGP:
             if getattr(self, "_bound_ub", None) is None or self._bound_ub.numel() < M:
                 self._bound_ub = torch.empty(M, dtype=torch.float64, device=self.device)
             lsp = self.ls_h.ctypes.data_as(C.c_void_p)
-            if subset not in ("fps", "arrival"):
-                raise ValueError("subset must be 'fps' or 'arrival'")
-            sub = self._ensure_bound_subset(J, J2) if subset == "fps" else None
-            if sub is not None and sub[4] != 0:
-                sub = None  # K_SS not positive definite at this jitter (duplicated members): the literal prefix instead
-            if sub is not None:
-                st = self.lib.gpbo_posterior_prefix_subset_f64(
-                    self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d, lsp, self._ptr(self.U),
-                    self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), chunk, J, self._ptr(sub[0]), sub[2],
-                    sub[2], self._ptr(sub[1]), None, None, self._ptr(self._bound_ub), self._ptr(self._result),
-                    self._ptr(self._work_post), wbytes, self._profile if self.profile_active else None, self._stream())
-                _lib.check(st, "gpbo_posterior_prefix_subset_f64")
-            else:
-                st = self.lib.gpbo_posterior_prefix_f64(
-                    self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d, lsp, self._ptr(self.U),
-                    self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), chunk, J, None, None,
-                    self._ptr(self._bound_ub), self._ptr(self._result), self._ptr(self._work_post), wbytes,
-                    self._profile if self.profile_active else None, self._stream())
-                _lib.check(st, "gpbo_posterior_prefix_f64")
+            st = self.lib.gpbo_posterior_prefix_f64(
+                self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d, lsp, self._ptr(self.U),
+                self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), chunk, J, None, None,
+                self._ptr(self._bound_ub), self._ptr(self._result), self._ptr(self._work_post), wbytes,
+                self._profile if self.profile_active else None, self._stream())
+            _lib.check(st, "gpbo_posterior_prefix_f64")
             # every first-level survivor may go on to the second-level bound (N/4 rows: 1/16 of a plain pass per candidate -
             # cheaper than falling back even if ALL of them survive); LCB(explore=10) on the headline workload leaves 256k
             # of 2^21: 24 ms through the second level against 518 ms through the plain pass (tools/bound_cap_probe.py)
@@ -631,23 +656,15 @@ class DeviceGP:
                 self._work_rescore = torch.empty((rbytes + 7) // 8, dtype=torch.float64, device=self.device)
             stats = _lib.ScreenStats()
             stride = max(1, M // self.SCREEN_SAMPLE)
-            if sub is not None:
-                st = self.lib.gpbo_bound_select_subset_f64(
-                    self._ptr(Xsd), M, self._ptr(self._bound_ub), self._ptr(self.X), self.N, self.Np, self.d, lsp,
-                    self._ptr(self.U), self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), stride, cap,
-                    chunk64, J2, self._ptr(sub[0]), sub[2], sub[2], self._ptr(sub[1]), self._ptr(self._result),
-                    C.byref(stats), self._ptr(self._work_rescore), rbytes, self._stream())
-                _lib.check(st, "gpbo_bound_select_subset_f64")
-            else:
-                st = self.lib.gpbo_bound_select_f64(
-                    self._ptr(Xsd), M, self._ptr(self._bound_ub), self._ptr(self.X), self.N, self.Np, self.d, lsp,
-                    self._ptr(self.U), self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), stride, cap,
-                    chunk64, J2, self._ptr(self._result), C.byref(stats), self._ptr(self._work_rescore), rbytes,
-                    self._stream())
-                _lib.check(st, "gpbo_bound_select_f64")
-            self.last_screen = dict(mode="bound", subset="fps" if sub is not None else "arrival", prefix=J, prefix2=J2, survivors=int(stats.survivors), rescored=int(stats.rescored),
-                                    rounds=int(stats.rounds), fallback=bool(stats.fallback), threshold=float(stats.tau),
-                                    candidates=M)
+            st = self.lib.gpbo_bound_select_f64(
+                self._ptr(Xsd), M, self._ptr(self._bound_ub), self._ptr(self.X), self.N, self.Np, self.d, lsp,
+                self._ptr(self.U), self._ptr(self.alpha), prior_var, kind, p0, p1, int(idx_offset), stride, cap,
+                chunk64, J2, self._ptr(self._result), C.byref(stats), self._ptr(self._work_rescore), rbytes,
+                self._stream())
+            _lib.check(st, "gpbo_bound_select_f64")
+            self.last_screen = dict(mode="bound", order=self.order, prefix=J, prefix2=J2, survivors=int(stats.survivors),
+                                    rescored=int(stats.rescored), rounds=int(stats.rounds), fallback=bool(stats.fallback),
+                                    threshold=float(stats.tau), candidates=M)
         self._keep = Xsd
         if stats.fallback:
             return self.score_async(Xsd, acquisition, explore, f_best, xi, False, idx_offset, 0.0, prior_var)
@@ -775,7 +792,14 @@ class DeviceGP:
 
     # -- dense covariance blocks for inspection (small problems only) --------------------------------------
     def cov_meas_host(self) -> np.ndarray:
-        return self.K[: self.N, : self.N].cpu().numpy()
+        """cov_meas (point_selector.py:79) in the caller's order of the observations."""
+        K = self.K[: self.N, : self.N].cpu().numpy()
+        p = self._perm_host()
+        if p is None:
+            return K
+        Ka = np.empty_like(K)
+        Ka[np.ix_(p, p)] = K
+        return Ka
 
     def kxx_host(self, P, ls, jitter1, jitter2) -> np.ndarray:
         """k(P,P) with the reference's jitter, as a host array (used for `cov_pred` on small grids)."""
@@ -808,4 +832,10 @@ class DeviceGP:
                                             self._ptr(self.alpha), float(diag_add), 0, self._ptr(kst), ldk,
                                             self._ptr(mup), self._stream())
             _lib.check(st, "gpbo_kstar_mu_f64")
-            return kst[: self.N, :M].t().contiguous().cpu().numpy()
+            Kf = kst[: self.N, :M].t().contiguous().cpu().numpy()
+        p = self._perm_host()
+        if p is None:
+            return Kf
+        Ka = np.empty_like(Kf)   # columns back in the caller's order of the observations
+        Ka[:, p] = Kf
+        return Ka

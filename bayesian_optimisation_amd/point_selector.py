@@ -243,7 +243,7 @@ class PointSelector:
             if self._inc is None and self._state_path is not None and os.path.exists(self._state_path):
                 try:
                     gp.load_state(self._state_path)
-                    self._inc = (gp.X[: gp.N].cpu().numpy(), gp.y[: gp.N].cpu().numpy(), np.array(gp.ls_h))
+                    self._inc = (*gp.observations_host(), np.array(gp.ls_h))   # in the caller's order
                 except Exception as exc:  # noqa: BLE001 - an unreadable state file only costs the shortcut
                     self._log(f"state file {self._state_path!r} ignored: {exc}")
                     self._inc = None
@@ -255,7 +255,9 @@ class PointSelector:
                               and gp.n_appended + (len(X) - n0) <= MAX_APPENDED_COLUMNS
                               and ls0.shape == ls.shape and np.array_equal(ls0, ls)
                               and gp.jitter1 == JITTER_KERNEL and gp.jitter2 == JITTER_ASSEMBLY
-                              and np.array_equal(X[:n0], X0) and np.array_equal(y[:n0], y0))
+                              and np.array_equal(X[:n0], X0) and np.array_equal(y[:n0], y0)
+                              # (a permuted factorisation cannot carry the N == M quirk, which is keyed on the arrival index)
+                              and (gp.perm is None or np.shape(self.predicted_pts) != np.shape(X)))
             # the route is a collective decision: a rank that appends while another refactorises would hold factors
             # that differ at rounding level, and the lowest-index tie rule across shards assumes identical factors
             if D.all_agree(can_append) if self._shard else can_append:
@@ -268,7 +270,11 @@ class PointSelector:
                 if self._shard:
                     appended = D.all_agree(appended)
         if not appended:
-            gp.factorise(X, y, ls, JITTER_KERNEL, JITTER_ASSEMBLY, check=True)
+            # next point only (dense_outputs=False): the acquisition calls prune by the first observations of the
+            # factorisation (DeviceGP.score_bound), so those are chosen to cover the region whatever the order of the
+            # history; not with the N == M quirk, which is keyed on the arrival index (:173)
+            fps = not self._dense and np.shape(self.predicted_pts) != np.shape(X)
+            gp.factorise(X, y, ls, JITTER_KERNEL, JITTER_ASSEMBLY, check=True, order="fps" if fps else "arrival")
         self.last_update = "append" if appended else "factorise"
         if self._incremental:
             self._inc = (X.copy(), y.copy(), ls.copy())

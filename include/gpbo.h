@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPBO_VERSION 130 /* 0.3.0: fused Cholesky + inverse factor (gpbo_cholinv_*), bound on an observation subset (gpbo_*_subset_f64), any d on the fp64 route */
+#define GPBO_VERSION 140 /* 0.4.0: the prefix bound on ONE factorisation of the farthest-point-ordered observations (gpbo_fps_order_f64 replaces gpbo_*_subset_f64) */
 
 #define GPBO_OK 0
 #define GPBO_ERR_ARG (-1)      /* null pointer, bad size/alignment, unsupported d */
@@ -245,31 +245,20 @@ int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *acq_ub, con
                           bounds of the survivors before they are re-scored */, gpbo_result *result,
                           gpbo_screen_stats *stats_host, void *work, int64_t work_bytes, void *stream);
 
-/* The same two calls with the variance side on an observation SUBSET chosen independently of the arrival order
- * (csrc/subset.hip): conditioning on any subset S of the observations bounds the posterior variance from above, so
- * |chol(K_SS)^-1 k_S|^2 over the first n_prefix members is as valid a bound as the arrival-order prefix, and it does not
- * degrade when the history is sorted or clustered.  gpbo_bound_subset_f64 picks the members by farthest-point sampling
- * in length-scale units (first member: the observation farthest from the centroid; ties to the lowest index; J members),
- * extends them to J2 members by the first unchosen observations in index order (J2 = 0: none), gathers them and
- * factorises K_SS with the full problem's jitters: perm_out [Ns] (device int64), Xsub_out [Ns x d], Usub_out [Ns x Ns],
- * Ns = max(J, J2) <= N, multiples of 128.  The mean, the exact re-scoring and therefore the selected point are the full
- * problem's in every case. */
-int64_t gpbo_bound_subset_workspace_bytes(int64_t N, int64_t Ns);
-int gpbo_bound_subset_f64(const double *X, int64_t N, int32_t d, const double *ls_host, double jitter1, double jitter2,
-                          int64_t J, int64_t J2, int64_t *perm_out, double *Xsub_out, double *Usub_out, int32_t *info,
-                          void *work, int64_t work_bytes, void *stream);
-int gpbo_posterior_prefix_subset_f64(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
-                                     const double *ls_host, const double *U, const double *alpha, double prior_var,
-                                     int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk,
-                                     int64_t n_prefix, const double *Xsub, int64_t Nsub, int64_t Npsub, const double *Usub,
-                                     double *mu_out, double *sigma_ub_out, double *acq_ub_out, gpbo_result *result,
-                                     void *work, int64_t work_bytes, gpbo_profile *prof /* or NULL */, void *stream);
-int gpbo_bound_select_subset_f64(const double *Xs, int64_t M, const double *acq_ub, const double *X, int64_t N, int64_t Np,
-                                 int32_t d, const double *ls_host, const double *U, const double *alpha, double prior_var,
-                                 int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t sample_stride,
-                                 int64_t cap, int64_t chunk64, int64_t n_prefix2, const double *Xsub, int64_t Nsub,
-                                 int64_t Npsub, const double *Usub, gpbo_result *result, gpbo_screen_stats *stats_host,
-                                 void *work, int64_t work_bytes, void *stream);
+/* Order independence of that bound (csrc/subset.hip; version 140, replaces the gpbo_*_subset_f64 calls of 130): which
+ * observations come FIRST decides how much the prefix prunes, and a history sorted along an axis or started inside one
+ * cluster is a bad prefix.  gpbo_fps_order_f64 writes a permutation of the observations - J members by farthest-point
+ * sampling in length-scale units (first member: the observation farthest from the centroid; then the one farthest from
+ * the members so far; ties to the lowest index), then every other observation in index order - and gathers X / y in that
+ * order.  The caller factorises the PERMUTED problem (a GP's posterior does not depend on the order of its observations:
+ * same mean_func / cov_func within rounding, point_selector.py:89-98) and runs every pass - gpbo_posterior_acq_f64 as
+ * well as the two calls above - on that one factorisation, so the bound's |v[:J]|^2 is a partial sum of the squares the
+ * plain pass itself adds up, whatever the history.
+ * perm_out [N] int64, Xp_out [N x d], yp_out [N] (both optional; y may be NULL when yp_out is): device memory;
+ * 1 <= J <= N, d <= GPBO_MAX_D; work: gpbo_fps_order_workspace_bytes(N) bytes, 256-byte aligned. */
+int64_t gpbo_fps_order_workspace_bytes(int64_t N);
+int gpbo_fps_order_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_host, int64_t J,
+                       int64_t *perm_out, double *Xp_out, double *yp_out, void *work, int64_t work_bytes, void *stream);
 
 /* int8-sliced variance screen (Ozaki-style splitting on the integer matrix cores, csrc/ozaki.hip): same role and
  * outputs as gpbo_posterior_acq_f32 - mean exactly the fp64 path's, variance from 20 exact int8 slice products

@@ -54,7 +54,7 @@ def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
     pb = line["also"]["prefix_bound_screen_same_workload"]
     assert pb["argmax_matches_fp64"] is True and not pb["screen"]["fallback"] and pb["value"] > 0
     assert pb["screen"]["mode"] == "bound" and pb["screen"]["rescored"] < (1 << 21) // 16
-    assert pb["unit"] == "candidates disposed/s" and pb["screen"]["subset"] == "fps"
+    assert pb["unit"] == "candidates disposed/s" and pb["screen"]["order"] == "fps"
     assert set(pb["survivors_by_acquisition"]) == {"lcb_explore_1", "lcb_explore_4", "lcb_explore_10", "ei"}
     assert all(v["same_point_as_plain_pass"] for v in pb["survivors_by_acquisition"].values())
     pe = line["also"]["prefix_bound_screen_ei_same_workload"]

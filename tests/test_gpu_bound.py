@@ -299,37 +299,64 @@ def _fps_reference(X, ls, J):
 
 
 @pytest.mark.parametrize("N,d", [(1500, 5), (9300, 3), (700, 16), (3000, 16), (5000, 8)])
-def test_subset_is_farthest_point_sampling_and_its_factor_is_the_subsets(N, d):
-    """gpbo_bound_subset_f64 against NumPy: the members, their extension in index order, the gathered rows and
-    U_S = chol(K_SS + jitter)^-T of exactly those rows (register-resident kernel; one launch per member where a thread's
-    points would not fit its registers: N = 9300, 3000 x 16, 5000 x 8)."""
+def test_farthest_point_order_and_the_factorisation_of_the_permuted_problem(N, d):
+    """gpbo_fps_order_f64 against NumPy: the J members, every other observation after them in index order, the gathered rows
+    (register-resident kernel; one launch per member where a thread's points would not fit its registers: N = 9300,
+    3000 x 16, 5000 x 8) - and factorise(order="fps") = the factorisation of exactly that permuted problem."""
     X, y, Xs, ls = make_problem(N, 512, d)
-    gp = DeviceGP().factorise(X, y, ls)
-    J, J2 = 128, 512
-    Xsub, Usub, Ns, perm, info = gp._ensure_bound_subset(J, J2)
-    assert Ns == 512 and info == 0
-    perm = perm.cpu().numpy()
+    gp = DeviceGP().factorise(X, y, ls, order="fps")
+    J = gp.bound_prefix()
+    assert gp.order == "fps" and J == 128 * max(1, gp.Np // 16 // 128)
+    perm = gp.perm.cpu().numpy()
     ref = _fps_reference(X, ls, J)
     # distances are sums of d squares in a different association on the GPU (fma) - members agree unless two candidates
     # tie to the last bit; on this seeded problem they do not
     assert np.array_equal(perm[:J], ref)
-    rest = np.setdiff1d(np.arange(N), ref)[: J2 - J]
-    assert np.array_equal(perm[J:], rest) and len(set(perm.tolist())) == J2
-    for _ in range(3):   # the same members every time (the one-launch-per-member form hands partial results between workgroups)
-        gp._bound_subset = None
-        assert np.array_equal(gp._ensure_bound_subset(J, J2)[3].cpu().numpy(), perm)
-    assert np.array_equal(Xsub.cpu().numpy(), X[perm])
-    K = O.kernel_rbf(X[perm], X[perm], ls) + 1e-6 * np.eye(J2)   # kernel_rbf adds its own 1e-4 (same shapes)
+    rest = np.setdiff1d(np.arange(N), ref)
+    assert np.array_equal(perm[J:], rest) and np.array_equal(np.sort(perm), np.arange(N))
+    for _ in range(3):   # the same order every time (the one-launch-per-member form hands partial results between workgroups)
+        assert np.array_equal(DeviceGP().factorise(X, y, ls, order="fps").perm.cpu().numpy(), perm)
+    assert np.array_equal(gp.X[:N].cpu().numpy(), X[perm]) and np.array_equal(gp.y[:N].cpu().numpy(), y[perm])
+    Xa, ya = gp.observations_host()
+    assert np.array_equal(Xa, X) and np.array_equal(ya, y)
+    # the factors are those of the permuted problem ...
+    K = O.kernel_rbf(X[perm], X[perm], ls) + 1e-6 * np.eye(N)   # kernel_rbf adds its own 1e-4 (same shapes)
     L = np.linalg.cholesky(K)
     U_ref = np.linalg.inv(L).T
-    assert np.max(np.abs(Usub.cpu().numpy() - U_ref)) <= 1e-9 * np.abs(U_ref).max()
+    assert np.max(np.abs(gp.U[:N, :N].cpu().numpy() - U_ref)) <= 1e-9 * np.abs(U_ref).max()
+    assert np.max(np.abs(gp.cov_meas_host() - (O.kernel_rbf(X, X, ls) + 1e-6 * np.eye(N)))) <= 1e-14   # caller's order
+    # ... and the posterior is the arrival-order one within rounding (a GP does not know the order of its observations)
+    ga = DeviceGP().factorise(X, y, ls)
+    rf, ra = gp.score(Xs, dense=True), ga.score(Xs, dense=True)
+    ys = max(1.0, float(np.abs(y).max()))
+    assert np.max(np.abs(rf.mu.cpu().numpy() - ra.mu.cpu().numpy())) <= 1e-10 * ys
+    assert np.max(np.abs(rf.sigma.cpu().numpy() - ra.sigma.cpu().numpy())) <= 1e-9
+    assert rf.best_idx == ra.best_idx
+    mu_o, sig_o = O.posterior_chol(X, y, Xs, ls)
+    assert np.max(np.abs(rf.mu.cpu().numpy() - mu_o)) <= 1e-10 * ys and np.max(np.abs(rf.sigma.cpu().numpy() - sig_o)) <= 1e-9
+    # argument checks of the C entry point
+    import torch
+
+    lib, t = gp.lib, torch
+    Xd = gp._dev(X)
+    pr = t.empty(N, dtype=t.int64, device=gp.device)
+    wb = int(lib.gpbo_fps_order_workspace_bytes(N))
+    w = t.empty(wb // 8 + 1, dtype=t.float64, device=gp.device)
+    lsp = gp.ls_h.ctypes.data_as(C.c_void_p)
+    assert lib.gpbo_fps_order_f64(gp._ptr(Xd), None, N, d, lsp, 0, gp._ptr(pr), None, None, gp._ptr(w), wb, gp._stream()) == -1
+    assert lib.gpbo_fps_order_f64(gp._ptr(Xd), None, N, d, lsp, N + 1, gp._ptr(pr), None, None, gp._ptr(w), wb, gp._stream()) == -1
+    assert lib.gpbo_fps_order_f64(gp._ptr(Xd), None, N, d, lsp, J, gp._ptr(pr), None, gp._ptr(w), gp._ptr(w), wb, gp._stream()) == -1  # yp without y
+    assert lib.gpbo_fps_order_f64(gp._ptr(Xd), None, N, d, lsp, J, gp._ptr(pr), None, None, gp._ptr(w), 8, gp._stream()) == -3
+    assert lib.gpbo_fps_order_f64(gp._ptr(Xd), None, N, d, lsp, J, gp._ptr(pr), None, None, gp._ptr(w), wb, gp._stream()) == 0
+    t.cuda.synchronize()
+    assert np.array_equal(pr.cpu().numpy(), perm)
 
 
 @pytest.mark.parametrize("order", ["sobol", "sorted", "reversed", "clustered_first"])
 def test_pruning_does_not_depend_on_the_order_of_the_observations(order):
     """the literal prefix of a history sorted along an axis (or whose first rows sit in one
-    cluster) knows one corner of the domain and prunes nothing; the farthest-point subset prunes it like a Sobol history.
-    The selected point is the plain pass's in every order, and the same point in all of them."""
+    cluster) knows one corner of the domain and prunes nothing; factorised in farthest-point order it prunes like a Sobol
+    history.  The selected point is the plain pass's in every order, and the same point in all of them."""
     N, M, d = 2048, 1 << 17, 8
     X, y, Xs, ls = make_problem(N, M, d)
     if order == "sorted":
@@ -341,15 +368,182 @@ def test_pruning_does_not_depend_on_the_order_of_the_observations(order):
         o = np.argsort(c)          # the first rows are the observations nearest one point of the domain
     else:
         o = np.arange(N)
-    gp = DeviceGP(chunk=1 << 15).factorise(X[o], y[o], ls)
+    gp = DeviceGP(chunk=1 << 15).factorise(X[o], y[o], ls, order="fps")
+    ga = DeviceGP(chunk=1 << 15).factorise(X[o], y[o], ls)
     for kw in (dict(acquisition="lcb", explore=4.0), dict(acquisition="ei", f_best=float(y.min()), xi=0.0)):
         r64 = gp.score(Xs, **kw)
         rb = gp.score_bound(Xs, **kw)
         st = dict(gp.last_screen)
         _same(rb, r64, max(1.0, float(np.abs(y).max())))
-        assert st["subset"] == "fps" and not st["fallback"] and st["rescored"] < M // 4, (order, st)
+        assert st["order"] == "fps" and not st["fallback"] and st["rescored"] < M // 4, (order, st)
+        assert ga.score(Xs, **kw).best_idx == rb.best_idx   # and the arrival-order factorisation's plain pass agrees
     if order in ("sorted", "clustered_first"):
-        gp.score_bound(Xs, subset="arrival")
-        arrival = dict(gp.last_screen)
-        gp.score_bound(Xs)
+        ra = ga.score_bound(Xs)
+        arrival = dict(ga.last_screen)
+        assert arrival["order"] == "arrival" and ra.best_idx == gp.score_bound(Xs).best_idx
         assert gp.last_screen["rescored"] <= arrival.get("rescored", M) or arrival["fallback"]
+
+
+# ---- the bound of the route that SHIPS, per candidate -------------------------------------------------
+# Since round 4 the route has ONE factorisation (the farthest-point-ordered observations): bounds and exact values come from
+# the same U through the same kernels, |v[:J]|^2 is a partial sum of the squares the plain pass adds up.  These tests hold
+# acq_ub >= acq for EVERY candidate on that form - both levels, unnormalised inputs, candidates on observations, an
+# ill-conditioned history.
+
+def _prefix_pass(gp, Xs, J, kind=None, p0=4.0, p1=0.0):
+    import torch
+
+    Xd = gp._dev(Xs)
+    M = Xd.shape[0]
+    chunk, wbytes = gp._ensure_post_workspace(M)
+    o = [torch.empty(M, dtype=torch.float64, device=gp.device) for _ in range(3)]
+    st = gp.lib.gpbo_posterior_prefix_f64(gp._ptr(Xd), M, gp._ptr(gp.X), gp.N, gp.Np, gp.d, gp.ls_h.ctypes.data_as(C.c_void_p),
+                                          gp._ptr(gp.U), gp._ptr(gp.alpha), 1.000101, _lib.ACQ_LCB if kind is None else kind,
+                                          p0, p1, 0, chunk, J, gp._ptr(o[0]), gp._ptr(o[1]), gp._ptr(o[2]), gp._ptr(gp._result),
+                                          gp._ptr(gp._work_post), wbytes, None, gp._stream())
+    assert st == 0
+    torch.cuda.synchronize()
+    return tuple(t.cpu().numpy() for t in o)
+
+
+def _ill_conditioned(N, M, d, seed):
+    """Hundreds of points on a line, a tenth of them duplicated rows, the rest scattered: cond(K) ~ 1e7 at the reference's
+    jitter - the case the fuzz sweeps report as worst for the mean."""
+    rng = np.random.default_rng(seed)
+    t = rng.uniform(0, 1, N)
+    X = 0.5 + np.outer(t - 0.5, np.linspace(0.2, 0.5, d))
+    X[N // 2:] = rng.uniform(0, 1, (N - N // 2, d))
+    dup = rng.integers(0, N // 2, N // 10)
+    X[rng.integers(0, N, N // 10)] = X[dup]
+    X = X[rng.permutation(N)]
+    ls = np.full(d, 0.6)
+    y = np.sin(5 * X[:, 0]) + 0.3 * X.sum(1) + 1e-3 * rng.standard_normal(N)
+    Xs = rng.uniform(0, 1, (M, d))
+    Xs[:400] = X[rng.integers(0, N, 400)]                                    # candidates ON observations
+    Xs[400:800] = 0.5 + np.outer(rng.uniform(-0.5, 0.5, 400), np.linspace(0.2, 0.5, d))   # ... and on the line between them
+    return X, y, Xs, ls
+
+
+@pytest.mark.parametrize("problem", ["sobol", "raw_1e3", "raw_5e4", "tiny_ls", "ill_conditioned", "sorted_history"])
+def test_shipping_bound_holds_for_every_candidate_at_both_levels(problem):
+    """factorise(order="fps") + gpbo_posterior_prefix_f64 at J = 128 / 256 / 1024 (the first level of N = 2048 / 4096 and
+    the second level of N = 4096) and J = N/4 (this problem's second level): sigma_ub >= sigma and acq_ub >= acq of the plain
+    pass ON THE SAME FACTORISATION for every candidate, LCB and EI; the bounds tighten as J grows; and the plain pass's own
+    variance stays far from the |var| reflection (>= half the jitter) even at cond(K) ~ 1e7."""
+    N, M, d = 1500, 30000, 6
+    rng = np.random.default_rng(11)
+    if problem == "sobol":
+        X, y, Xs, ls = make_problem(N, M, d)
+        Xs = Xs.copy()
+        Xs[:60] = X[::25]
+    elif problem in ("raw_1e3", "raw_5e4", "tiny_ls"):
+        scale, ls_lo, ls_hi, yscale = {"raw_1e3": (1e3, 8.0, 60.0, 1e-3), "raw_5e4": (5e4, 300.0, 4e3, 1e-6),
+                                       "tiny_ls": (1.0, 0.02, 0.2, 1e-4)}[problem]
+        X = rng.uniform(0, scale, (N, d))
+        Xs = rng.uniform(-0.05 * scale, 1.05 * scale, (M, d))
+        Xs[:200] = X[:200] + 1e-7 * scale * rng.standard_normal((200, d))
+        ls = np.exp(rng.uniform(np.log(ls_lo), np.log(ls_hi), d))
+        y = yscale * rng.standard_normal(N)
+    elif problem == "ill_conditioned":
+        X, y, Xs, ls = _ill_conditioned(N, M, d, 5)
+        K = O.kernel_rbf(X, X, ls) + 1e-6 * np.eye(N)
+        assert np.linalg.cond(K) > 3e6
+    else:
+        X, y, Xs, ls = make_problem(N, M, d)
+        o = np.argsort(X[:, 0])
+        X, y = X[o], y[o]
+    gp = DeviceGP(chunk=8192).factorise(X, y, ls, order="fps")
+    full = gp.score(Xs, dense=True)
+    mu, sig, acq = (t.cpu().numpy() for t in (full.mu, full.sigma, full.acq))
+    var = gp.score(Xs[:800], dense=True).sigma.cpu().numpy() ** 2
+    assert var.min() >= 0.5 * 1.01e-4   # true variance >= jitter: the plain pass never gets near a negative value
+    fb = float(y.min())
+    ei = gp.score(Xs, acquisition="ei", f_best=fb, dense=True).acq.cpu().numpy()
+    prev = None
+    for J in (128, 256, 384, 1024):      # 384 = N/4 rounded to the granule: this problem's own second level
+        m, s, a = _prefix_pass(gp, Xs, J)
+        assert np.all(m <= mu)           # the mean is reported from below (kstar_mfma.hip), never above the plain pass's
+        assert np.all(s >= sig) and np.all(a >= acq), (problem, J, float((sig - s).max()))
+        _, _, ae = _prefix_pass(gp, Xs, J, kind=_lib.ACQ_EI, p0=fb, p1=0.0)
+        # (EI = imp Phi(z) + sigma phi(z) cancels for z << 0: values of 1e-100 carry rounding noise of their own size; the
+        #  selection's slack, 1e-10 max(1, |t|), is what covers it - rescore.hip)
+        assert np.all(ae >= ei - 1e-13 * max(1.0, float(ei.max()))), (problem, J, float((ei - ae).max()))
+        if prev is not None:
+            assert np.all(s <= prev + 1e-13)
+        prev = s
+    # the whole route: same point as the plain pass of the same factorisation AND of the arrival-order one
+    ga = DeviceGP(chunk=8192).factorise(X, y, ls)
+    for kw in (dict(acquisition="lcb", explore=4.0), dict(acquisition="lcb", explore=0.5), dict(acquisition="ei", f_best=fb)):
+        rb, r64 = gp.score_bound(Xs, **kw), gp.score(Xs, **kw)
+        assert rb.best_idx == r64.best_idx and rb.nan_count == r64.nan_count == 0
+        assert abs(rb.best_val - r64.best_val) <= 1e-9 * max(1.0, abs(r64.best_val))
+        ra = ga.score(Xs, **kw)
+        if problem != "ill_conditioned":      # (there the two factorisations' values differ by cond * eps: ties may flip)
+            assert ra.best_idx == rb.best_idx
+
+
+def test_second_level_bound_of_the_headline_size_for_every_candidate():
+    """N = 4096: J = 256 (first level) and 1024 (second level) exactly as bench.py --dtype f64b runs them."""
+    X, y, Xs, ls = make_problem(4096, 20000, 8)
+    gp = DeviceGP(chunk=4096).factorise(X, y, ls, order="fps")
+    assert gp.bound_prefix() == 256
+    full = gp.score(Xs, dense=True)
+    sig, acq = full.sigma.cpu().numpy(), full.acq.cpu().numpy()
+    s1 = None
+    for J in (256, 1024):
+        m, s, a = _prefix_pass(gp, Xs, J)
+        assert np.all(s >= sig) and np.all(a >= acq)
+        s1 = s if s1 is None else s1
+    assert np.all(s <= s1 + 1e-13) and np.mean(s - sig) < np.mean(s1 - sig)
+    rb = gp.score_bound(Xs)
+    assert gp.last_screen["prefix"] == 256 and gp.last_screen["prefix2"] == 1024 and rb.best_idx == full.best_idx
+
+
+def test_state_loaded_into_a_used_surrogate_takes_its_own_order_with_it():
+    """score_bound, then load_state of a DIFFERENT surrogate with the same padded size, then
+    score_bound again - the bound must belong to the loaded observations (round 3 kept the old observation subset and could
+    prune the true arg-max; there is no such cached state any more: the order is part of the factorisation and of its
+    state)."""
+    N, M, d = 1200, 40000, 5
+    X1, y1, Xs, ls1 = make_problem(N, M, d)
+    rng = np.random.default_rng(9)
+    X2 = rng.uniform(0, 1, (N, d))
+    X2 = X2[np.argsort(X2[:, 1])]
+    y2 = np.cos(7 * X2[:, 0]) - X2[:, 2] + 0.01 * rng.standard_normal(N)
+    ls2 = np.array([0.3, 0.5, 0.2, 0.9, 0.4])
+    other = DeviceGP(chunk=8192).factorise(X2, y2, ls2, order="fps")
+    st = other.state_dict()
+    assert "perm" in st and np.array_equal(np.sort(st["perm"]), np.arange(N))
+    gp = DeviceGP(chunk=8192).factorise(X1, y1, ls1, order="fps")
+    r1 = gp.score_bound(Xs)
+    assert r1.best_idx == gp.score(Xs).best_idx
+    gp.load_state_dict(st)
+    assert gp.order == "fps" and np.array_equal(gp.perm.cpu().numpy(), st["perm"])
+    Xa, ya = gp.observations_host()
+    assert np.array_equal(Xa, X2) and np.array_equal(ya, y2)
+    for kw in (dict(acquisition="lcb", explore=4.0), dict(acquisition="ei", f_best=float(y2.min()))):
+        rb, r64, ro = gp.score_bound(Xs, **kw), gp.score(Xs, **kw), other.score(Xs, **kw)
+        assert not gp.last_screen["fallback"]
+        assert rb.best_idx == r64.best_idx == ro.best_idx and rb.best_val == pytest.approx(ro.best_val, rel=1e-12)
+    # an appended observation goes last in both orders; the state of an arrival-order surrogate carries no permutation
+    gp.append(np.full(d, 0.5), 0.1)
+    assert gp.perm.shape[0] == N + 1 and int(gp.perm[-1]) == N
+    Xa, ya = gp.observations_host()
+    assert np.array_equal(Xa[:N], X2) and np.array_equal(Xa[N], np.full(d, 0.5)) and ya[N] == 0.1
+    assert gp.score_bound(Xs).best_idx == gp.score(Xs).best_idx
+    assert "perm" not in DeviceGP().factorise(X1, y1, ls1).state_dict()
+
+
+def test_routes_the_bound_must_not_take_with_a_permuted_factorisation():
+    """The N == M quirk is keyed on the arrival index (point_selector.py:173): a permuted factorisation refuses it; a jitter
+    too small for the |var| rule sends score_bound to the plain pass."""
+    X, y, Xs, ls = make_problem(600, 600, 4)
+    gp = DeviceGP(chunk=1024).factorise(X, y, ls, order="fps")
+    with pytest.raises(ValueError):
+        gp.score(Xs, diag_add=1e-4)
+    g0 = DeviceGP(chunk=1024).factorise(X, y, ls, 1e-8, 0.0)
+    X2, y2, Xs2, ls2 = make_problem(600, 20000, 4)
+    g0.factorise(X2, y2, ls2, 1e-8, 0.0, order="fps")
+    r = g0.score_bound(Xs2, prior_var=1.0 + 1e-8)
+    assert g0.last_screen["fallback"] and "jitter" in g0.last_screen["reason"]
+    assert r.best_idx == g0.score(Xs2, prior_var=1.0 + 1e-8).best_idx

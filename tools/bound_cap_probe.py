@@ -16,7 +16,7 @@ y = rff_objective(X, ls)
 Xs = sobol_points(N, M, d)
 gp = DeviceGP(dev)
 Xd, yd, Xsd = gp._dev(X), gp._dev(y), gp._dev(Xs)
-gp.factorise(Xd, yd, ls, check=False)
+gp.factorise(Xd, yd, ls, check=False, order="fps")
 fb = float(np.min(y))
 for cap in (0, M // 16):
     gp.screen_cap = cap

@@ -9,7 +9,7 @@ from bayesian_optimisation_amd.synthetic import make_problem
 for N, M, d, chunk in [(256, 2048, 8, 1024), (700, 5000, 8, 2048), (2048, 40000, 8, 4096), (1000, 60000, 16, 8192),
                        (2500, 70000, 8, 1 << 15), (4096, 1 << 17, 8, 1 << 16)]:
     X, y, Xs, ls = make_problem(N, M, d)
-    gp = DeviceGP(chunk=chunk).factorise(X, y, ls)
+    gp = DeviceGP(chunk=chunk).factorise(X, y, ls, order="fps")
     for kw in (dict(acquisition="lcb"), dict(acquisition="lcb", explore=1.0), dict(acquisition="lcb", explore=12.0),
                dict(acquisition="ei", f_best=float(y.min()))):
         r = gp.score_bound(Xs, idx_offset=3, **kw)
@@ -21,7 +21,7 @@ for N, M, d, chunk in [(256, 2048, 8, 1024), (700, 5000, 8, 2048), (2048, 40000,
 if len(sys.argv) > 1:
     N, M, d = 4096, 1 << 21, 8
     X, y, Xs, ls = make_problem(N, M, d)
-    gp = DeviceGP().factorise(X, y, ls)
+    gp = DeviceGP().factorise(X, y, ls, order="fps")
     Xd = gp._dev(Xs)
     for name, fn in [("bound", gp.score_bound), ("bound J=512 one level", lambda P: gp.score_bound(P, prefix=512, prefix2=0)),
                      ("bound J=256 one level", lambda P: gp.score_bound(P, prefix=256, prefix2=0)),

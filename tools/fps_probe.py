@@ -1,19 +1,21 @@
-"""Time of the bound route's observation subset (farthest-point sampling + gather + its own factorisation): python tools/fps_probe.py"""
+"""Time of the farthest-point order of the observations (gpbo_fps_order_f64: selection + gather) the bound route's
+factorisation starts with: python tools/fps_probe.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bayesian_optimisation_amd import DeviceGP
 from bayesian_optimisation_amd.synthetic import make_problem
-for N, d in ((4096, 8), (8192, 8), (8192, 4), (6000, 6)):
+for N, d in ((2048, 8), (4096, 8), (8192, 8), (8192, 16), (8192, 4), (6000, 6)):
     X, y, Xs, ls = make_problem(N, 512, d)
     gp = DeviceGP()
-    gp.factorise(X, y, ls)
-    Np = gp.Np
-    J = max(128, (Np // 16) // 128 * 128); J2 = 4 * J
-    ts = []
+    Xd, yd = gp._dev(X), gp._dev(y)
+    ta, tf = [], []
     for _ in range(5):
-        gp._bound_subset = None   # rebuild
         torch.cuda.synchronize(); t = time.perf_counter()
-        gp._ensure_bound_subset(J, J2)
-        torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
-    print(f"N={N} d={d}: subset (FPS + gather + factor of {J2}) {min(ts)*1e3:.3f} ms", flush=True)
+        gp.factorise(Xd, yd, ls, check=False)
+        torch.cuda.synchronize(); ta.append(time.perf_counter() - t)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        gp.factorise(Xd, yd, ls, check=False, order="fps")
+        torch.cuda.synchronize(); tf.append(time.perf_counter() - t)
+    print(f"N={N} d={d}: factorise {min(ta)*1e3:.3f} ms, with the farthest-point order ({gp.bound_prefix()} members) "
+          f"{min(tf)*1e3:.3f} ms: order {1e3*(min(tf)-min(ta)):.3f} ms", flush=True)

@@ -4,8 +4,7 @@ import numpy as np, torch
 from bayesian_optimisation_amd import DeviceGP
 from bayesian_optimisation_amd.synthetic import make_problem
 X, y, Xs, ls = make_problem(8192, 512, 16)
-gp = DeviceGP(); gp.factorise(X, y, ls)
+gp = DeviceGP()
 for _ in range(3):
-    gp._bound_subset = None
-    gp._ensure_bound_subset(512, 2048)
+    gp.factorise(X, y, ls, order="fps")
 torch.cuda.synchronize()

@@ -1,5 +1,6 @@
 """Randomised sweep of the exact prefix bound (DeviceGP.score_bound) against the plain fp64 pass: random sizes, feature
-counts, length scales, objectives (rough / nearly flat), observation orders (random / sorted along an axis / clustered),
+counts, length scales, objectives (rough / nearly flat), observation orders (random / sorted along an axis / clustered;
+factorised in arrival or in farthest-point order), ill-conditioned histories (points on a line, duplicated rows),
 acquisitions (LCB weights 0 .. 30, EI), prefix lengths, duplicated and NaN candidates.  The bar: the same index, the same
 NaN count, the value within 1e-9 relative (both values are fp64 kernels' - the fused launch of the plain pass and the
 column-split launch that re-scores the survivors add |v|^2 up in different orders, and sigma^2 = c - |v|^2 cancels: with
@@ -31,7 +32,14 @@ while time.time() < t_end:
         X = X[np.argsort(X[:, 0])]
     elif kind == 2:
         X[: N // 2] = 0.5 + 0.05 * rng.standard_normal((N // 2, d))
+    elif rng.random() < 0.15:   # hundreds of points on a line + duplicated rows: cond(K) ~ 1e7 at the reference's jitter
+        t = rng.uniform(0, 1, N)
+        X = 0.5 + np.outer(t - 0.5, rng.standard_normal(d) * 0.3)
+        X[rng.integers(0, N, N // 10)] = X[rng.integers(0, N, N // 10)]
     Xs = rng.uniform(-0.1, 1.1, (M, d))
+    if rng.random() < 0.3:      # candidates ON observations (smallest variances)
+        k = min(M, N) // 2
+        Xs[:k] = X[rng.integers(0, N, k)]
     if rng.random() < 0.25:  # raw physical units: large coordinates, length scales to match
         sc = float(rng.choice([1e2, 1e3, 5e4]))
         X, Xs, ls = X * sc, Xs * sc, ls * sc * float(rng.choice([0.05, 0.3, 1.0]))
@@ -46,14 +54,15 @@ while time.time() < t_end:
         kw = dict(acquisition="ei", f_best=float(y.min()), xi=float(rng.choice([0.0, 0.01])))
     tag = f"d={d} N={N} M={M} order={kind} {kw}"
     try:
-        gp = DeviceGP(chunk=int(rng.choice([4096, 1 << 15, 1 << 17]))).factorise(X, y, ls)
+        order = str(rng.choice(["fps", "fps", "arrival"]))   # the factorisation's order of the observations (both exact)
+        gp = DeviceGP(chunk=int(rng.choice([4096, 1 << 15, 1 << 17]))).factorise(X, y, ls, order=order)
         J = int(rng.choice([0, 128, 256]))
         args = dict(prefix=J, prefix2=int(rng.choice([0, 2 * J, 4 * J]))) if J else {}
         if J and 2 * J > gp.Np:
             args = {}
         if args.get("prefix2", 0) > gp.Np:
             args["prefix2"] = 0
-        r = gp.score_bound(Xs, idx_offset=5, subset=str(rng.choice(["fps", "fps", "arrival"])), **kw, **args)
+        r = gp.score_bound(Xs, idx_offset=5, **kw, **args)
         st = dict(gp.last_screen)
         r64 = gp.score(Xs, idx_offset=5, **kw)
         n_fallback += bool(st.get("fallback"))
