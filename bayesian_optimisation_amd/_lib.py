@@ -57,10 +57,11 @@ SIGNATURES = {
     "gpbo_profile_reset": (None, [_p]),
     "gpbo_profile_read": (C.c_int, [_p, C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gpbo_profile_read_kstar": (C.c_int, [_p, C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "gpbo_profile_read_qei": (C.c_int, [_p, C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gpbo_profile_destroy": (None, [_p]),
     "gpbo_qei_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gpbo_posterior_qei_f64": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _f64, _f64, _p, _i32, _i64,
-                                         _i64, _p, _p, _p, _i64, _p]),
+                                         _i64, _p, _p, _p, _i64, _p, _p]),
     "gpbo_padded_n_f32": (_i64, [_i64]),
     "gpbo_prepare_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p]),
     "gpbo_posterior_workspace_bytes_f32": (_i64, [_i64, _i64, _i64]),

@@ -214,7 +214,7 @@ extern "C" int gpbo_select_qei_host_f64(const double *X, const double *y, int64_
     }
     const double prior_var = (1.0 + jitter1) + jitter2;
     rc = gpbo_posterior_qei_f64(dXs, M, dX, N, Np, d, ls, dU, dalpha, prior_var, f_best, xi, dZ, S, 0, chunk, dq, dres,
-                                dwork, wq, st);
+                                dwork, wq, nullptr, st);
     if (rc != GPBO_OK) return rc;
     bool okc = A.d2h(result, dres, sizeof(gpbo_result));
     if (qei_out) okc = okc && A.d2h(qei_out, dq, sizeof(double) * (M / 8));

@@ -978,7 +978,7 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
                                       const double *ls_host, const double *U, const double *alpha, double prior_var,
                                       double f_best, double xi, const double *Z, int32_t S, int64_t batch_offset,
                                       int64_t chunk, double *qei_out, gpbo_result *result, void *work,
-                                      int64_t work_bytes, void *stream) {
+                                      int64_t work_bytes, gpbo_profile *prof, void *stream) {
     if (!Xs || !X || !U || !alpha || !Z || !result || !work) return GPBO_ERR_ARG;
     if (M < QQ || M % QQ || N < 1 || Np != gpbo_padded_n(N) || S < 1 || d < 1 || d > GPBO_MAX_D) return GPBO_ERR_ARG;
     if (chunk < GPBO_CHUNK_GRANULE || chunk % GPBO_CHUNK_GRANULE || chunk > GPBO_CHUNK_MAX) return GPBO_ERR_ARG;
@@ -1010,8 +1010,13 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
     int64_t nparts = 0;
     for (int64_t s = 0; s < M; s += chunk) {
         const int64_t Mc = (M - s < chunk) ? (M - s) : chunk;
+        // one profile slot per chunk: kbegin | K(X*,X) | begin | variance launch (+ its finish) | end | qEI launch | qend
+        const bool rec = prof && prof->count < prof->capacity;
+        auto mark = [&](void *ev) { return hipEventRecord(reinterpret_cast<hipEvent_t>(ev), st) == hipSuccess; };
+        if (rec && !mark(prof->kbegin[prof->count])) return GPBO_ERR_LAUNCH;
         rc = gpbo_kstar_mu_f64(Xs + s * d, Mc, Xsc, N, Np, d, ls_host, alpha, 0.0, 0, KsT, chunk, mu_part, stream);
         if (rc != GPBO_OK) return rc;
+        if (rec && !mark(prof->begin[prof->count])) return GPBO_ERR_LAUNCH;
         const int64_t nblk = (Mc + BM - 1) / BM;
         // the variance kernel also leaves V (vbuf) and mu; its own single-point acquisition result is ignored.
         // Large calls: column groups on one XCD as in gpbo_posterior_acq_f64 (each group writes its column blocks of V;
@@ -1034,12 +1039,20 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
                                (int)nblk, 0);
         }
         GPBO_CHECK_LAUNCH();
+        if (rec && !mark(prof->end[prof->count])) return GPBO_ERR_LAUNCH;
         const int64_t nbatch = Mc / QQ;
         const int64_t qblk = (nbatch + 3) / 4;
         hipLaunchKernelGGL(qei_kernel, dim3((unsigned)qblk), dim3(256), 0, st, Vb, (int)Np, mu, Xs + s * d, (int)d, ls, nbatch,
                            prior_var, f_best, xi, Z, (int)S, batch_offset + s / QQ, qei_out ? qei_out + s / QQ : nullptr,
                            part_val + nparts, part_idx + nparts, nan_count);
         GPBO_CHECK_LAUNCH();
+        if (rec) {
+            if (!mark(prof->qend[prof->count])) return GPBO_ERR_LAUNCH;
+            prof->kmode[prof->count] = 1;
+            prof->qmode[prof->count] = 1;
+            prof->cands[prof->count] = Mc;
+            ++prof->count;
+        }
         nparts += qblk;
     }
     return gpbo_launch_argmax_finish(part_val, part_idx, nparts, nan_count, result, st);

@@ -96,6 +96,12 @@ class DeviceGP:
                    "gpbo_profile_read_kstar")
         return ms.value, n.value, c.value
 
+    def read_profile_qei(self):
+        """(total ms, launches, candidates) of the qEI launches recorded by score_qei()."""
+        ms, n, c = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(self.lib.gpbo_profile_read_qei(self._profile, C.byref(ms), C.byref(n), C.byref(c)), "gpbo_profile_read_qei")
+        return ms.value, n.value, c.value
+
     # -- helpers -------------------------------------------------------------------------------
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
@@ -698,7 +704,7 @@ class DeviceGP:
                 self._ptr(Xsd), M, self._ptr(self.X), self.N, self.Np, self.d, self.ls_h.ctypes.data_as(C.c_void_p),
                 self._ptr(self.U), self._ptr(self.alpha), prior_var, float(f_best), float(xi), self._ptr(Zd), S,
                 int(batch_offset), chunk, self._ptr(qei), self._ptr(self._result), self._ptr(self._work_qei), need,
-                self._stream())
+                self._profile if self.profile_active else None, self._stream())
             _lib.check(st, "gpbo_posterior_qei_f64")
         self._keep = (Xsd, Zd)
         return self._result, qei

@@ -158,6 +158,120 @@ def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best, variance_dty
                        f"{', variance product in fp32; arg-max checked against the fp64 route' if variance_dtype == 'f32' else ''})"), idx, ns
 
 
+def _pmc_entry(N, d, dtype, cands):
+    """The committed rocprofv3 --pmc entry of this shape (profiles/pmc_sigma_acq.json) and whether the kernel sources have
+    changed since it was collected (profiles/source_hash.py): (entry or None, stale True / False / None = no hash stored)."""
+    try:
+        shapes = json.load(open(os.path.join(REPO, "profiles", "pmc_sigma_acq.json")))
+        e = shapes.get(f"N={N},d={d},dtype={dtype},candidates_per_launch={int(cands)}")
+        if not e:
+            return None, None
+        sys.path.insert(0, os.path.join(REPO, "profiles"))
+        from source_hash import kernel_source_hash
+
+        stale = (e["kernel_source_hash"] != kernel_source_hash(dtype)) if "kernel_source_hash" in e else None
+        return e, stale
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+def kernel_rooflines(gp, N, d, dtype, qei=False, event_stride=1):
+    """(roofline, kstar_roofline, qei_roofline) of the launches `gp`'s profile has recorded since its last reset: the
+    dominant kernel (sigma / acquisition / arg-max) on the matrix-core peak of its arithmetic type, the K(X*,X) build on
+    HBM (or, on the bound route, on the fp64 vector-issue ceiling), the qEI stage on HBM.  ALGORITHMIC work per candidate
+     x candidates per launch / the average launch time, hipEvents on the kernels' own stream."""
+    f32, i8c, bnd = dtype == "f32", dtype == "i8c", dtype == "f64b"
+    i8 = dtype in ("i8", "i8c")
+    k_ms, k_launches, k_cands = gp.read_profile()
+    if not k_launches:
+        return None, None, None
+    k_avg_ms = k_ms / k_launches
+    cand_per_launch = k_cands / k_launches
+    flop_per_cand = float(N) * N + 2.0 * N           # triangular product N^2 + |v|^2 2N  (DESIGN.md)
+    if bnd:   # the first pass multiplies the first J columns of V only (the re-scoring launches are not bracketed)
+        Jp = float((gp.last_screen or {}).get("prefix", N))
+        flop_per_cand = Jp * Jp + 2.0 * Jp
+    achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
+    # HBM bytes of one launch from the committed rocprofv3 --pmc passes of this same command line (profiles/):
+    # counters cannot be read from inside the run, so the figure is replayed for the shape it was collected on - and
+    # flagged when the kernel sources are no longer the ones that were profiled
+    entry, stale = _pmc_entry(N, d, dtype, cand_per_launch)
+    traffic = entry["hbm_bytes_per_launch"] if entry else None
+    traffic_src = (f"committed PMC pass {entry['source']} (FETCH_SIZE x2 + WRITE_SIZE), not this run" if entry else None)
+    peak = FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS
+    unit = "TFLOP/s"
+    if i8:  # algorithmic work of this kernel: 20 (coarse: 6) int8 slice products per multiply-add of the triangular product
+        flop_per_cand = (I8C_SLICE_PRODUCTS if i8c else I8_SLICE_PRODUCTS) * float(N) * N
+        achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
+        peak, unit = I8_MFMA_PEAK_TOPS, "TOP/s (int8)"
+    roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit=unit,
+                    frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src, traffic_stale=stale,
+                    kernel={"f32": "sigma_acq_f32_kernel", "i8": "sigma_i8_kernel", "i8c": "sigma_i8c_kernel"}.get(
+                        dtype, "sigma_acq_kernel"),
+                    launches=int(k_launches),
+                    avg_launch_ms=round(k_avg_ms, 4), flop_per_candidate=flop_per_cand,
+                    candidates_per_launch=cand_per_launch,
+                    event_stride=int(max(event_stride, 1)))  # launches of every k-th timed step are bracketed
+    # second kernel of the path: K(X*,X) build (HBM-write bound when materialised): algorithmic bytes per
+    # candidate = N*w written + d*8 read (w = 8 for fp64, 4 for the fp32 screen), DESIGN.md section 4
+    kstar_roofline = None
+    ks_ms, ks_launches, ks_cands = gp.read_profile_kstar()
+    if ks_launches:
+        ks_avg = ks_ms / ks_launches
+        bytes_per_cand = {"f32": 4.0, "i8": 5.0, "i8c": 3.0}.get(dtype, 8.0) * N + 8.0 * d
+        if bnd:
+            # The prefix-bound route's K(X*,X) interval = kstar_mu_mfma_kernel (the mean of all N observations: 19 fp64
+            # VALU instructions per (candidate, observation) pair beside 2 fp64 MFMAs per 256 pairs, DESIGN.md 4d) +
+            # kstar_mu_kernel on the J stored rows (41 per pair).  It writes J rows, not N: the bound is the vector
+            # fp64 issue rate (33 T lane-instructions/s measured by tools/valu_f64_peak.hip), not HBM.  The MFMAs do not
+            # run beside fp64 VALU on gfx950 (32 of the ~108 cycles per pair and lane), so frac cannot reach 1.
+            Jp = float((gp.last_screen or {}).get("prefix", N))
+            lane_instr_per_cand = 19.0 * N + 41.0 * Jp
+            tli = lane_instr_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e12
+            kstar_roofline = dict(bound="valu", achieved=round(tli, 2), peak=VALU_F64_PEAK_TLANE,
+                                  unit="T lane-instructions/s (fp64 VALU)", frac=round(tli / VALU_F64_PEAK_TLANE, 4),
+                                  kernel="kstar_mu_mfma_kernel + kstar_mu_kernel on the stored rows",
+                                  launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
+                                  lane_instructions_per_candidate=lane_instr_per_cand,
+                                  note="static instruction counts per pair (ISA of the two kernels); the 2 fp64 MFMAs per 256 "
+                                       "pairs of the first kernel occupy the SIMD for 32 of ~108 cycles per pair and lane and "
+                                       "do not overlap with fp64 VALU on gfx950")
+        else:
+            gbs = bytes_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e9
+            kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                  frac=round(gbs / HBM_PEAK_GBS, 4),
+                                  kernel={"f32": "kstar_mu_kernel<..., float>", "i8": "kstar_slices_kernel<..., 5>",
+                                          "i8c": "kstar_slices_kernel<..., 3>"}.get(dtype, "kstar_mu_kernel"),
+                                  launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
+                                  bytes_per_candidate=bytes_per_cand)
+            # the other resource this kernel loads: vector issue.  SQ_INSTS_VALU of the committed PMC pass of this shape
+            # (a static property of the kernel and the shape, replayed like roofline.traffic), over THIS run's launch time
+            e2, stale2 = _pmc_entry(N, d, dtype, ks_cands / ks_launches)
+            wi = (e2 or {}).get("kstar_valu_wave_instructions_per_launch")
+            if wi:
+                tli = wi * 64.0 / (ks_avg * 1e-3) / 1e12
+                kstar_roofline["valu"] = dict(
+                    lane_instructions_per_s_T=round(tli, 2), fp64_issue_peak_T=VALU_F64_PEAK_TLANE,
+                    frac=round(tli / VALU_F64_PEAK_TLANE, 4), wave_instructions_per_launch=wi,
+                    source=f"SQ_INSTS_VALU of the committed PMC pass {e2['source']}, not this run", stale=stale2,
+                    note="the kernel issues vector instructions at this share of the measured fp64 issue ceiling WHILE "
+                         "streaming its stores: two nearly saturated resources that do not overlap perfectly")
+    qei_roofline = None
+    if qei:
+        # the qEI stage (qei_kernel: Gram of the 8 rows of V of a batch, 8 x 8 Cholesky, S samples): an HBM READ of V,
+        # 8 N bytes per candidate (the variance launch of this mode WRITES V: the same bytes, inside its own interval)
+        q_ms, q_launches, q_cands = gp.read_profile_qei()
+        if q_launches:
+            q_avg = q_ms / q_launches
+            gbs = 8.0 * N * (q_cands / q_launches) / (q_avg * 1e-3) / 1e9
+            qei_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=round(gbs / HBM_PEAK_GBS, 4), kernel="qei_kernel", launches=int(q_launches),
+                                avg_launch_ms=round(q_avg, 4), bytes_per_candidate=8.0 * N,
+                                note="algorithmic bytes = the rows of V the stage reads (8 N per candidate); 36 N / 8 flop "
+                                     "per candidate + S x 44 / 8 beside them")
+    return roofline, kstar_roofline, qei_roofline
+
+
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
@@ -225,7 +339,7 @@ def main():
     Zd = None
     if qei:
         Zd = gp._dev(np.random.default_rng(7).standard_normal((512, 8)))  # fixed base samples
-    events = not args.no_kernel_events and not qei
+    events = not args.no_kernel_events
     if events:
         gp.enable_profile(8192)
     acq_kw = dict(acquisition="lcb", explore=4.0) if args.acq == "lcb" else dict(acquisition="ei", f_best=f_best, xi=0.0)
@@ -274,96 +388,20 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     gp.profile_active = True
+    per_rank_ms = [dt / args.steps * 1e3]
     if use_pg:
+        # every rank's own time, gathered over the process group (RCCL: device tensors); the step time is the MAX
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        allt = torch.empty(dist.get_world_size(), dtype=torch.float64, device=tt.device)
+        dist.all_gather_into_tensor(allt, tt)
+        per_rank_ms = [float(v) / args.steps * 1e3 for v in allt.cpu()]
+        dt = max(float(v) for v in allt.cpu())
     ms_step = dt / args.steps * 1e3
     value = M_total / (dt / args.steps)
 
-    roofline = kstar_roofline = None
+    roofline = kstar_roofline = qei_roofline = None
     if events:
-        # dominant kernel (sigma/acquisition/arg-max): hipEvent pairs recorded on its stream inside the timed region
-        k_ms, k_launches, k_cands = gp.read_profile()
-        k_avg_ms = k_ms / max(k_launches, 1)
-        cand_per_launch = k_cands / max(k_launches, 1)
-        flop_per_cand = float(N) * N + 2.0 * N           # triangular product N^2 + |v|^2 2N  
-        if bnd:   # the first pass multiplies the first J columns of V only (the re-scoring launches are not bracketed)
-            Jp = float((gp.last_screen or {}).get("prefix", N))
-            flop_per_cand = Jp * Jp + 2.0 * Jp
-        achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
-        # HBM bytes of one launch from the committed rocprofv3 --pmc passes of this same command line (profiles/):
-        # counters cannot be read from inside the run, so the figure is replayed for the shape it was collected on
-        traffic = traffic_src = None
-        try:
-            shapes = json.load(open(os.path.join(REPO, "profiles", "pmc_sigma_acq.json")))
-            key = f"N={N},d={d},dtype={args.dtype},candidates_per_launch={int(cand_per_launch)}"
-            if key in shapes:
-                traffic = shapes[key]["hbm_bytes_per_launch"]
-                traffic_src = f"committed PMC pass {shapes[key]['source']} (FETCH_SIZE x2 + WRITE_SIZE), not this run"
-        except Exception:  # noqa: BLE001
-            pass
-        peak = FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS
-        unit = "TFLOP/s"
-        if i8:  # algorithmic work of this kernel: 20 (coarse: 6) int8 slice products per multiply-add of the triangular product
-            flop_per_cand = (I8C_SLICE_PRODUCTS if i8c else I8_SLICE_PRODUCTS) * float(N) * N
-            achieved = flop_per_cand * cand_per_launch / (k_avg_ms * 1e-3) / 1e12
-            peak, unit = I8_MFMA_PEAK_TOPS, "TOP/s (int8)"
-        roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit=unit,
-                        frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src,
-                        kernel={"f32": "sigma_acq_f32_kernel", "i8": "sigma_i8_kernel", "i8c": "sigma_i8c_kernel"}.get(
-                            args.dtype, "sigma_acq_kernel"),
-                        launches=int(k_launches),
-                        avg_launch_ms=round(k_avg_ms, 4), flop_per_candidate=flop_per_cand,
-                        candidates_per_launch=cand_per_launch,
-                        event_stride=int(max(args.event_stride, 1)))  # launches of every k-th timed step are bracketed
-        # second kernel of the path: K(X*,X) build (HBM-write bound when materialised): algorithmic bytes per
-        # candidate = N*w written + d*8 read (w = 8 for fp64, 4 for the fp32 screen), DESIGN.md section 4
-        ks_ms, ks_launches, ks_cands = gp.read_profile_kstar()
-        if ks_launches:
-            ks_avg = ks_ms / ks_launches
-            bytes_per_cand = {"f32": 4.0, "i8": 5.0, "i8c": 3.0}.get(args.dtype, 8.0) * N + 8.0 * d
-            if bnd:
-                # The prefix-bound route's K(X*,X) interval = kstar_mu_mfma_kernel (the mean of all N observations: 19 fp64
-                # VALU instructions per (candidate, observation) pair beside 2 fp64 MFMAs per 256 pairs) +
-                # kstar_mu_kernel on the J stored rows (41 per pair).  It writes J rows, not N: the bound is the vector
-                # fp64 issue rate (33 T lane-instructions/s measured by tools/valu_f64_peak.hip), not HBM.  The MFMAs do not
-                # run beside fp64 VALU on gfx950 (32 of the ~108 cycles per pair and lane), so frac cannot reach 1.
-                Jp = float((gp.last_screen or {}).get("prefix", N))
-                lane_instr_per_cand = 19.0 * N + 41.0 * Jp
-                tli = lane_instr_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e12
-                kstar_roofline = dict(bound="valu", achieved=round(tli, 2), peak=VALU_F64_PEAK_TLANE,
-                                      unit="T lane-instructions/s (fp64 VALU)", frac=round(tli / VALU_F64_PEAK_TLANE, 4),
-                                      kernel="kstar_mu_mfma_kernel + kstar_mu_kernel on the stored rows",
-                                      launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
-                                      lane_instructions_per_candidate=lane_instr_per_cand,
-                                      note="static instruction counts per pair (ISA of the two kernels); the 2 fp64 MFMAs per 256 "
-                                           "pairs of the first kernel occupy the SIMD for 32 of ~108 cycles per pair and lane and "
-                                           "do not overlap with fp64 VALU on gfx950")
-            else:
-                gbs = bytes_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e9
-                kstar_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                                      frac=round(gbs / HBM_PEAK_GBS, 4),
-                                      kernel={"f32": "kstar_mu_kernel<..., float>", "i8": "kstar_slices_kernel<..., 5>",
-                                              "i8c": "kstar_slices_kernel<..., 3>"}.get(args.dtype, "kstar_mu_kernel"),
-                                      launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
-                                      bytes_per_candidate=bytes_per_cand)
-                # the other resource this kernel loads: vector issue.  SQ_INSTS_VALU of the committed PMC pass of this shape
-                # (a static property of the kernel and the shape, replayed like roofline.traffic), over THIS run's launch time
-                try:
-                    shapes = json.load(open(os.path.join(REPO, "profiles", "pmc_sigma_acq.json")))
-                    key = f"N={N},d={d},dtype={args.dtype},candidates_per_launch={int(ks_cands / ks_launches)}"
-                    wi = shapes.get(key, {}).get("kstar_valu_wave_instructions_per_launch")
-                    if wi:
-                        tli = wi * 64.0 / (ks_avg * 1e-3) / 1e12
-                        kstar_roofline["valu"] = dict(
-                            lane_instructions_per_s_T=round(tli, 2), fp64_issue_peak_T=VALU_F64_PEAK_TLANE,
-                            frac=round(tli / VALU_F64_PEAK_TLANE, 4), wave_instructions_per_launch=wi,
-                            source=f"SQ_INSTS_VALU of the committed PMC pass {shapes[key]['source']}, not this run",
-                            note="the kernel issues vector instructions at this share of the measured fp64 issue ceiling WHILE "
-                                 "streaming its stores: two nearly saturated resources that do not overlap perfectly")
-                except Exception:  # noqa: BLE001
-                    pass
+        roofline, kstar_roofline, qei_roofline = kernel_rooflines(gp, N, d, args.dtype, qei, args.event_stride)
 
     # time of the scoring part alone (factorisation excluded), for the record
     fence()
@@ -375,9 +413,125 @@ def main():
     torch.cuda.synchronize(dev)
     ms_score = (time.perf_counter() - t1) / reps * 1e3
 
+    def timed_steps(fn, reps, g):
+        """1 untimed + `reps` timed calls of fn() (each ends with the read-back of the result record); the kernels of the
+        timed calls are bracketed with events in g's profile."""
+        g.profile_active = False
+        fn()
+        torch.cuda.synchronize(dev)
+        g.reset_profile()
+        g.profile_active = True
+        t = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / reps * 1e3, out
+
+    def fact_entry(g, A, b, n, reps=5):
+        """The once-per-step part of a (factorised) surrogate by itself, on the fp64 matrix-core roofline (2 n^3 / 3 flop)."""
+        for _ in range(2):
+            g.factorise(A, b, g.ls_h, check=False)
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(reps):
+            g.factorise(A, b, g.ls_h, check=False)
+        torch.cuda.synchronize(dev)
+        fms = (time.perf_counter() - t) / reps * 1e3
+        ftf = 2.0 * float(n) ** 3 / 3.0 / (fms * 1e-3) / 1e12
+        return dict(ms_per_call=fms, flop=2.0 * float(n) ** 3 / 3.0, achieved_tflops=round(ftf, 2), peak=FP64_MFMA_PEAK_TFLOPS,
+                    frac=round(ftf / FP64_MFMA_PEAK_TFLOPS, 4), steps=reps)
+
+    def also_config3():
+        """BASELINE configs[3], per-GPU shard: d=16, N=8192, 2^19 candidates, fp64 factorisation + fp32 variance screen +
+        fp64 decision (--dtype f32 --d 16 --n-obs 8192 --m-per-gpu 524288 times it as the main workload)."""
+        n3, d3, m3 = 8192, 16, 1 << 19
+        ls3 = ard_length_scales(d3)
+        X3 = sobol_points(0, n3, d3)
+        y3 = rff_objective(X3, ls3)
+        g3 = DeviceGP(dev)
+        g3.enable_profile(256)
+        A3, b3, P3 = g3._dev(X3), g3._dev(y3), g3._dev(sobol_points(n3, m3, d3))
+
+        def one():
+            g3.factorise(A3, b3, ls3, check=False)
+            g3.prepare_f32()
+            g3.score_async_f32(P3, acquisition="lcb", explore=4.0)
+            return D.allreduce_status(g3.status)
+
+        ms, (v, i, n, info) = timed_steps(one, 3, g3)
+        rf, krf, _ = kernel_rooflines(g3, n3, d3, "f32")
+        scr = dict(g3.last_screen)
+        r64 = g3.score(P3[:1 << 15], acquisition="lcb", explore=4.0)      # the fp64 kernels on a slice that ...
+        rs = g3.score_f32(P3[:1 << 15], acquisition="lcb", explore=4.0)   # ... the screened route must agree with
+        fz = fact_entry(g3, A3, b3, n3)
+        del g3, A3, b3, P3
+        torch.cuda.empty_cache()
+        return dict(workload="configs[3] (per-GPU shard): d=16, N=8192, M=2^19, fp64 factorisation + fp32 variance screen + "
+                             "fp64 re-score of the survivors, LCB(explore=4)", value=m3 / (ms * 1e-3), unit="candidates/s",
+                    ms_per_step=ms, steps=3, dtype="f32", argmax_index=i, nan_count=n, screen=scr,
+                    slice_argmax_matches_fp64=bool(r64.best_idx == rs.best_idx), roofline=rf, kstar_roofline=krf,
+                    factorisation=fz)
+
+    def also_config4():
+        """BASELINE configs[4], per-GPU shard: q=8 Monte-Carlo qEI (512 fixed base samples), d=8, N=2048, 2^20 candidates
+        (--acq qei --n-obs 2048 --m-per-gpu 1048576 times it as the main workload)."""
+        n4, m4 = 2048, 1 << 20
+        X4 = sobol_points(0, n4, d)
+        y4 = rff_objective(X4, ls)
+        g4 = DeviceGP(dev)
+        g4.enable_profile(256)
+        A4, b4, P4 = g4._dev(X4), g4._dev(y4), g4._dev(sobol_points(n4, m4, d))
+        Z4 = g4._dev(np.random.default_rng(7).standard_normal((512, 8)))
+        fb4 = float(np.min(y4))
+
+        def one():
+            g4.factorise(A4, b4, ls, check=False)
+            g4.score_qei_async(P4, Z4, f_best=fb4, xi=0.0)
+            return D.allreduce_status(g4.status)
+
+        ms, (v, i, n, info) = timed_steps(one, 3, g4)
+        rf, krf, qrf = kernel_rooflines(g4, n4, d, "f64", qei=True)
+        fz = fact_entry(g4, A4, b4, n4)
+        del g4, A4, b4, P4
+        torch.cuda.empty_cache()
+        return dict(workload="configs[4] (per-GPU shard): q=8 Monte-Carlo qEI, 512 fixed base samples, d=8, N=2048, M=2^20 "
+                             "(2^17 batches), fp64", value=m4 / (ms * 1e-3), unit="candidates/s", ms_per_step=ms, steps=3,
+                    dtype="f64", argmax_batch=i, nan_count=n, qei_value=v, roofline=rf, kstar_roofline=krf, qei_roofline=qrf,
+                    factorisation=fz)
+
+    def also_full_m():
+        """All 2^24 candidates of configs[2] in ONE call on one GPU (what 8 ranks share out): per-candidate rate, index
+        width, workspace and the 128 chunk launches at the full count.  Shard r of the candidate set = this run's 2^21
+        Sobol points shifted by r x the golden-ratio vector, mod 1 (a Cranley-Patterson rotation: generating 2^24 Sobol
+        points on the host would take longer than the run); shard 0 is the headline run's own candidate set."""
+        shards = 8
+        shift = np.modf(np.outer(np.arange(shards), np.modf((np.arange(1, d + 1) * 0.6180339887498949))[0]))[0]
+        Xall = torch.cat([torch.remainder(Xsd + gp._dev(shift[r])[None, :], 1.0) for r in range(shards)], 0)
+        mloc = Xsd.shape[0]
+        gp.factorise(Xd, yd, ls, check=False)
+        per = [gp.score(Xall[r * mloc:(r + 1) * mloc], idx_offset=r * mloc, **acq_kw) for r in range(shards)]
+        vb, ib = max(((r.best_val, -r.best_idx) for r in per))
+        gp.profile_active = False
+        gp.score_async(Xall, idx_offset=0, **acq_kw)        # untimed warm-up (workspace of the full count)
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        gp.factorise(Xd, yd, ls, check=False)
+        gp.score_async(Xall, idx_offset=0, **acq_kw)
+        v, i, n, info = D.allreduce_status(gp.status)
+        ms = (time.perf_counter() - t) * 1e3
+        gp.profile_active = True
+        mall = int(Xall.shape[0])
+        del Xall
+        torch.cuda.empty_cache()
+        return dict(workload=f"d={d}, N={N}, M=2^24 candidates in one call on one GPU, fp64, {args.acq.upper()}",
+                    value=mall / (ms * 1e-3), unit="candidates/s", ms_per_step=ms, steps=1, candidates=mall,
+                    argmax_index=i, nan_count=n, equals_reduction_of_8_shard_calls=bool(i == -ib and v == vb),
+                    shard0_is_the_headline_run=bool(per[0].best_idx == best[1] - lo),
+                    per_candidate_rate_vs_headline=round((mall / (ms * 1e-3)) / value, 4))
+
     def also():
-        """Two more numbers from the same build on the same box (N=1 only): BASELINE configs[1] and EI on the
-        default workload - a few steps each, outside the timed region above."""
+        """More numbers from the same build on the same box (N=1 only): every BASELINE config with its own roofline, EI
+        and the screened / bounded routes on the default workload - a few steps each, outside the timed region above."""
         res = {}
         reps2 = 3
         if args.acq == "lcb" and args.dtype == "f64":
@@ -532,6 +686,10 @@ def main():
             ms = (time.perf_counter() - t) / 20 * 1e3
             res["configs[1]"] = dict(workload="d=8, N=512, M=2^20, fp64, LCB(explore=4)", value=m2 / (ms * 1e-3),
                                      unit="candidates/s", ms_per_step=ms, argmax_index=i, steps=20)
+        if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb"):
+            res["configs[3]"] = also_config3()
+            res["configs[4]"] = also_config4()
+            res["configs[2]_all_2^24_candidates_on_one_gpu"] = also_full_m()
         if not qei:
             # the once-per-step part by itself: K(X,X) + fused Cholesky / inverse factor + alpha (gpbo_factorise_f64), on the
             # matrix-core roofline that bounds it (2 N^3 / 3 flop: Cholesky + triangular inverse)
@@ -576,7 +734,13 @@ def main():
             "ms_per_step_scoring_only": ms_score,
             "value_excl_factorisation": (hi - lo) * world / (ms_score * 1e-3),
             "argmax_index": best[1], "roofline": roofline, "kstar_roofline": kstar_roofline,
+            # one entry per rank (len = ranks_seen): the slowest one is ms_per_step
+            "ms_per_step_by_rank": {"min": min(per_rank_ms), "max": max(per_rank_ms), "ranks": len(per_rank_ms)},
+            "multi_gpu_note": ("value is measured on the ranks of THIS run only (n_gpus / ranks_seen); any 8-GPU figure quoted "
+                               "elsewhere for a 1-GPU run is that number times 8 - an extrapolation, not a measurement"),
         }
+        if qei_roofline is not None:
+            out["qei_roofline"] = qei_roofline
         if world == 1 and not args.no_cpu_baseline and not qei:
             cb, idx_cpu, ns = cpu_baseline(X, y, Xs_local, ls, args.acq, args.cpu_seconds, args.cpu_sample, f_best,
                                            "f32" if f32 else "f64", winner=best[1] - lo)

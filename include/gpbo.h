@@ -61,6 +61,8 @@ typedef struct gpbo_profile {
     int64_t *cands;        /* candidates processed by each recorded launch */
     void **kbegin;         /* hipEvent_t before the K(X*,X) launch of the slot (used when kmode == 1) */
     int32_t *kmode;        /* K(X*,X) launch of the slot: 0 not timed, 1 kbegin[i]..begin[i], 2 end[i-1]..begin[i] */
+    void **qend;           /* gpbo_posterior_qei_f64: hipEvent_t after the qEI launch of the slot (end[i]..qend[i]) */
+    int32_t *qmode;        /* 1: the slot has a qEI interval */
 } gpbo_profile;
 int gpbo_profile_create(int32_t capacity, gpbo_profile **out);
 void gpbo_profile_reset(gpbo_profile *p);
@@ -68,6 +70,8 @@ void gpbo_profile_reset(gpbo_profile *p);
 int gpbo_profile_read(gpbo_profile *p, double *total_ms_host, int64_t *launches_host, int64_t *cands_host);
 /* Same for the K(X*,X) launches (fp64 path). */
 int gpbo_profile_read_kstar(gpbo_profile *p, double *total_ms_host, int64_t *launches_host, int64_t *cands_host);
+/* Same for the qEI launches (gpbo_posterior_qei_f64 with a profile). */
+int gpbo_profile_read_qei(gpbo_profile *p, double *total_ms_host, int64_t *launches_host, int64_t *cands_host);
 void gpbo_profile_destroy(gpbo_profile *p);
 
 int gpbo_version(void);
@@ -179,7 +183,8 @@ int64_t gpbo_qei_workspace_bytes(int64_t Np, int64_t chunk, int64_t M);
 int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
                            const double *ls_host, const double *U, const double *alpha, double prior_var, double f_best,
                            double xi, const double *Z, int32_t S, int64_t batch_offset, int64_t chunk, double *qei_out,
-                           gpbo_result *result, void *work, int64_t work_bytes, void *stream);
+                           gpbo_result *result, void *work, int64_t work_bytes, gpbo_profile *prof /* or NULL */,
+                           void *stream);
 
 /* fp32-screened scoring (BASELINE config 4).  The factorisation stays fp64; U is rounded to fp32 once per step
  * (gpbo_prepare_f32, re-padded to Np32 = gpbo_padded_n_f32(N), a multiple of 256; alpha32 may be NULL).

@@ -14,6 +14,9 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_hash import kernel_source_hash  # noqa: E402
+
 src, out = sys.argv[1], sys.argv[2]
 N, d, dtype, cands = 4096, 8, "f64", 131072
 if len(sys.argv) > 4:
@@ -65,6 +68,9 @@ shapes[f"N={N},d={d},dtype={dtype},candidates_per_launch={cands}"] = {
     "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
     "candidates_per_launch": cands,
     "algorithmic_bytes_per_launch": cands * w * (N + 5),  # K*^T slab once + mu partial slices read + outputs
+    # the kernel sources these counters were collected on (profiles/source_hash.py): bench.py flags the replay as stale
+    # when today's sources differ
+    "kernel_source_hash": kernel_source_hash(dtype),
 }
 ks = agg.get({"i8": "kstar_slices_kernel", "i8c": "kstar_slices_kernel"}.get(dtype, "kstar_mu_kernel"), {})
 if "SQ_INSTS_VALU" in ks:

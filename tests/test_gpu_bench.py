@@ -24,6 +24,8 @@ def test_two_self_launched_ranks_pick_the_point_one_rank_picks_over_the_same_can
     two = _bench("--gpus", "2", "--backend", "gloo", "--all-on-device", "0", "--m-per-gpu", "65536", *common)
     one = _bench("--gpus", "1", "--m-per-gpu", "131072", *common)
     assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and one["n_gpus"] == 1
+    assert two["ms_per_step_by_rank"]["ranks"] == 2 and two["ms_per_step_by_rank"]["max"] == two["ms_per_step"]
+    assert two["ms_per_step_by_rank"]["min"] <= two["ms_per_step_by_rank"]["max"]
     assert two["config"]["candidates_total"] == one["config"]["candidates_total"] == 131072
     assert two["argmax_index"] == one["argmax_index"]
     assert two["roofline"]["frac"] > 0 and one["roofline"]["frac"] > 0
@@ -59,6 +61,22 @@ def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
     assert all(v["same_point_as_plain_pass"] for v in pb["survivors_by_acquisition"].values())
     pe = line["also"]["prefix_bound_screen_ei_same_workload"]
     assert pe["argmax_matches_fp64"] is True and not pe["screen"]["fallback"] and pe["value"] > 0
+    # every BASELINE config under the same clock, each with the roofline of its own dominant kernel
+    c3 = line["also"]["configs[3]"]
+    assert "N=8192" in c3["workload"] and c3["dtype"] == "f32" and c3["nan_count"] == 0 and c3["slice_argmax_matches_fp64"]
+    assert c3["roofline"]["kernel"] == "sigma_acq_f32_kernel" and c3["roofline"]["peak"] == 157.3 and 0.3 < c3["roofline"]["frac"] <= 1.0
+    assert not c3["screen"]["fallback"] and 0.0 < c3["factorisation"]["frac"] <= 1.0 and c3["kstar_roofline"]["bound"] == "hbm"
+    c4 = line["also"]["configs[4]"]
+    assert "qEI" in c4["workload"] and c4["nan_count"] == 0 and 0 <= c4["argmax_batch"] < (1 << 17)
+    assert c4["roofline"]["kernel"] == "sigma_acq_kernel" and 0.3 < c4["roofline"]["frac"] <= 1.0
+    q = c4["qei_roofline"]
+    assert q["bound"] == "hbm" and q["kernel"] == "qei_kernel" and q["bytes_per_candidate"] == 8.0 * 2048 and 0.0 < q["frac"] <= 1.0
+    assert q["launches"] == c4["roofline"]["launches"] == 3 * 8   # 3 timed steps x 8 chunks of 2^17
+    fm = line["also"]["configs[2]_all_2^24_candidates_on_one_gpu"]
+    assert fm["candidates"] == 1 << 24 and fm["equals_reduction_of_8_shard_calls"] is True and fm["nan_count"] == 0
+    assert fm["shard0_is_the_headline_run"] is True and 0.8 < fm["per_candidate_rate_vs_headline"] < 1.25
+    assert line["ms_per_step_by_rank"]["ranks"] == 1 and line["roofline"]["traffic_stale"] in (False, True, None)
+    assert "extrapolation" in line["multi_gpu_note"]
 
 
 @pytest.mark.gpu
@@ -88,3 +106,14 @@ def test_prefix_bound_screen_as_the_main_workload():
     assert line["screen"]["mode"] == "bound" and not line["screen"]["fallback"]
     kr = line["kstar_roofline"]   # the K(X*,X) interval of this route is bound by fp64 VALU issue, not by HBM
     assert kr["bound"] == "valu" and kr["peak"] == 33.0 and 0.05 < kr["frac"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_qei_as_the_main_workload_has_its_rooflines():
+    """the qEI line used to switch the kernel events off.  Now the variance launch, the K(X*,X) build and the
+    qEI stage are bracketed, each on the roofline that bounds it."""
+    line = _bench("--acq", "qei", "--n-obs", "512", "--m-per-gpu", "131072", "--steps", "2", "--warmup", "1", "--no-also")
+    assert line["roofline"]["kernel"] == "sigma_acq_kernel" and 0.05 < line["roofline"]["frac"] <= 1.0
+    assert line["qei_roofline"]["bound"] == "hbm" and 0.0 < line["qei_roofline"]["frac"] <= 1.0
+    assert line["qei_roofline"]["launches"] == line["roofline"]["launches"] == 2
+    assert line["kstar_roofline"]["bound"] == "hbm" and line["kstar_roofline"]["launches"] == 2
