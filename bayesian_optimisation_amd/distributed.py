@@ -89,11 +89,23 @@ def allreduce_status(status, group=None, force_collective: bool = False):
     return parse(out.cpu().view(world, 5).tolist())
 
 
+def _collective_device(group=None):
+    """Where a tensor must live to travel through `group`: the current GPU on nccl (= RCCL), the host on gloo."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def gather_concat(local, total: int, group=None):
-    """Concatenation, in rank order, of the contiguous shards produced under shard_bounds (dense mu / sigma /
-    acquisition arrays, the ARD likelihood grid).  Every rank gets the full array; bytes travel unchanged.
-    A no-op outside a process group."""
+    """Concatenation, in rank order, of the contiguous shards produced under shard_bounds (the ARD likelihood grid: float32
+    cells, sharded along axis 0).  Every rank gets the full host array; bytes travel unchanged, as ONE tensor collective
+    (all_gather_into_tensor of a padded block per rank: device memory on RCCL, no pickling, no second collective for sizes -
+    every rank knows every shard's length from shard_bounds and checks it).  A no-op outside a process group."""
     import numpy as np
+    import torch
     import torch.distributed as dist
 
     local = np.ascontiguousarray(local)
@@ -101,12 +113,28 @@ def gather_concat(local, total: int, group=None):
         if local.shape[0] != total:
             raise ValueError("gather_concat: shard does not cover the whole array")
         return local
-    parts = [None] * dist.get_world_size(group)
-    dist.all_gather_object(parts, local, group=group)
-    out = np.concatenate(parts)
-    if out.shape[0] != total:
-        raise ValueError(f"gather_concat: shards add up to {out.shape[0]} rows, expected {total}")
-    return out
+    world = dist.get_world_size(group)
+    row = int(np.prod(local.shape[1:], dtype=np.int64)) * local.itemsize   # bytes per row
+    pad = -(-total // world) * row                                        # the longest shard, in bytes
+    # The block of a rank: its row count (8 bytes), then its rows as raw bytes - any dtype travels unchanged, and a rank
+    # whose shard is not the one shard_bounds assigns is seen by EVERY rank after the collective (all raise together; a
+    # rank that raised before it would leave the others waiting inside it).
+    mine = np.zeros(8 + pad, dtype=np.uint8)
+    mine[:8] = np.frombuffer(np.int64(local.shape[0]).tobytes(), dtype=np.uint8)
+    raw = local.reshape(-1).view(np.uint8)[:pad]
+    mine[8: 8 + raw.size] = raw
+    dev = _collective_device(group)
+    flat = torch.empty(world * (8 + pad), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(flat, torch.from_numpy(mine).to(dev), group=group)
+    flat = flat.cpu().numpy().reshape(world, 8 + pad)
+    parts = []
+    for r in range(world):
+        a, b = shard_bounds(total, world, r)
+        rows = int(flat[r, :8].copy().view(np.int64)[0])
+        if rows != b - a:
+            raise ValueError(f"gather_concat: rank {r} holds {rows} rows, shard_bounds gives {b - a} of {total}")
+        parts.append(flat[r, 8: 8 + (b - a) * row])
+    return np.concatenate(parts).view(local.dtype).reshape((total,) + local.shape[1:])
 
 
 def gather_concat_tensors(locals_, total: int, group=None):
@@ -115,7 +143,7 @@ def gather_concat_tensors(locals_, total: int, group=None):
     k one-dimensional tensors of this rank's shard (same length, same dtype, the shard shard_bounds gives this rank);
     they travel as one [k x padded] block per rank through all_gather_into_tensor (RCCL on nccl: device memory to
     device memory; gloo: CPU tensors) and every rank gets k tensors of `total` rows, bytes unchanged.  Round 2 pickled
-    the host copies through all_gather_object: 3 x 134 MB per call at BASELINE config 3's M = 2^24."""
+    the host copies through the object collective: 3 x 134 MB per call at BASELINE config 3's M = 2^24."""
     import torch
     import torch.distributed as dist
 
@@ -154,11 +182,12 @@ def gather_concat_tensors(locals_, total: int, group=None):
 def all_agree(flag: bool, group=None) -> bool:
     """True iff `flag` is true on EVERY rank (a collective decision: e.g. append-or-refactorise must be taken the same
     way everywhere, or the ranks' factors differ at rounding level and the lowest-index tie rule no longer holds).
-    Outside a process group: the flag itself."""
+    One int32 all_reduce(MIN).  Outside a process group: the flag itself."""
+    import torch
     import torch.distributed as dist
 
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return bool(flag)
-    votes = [None] * dist.get_world_size(group)
-    dist.all_gather_object(votes, bool(flag), group=group)
-    return all(votes)
+    vote = torch.tensor([1 if flag else 0], dtype=torch.int32, device=_collective_device(group))
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(vote.item()))

@@ -155,3 +155,103 @@ def test_bench_starts_its_own_ranks_when_asked_for_more_than_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--rendezvous-only"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+# ---- eight ranks (what the driver's scaling run uses) on CPU: gloo, one process per rank ------------------------------------
+
+def _worker8(rank, world, port, q):
+    import struct
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # an UNEVEN candidate count: the first M % 8 ranks hold one row more than the others
+        M = 8 * 1250 + 5
+        lo, hi = D.shard_bounds(M, world, rank)
+        acq = np.sin(np.arange(M) * 0.0137) * 3.0
+        acq[[1300, 4000, 9990]] = 7.25      # the same maximum on ranks 1, 3 and 7: index 1300 must win on every rank
+        loc = acq[lo:hi]
+        j = int(np.flatnonzero(loc == loc.max())[0])
+        tie = D.allreduce_argmax(float(loc[j]), lo + j, 0)
+        # one rank saw NaN candidates: the count reaches everybody (the caller raises IndexError, point_selector.py:207),
+        # and a rank whose best VALUE is NaN never wins
+        nan = D.allreduce_argmax(float("nan") if rank == 5 else float(loc[j]), lo + j, 3 if rank == 5 else 0)
+        # the device-record form with a failed factorisation on one rank
+        bits = struct.unpack("<q", struct.pack("<d", float(loc[j])))[0]
+        st = D.allreduce_status(torch.tensor([bits, lo + j, 0, 0, 0 if rank != 6 else 4097], dtype=torch.int64))
+        # the ARD grid (float32, uneven shards of a 50 x 50 grid and of a 20-cell axis) and a two-dimensional block
+        grid = (np.arange(2500, dtype=np.float32) * np.float32(0.37)) ** 2
+        glo, ghi = D.shard_bounds(2500, world, rank)
+        g = D.gather_concat(grid[glo:ghi], 2500)
+        a20 = np.linspace(-3, 3, 20).astype(np.float32)
+        alo, ahi = D.shard_bounds(20, world, rank)
+        g20 = D.gather_concat(a20[alo:ahi], 20)
+        blk = np.arange(M * 3, dtype=np.float64).reshape(M, 3)
+        gb = D.gather_concat(blk[lo:hi], M)
+        ok = (g.dtype == np.float32 and np.array_equal(g, grid) and g20.dtype == np.float32 and np.array_equal(g20, a20)
+              and gb.shape == (M, 3) and np.array_equal(gb, blk))
+        try:
+            D.gather_concat(grid[glo:ghi][:-1], 2500)   # a shard that is not the one shard_bounds assigns: refused
+            ok = False
+        except ValueError:
+            pass
+        # dense outputs: one collective for three tensors, uneven shards
+        t3 = [torch.from_numpy(np.cos(np.arange(M) * c)[lo:hi].copy()) for c in (0.11, 0.23, 0.31)]
+        g3 = D.gather_concat_tensors(t3, M)
+        ok = ok and all(torch.equal(x, torch.from_numpy(np.cos(np.arange(M) * c))) for x, c in zip(g3, (0.11, 0.23, 0.31)))
+        # the vote (append or refactorise?): true only when EVERY rank says so
+        votes = (D.all_agree(True), D.all_agree(rank != 2), D.all_agree(False))
+        q.put((rank, tie, nan, st, ok, votes, (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_process_gloo_exchange_uneven_shards_cross_rank_tie_and_a_nan_rank():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(8))
+    sizes = sorted(hi - lo for *_, (lo, hi) in res)
+    assert sizes == [1250] * 3 + [1251] * 5
+    for rank, tie, nan, st, ok, votes, _ in res:
+        assert ok, rank
+        assert tie == (7.25, 1300, 0)
+        assert nan == (7.25, 1300, 3)          # rank 5's NaN value is skipped, its NaN count is not
+        assert st == (7.25, 1300, 0, 4097)
+        assert votes == (True, False, False)
+
+
+def test_no_pickling_collective_is_left_on_the_multi_gpu_path():
+    src = open(os.path.join(os.path.dirname(D.__file__), "distributed.py")).read()
+    assert "all_gather_object" not in src and "broadcast_object" not in src and "gather_object" not in src
+
+
+def test_bench_launcher_with_eight_ranks():
+    """`python bench.py --gpus 8` as the driver's scaling run calls it (no rendezvous in the environment): eight ranks join
+    (gloo, --rendezvous-only: no GPU needed) and rank 0 reports them."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8", "--rendezvous-only"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8
