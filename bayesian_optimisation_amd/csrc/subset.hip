@@ -24,28 +24,46 @@ struct FpsLs {
     double isc[GPBO_MAX_D];  // 1 / ls_k
 };
 
-__device__ __forceinline__ void block_argmax(double &v, int64_t &i, double *s_val, int64_t *s_idx) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// Reductions of a selection step with DPP row operations instead of ds_bpermute shuffles.  A step is issue-bound (sixteen
+// waves share four SIMDs: every instruction of the step costs ~6 cycles x 4 waves), so the arg-max is taken in two cheap
+// phases - the largest VALUE (two DPP moves + v_max_f64 per stage), then the lowest INDEX among the lanes that hold it
+// (one DPP move + v_min_i32 per stage) - instead of one (value, index) compare-and-select chain per stage.
+__device__ __forceinline__ bool fps_better(double v2, int i2, double v, int i) { return (v2 > v) || (v2 == v && i2 < i); }
+template <int CTRL>
+__device__ __forceinline__ double fps_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// every lane of a ROW of 16 gets the row's result: xor 1, xor 2 (quad_perm), then the half-row and row mirrors
+__device__ __forceinline__ double fps_row_max(double v) {
+    v = fmax(v, fps_dpp_f64<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmax(v, fps_dpp_f64<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmax(v, fps_dpp_f64<0x141>(v));   // row_half_mirror
+    v = fmax(v, fps_dpp_f64<0x140>(v));   // row_mirror
+    return v;
+}
+__device__ __forceinline__ int fps_row_min(int i) {
+    i = min(i, __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, true));
+    i = min(i, __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, true));
+    i = min(i, __builtin_amdgcn_update_dpp(0, i, 0x141, 0xf, 0xf, true));
+    i = min(i, __builtin_amdgcn_update_dpp(0, i, 0x140, 0xf, 0xf, true));
+    return i;
+}
+// ... and every lane of the wave the wave's result: the four row results through scalar registers
+__device__ __forceinline__ double fps_wave_max(double v) {
+    v = fps_row_max(v);
+    double r = v;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double ov = __shfl_xor(v, off);
-        const int64_t oi = __shfl_xor(i, off);
-        if (gpbo_better(ov, oi, v, i)) { v = ov; i = oi; }
-    }
-    if (lane == 0) { s_val[w] = v; s_idx[w] = i; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double bv = s_val[0];
-        int64_t bi = s_idx[0];
-        for (int q = 1; q < FT / 64; ++q)
-            if (gpbo_better(s_val[q], s_idx[q], bv, bi)) { bv = s_val[q]; bi = s_idx[q]; }
-        s_val[0] = bv;
-        s_idx[0] = bi;
-    }
-    __syncthreads();
-    v = s_val[0];
-    i = s_idx[0];
-    __syncthreads();
+    for (int q = 1; q < 4; ++q)
+        r = fmax(r, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * q),
+                                     __builtin_amdgcn_readlane(__double2loint(v), 16 * q)));
+    return fmax(r, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0)));
+}
+__device__ __forceinline__ int fps_wave_min(int i) {
+    i = fps_row_min(i);
+    return min(min(__builtin_amdgcn_readlane(i, 0), __builtin_amdgcn_readlane(i, 16)),
+               min(__builtin_amdgcn_readlane(i, 32), __builtin_amdgcn_readlane(i, 48)));
 }
 
 // extension to J2 members: unchosen observations (mind > -inf) in index order; thread t of the FT owns a contiguous range
@@ -75,105 +93,205 @@ __device__ __forceinline__ void fps_extend(int64_t N, int64_t J, int64_t J2, con
     }
 }
 
-// perm[0 .. J) = farthest-point sequence; perm[J .. J2) = the first J2 - J observations not among them, in index order.
-// One workgroup.  PTS > 0: every thread keeps its PTS observations (scaled coordinates) and their distances to the
-// member set in registers (N <= 1024 PTS) - a selection step is then d fmas per point and one block arg-max, ~1 us;
-// PTS == 0: any N, coordinates re-read and distances kept in `mind` (global) every step.
-template <int PTS, int D>
-__global__ __launch_bounds__(FT) void fps_kernel(const double *__restrict__ X, int64_t N, int d_rt, FpsLs ls, int64_t J, int64_t J2,
-                                                 double *__restrict__ mind, int64_t *__restrict__ perm) {
+// ---- the selection with every observation in a REGISTER: one workgroup, or G workgroups that exchange one record per member ----
+// Thread t of workgroup w keeps PTS observations (scaled coordinates, running minimum distance to the members) in registers:
+// a selection step is D fmas per point, a wave reduction, one pass through LDS - and, with G > 1, ONE hand-off through
+// memory: every workgroup publishes its best point (value, index AND coordinates) in its slot, every workgroup reads all G
+// slots and picks the winner itself (all-to-all: no second hop to broadcast the result, no global load of the winner's
+// coordinates).  Same arithmetic and tie rule as the one-launch-per-member form below (distance = fma chain over the
+// coordinates in index order; largest value, lowest index), hence the same sequence.
+//
+// The hand-off needs no fence: a record is 3 + 2 D WORDS of 64 bits, each a relaxed device-scope atomic that carries 32
+// bits of payload AND the step's stamp (step + 1) - (value lo | stamp), (value hi | stamp), (index | stamp), then the
+// halves of the coordinates.  A reader accepts a record when EVERY word shows the stamp it waits for: each word validates
+// itself, so no ordering between words is assumed (no reliance on cache policy, no racy plain accesses),
+// and no release fence - which on this chip writes the L2's dirty lines back, ~0.5 us per step - is paid.  The record is
+// written by the winner's wave (lane w stores word w: one coalesced store) and read by wave 0 of every workgroup (lane w
+// loads word w of all G slots: G coalesced loads per poll), so a hand-off is one store and one load on the wire.
+// The workgroups that exchange are blockIdx.x = 0, 8, 16, ... of a grid of 8 G: under the round-robin dispatch they sit on
+// ONE XCD (speed only; any placement is correct).  Two slot sets alternate by step parity: a workgroup
+// can only be one step ahead of the slowest (it needs everybody's step-s record to start step s + 1), so the set of
+// step s + 2 is never written while somebody still reads step s.  Every wait is BOUNDED: a workgroup that does not see a
+// stamp within FPS_MAX_POLLS polls raises stt->error and leaves; so do the others; the host-side fall-back (identity
+// order - the arrival order, still an exact route) is applied by fps_check_kernel.  Nothing can hang.
+struct FpsSlot {
+    unsigned long long w[64];   // 3 + 2 d <= 35 words used; 512 bytes: slots of different workgroups share no cache line
+};
+static_assert(sizeof(FpsSlot) == 512, "FpsSlot");
+constexpr int FPS_MAXW = 16;            // cooperating workgroups at most
+constexpr int FPS_MAX_POLLS = 1 << 21;  // ~1 s: a co-operating workgroup that was never scheduled
+
+struct FpsState {
+    int64_t member;        // newest member (one-launch-per-member form: read by the next launch)
+    unsigned int ticket;   // workgroups of the current launch that have finished
+    unsigned int error;    // cooperative form: a bounded wait ran out
+    double centre[GPBO_MAX_D];   // scaled coordinates the next sweep measures distances to (first: the centroid)
+};
+
+template <int PTS, int D, bool COOP>
+__global__ __launch_bounds__(FT) void fps_coop_kernel(const double *__restrict__ X, int64_t N, FpsLs ls, int64_t J, int G,
+                                                      FpsState *__restrict__ stt, FpsSlot *__restrict__ slots,
+                                                      double *__restrict__ mind, int64_t *__restrict__ perm) {
     __shared__ double s_val[FT / 64];
     __shared__ int64_t s_idx[FT / 64];
-    __shared__ double s_c[GPBO_MAX_D];
-    __shared__ long long s_scan[FT];
-    const int tid = threadIdx.x;
-    const int d = (PTS > 0) ? D : d_rt;
+    __shared__ double s_c[D];
+    __shared__ int64_t s_member;
+    __shared__ int s_dead;
+    if (COOP && (blockIdx.x & 7)) return;   // (see above: the workers are every eighth workgroup)
+    const int wg = COOP ? (int)(blockIdx.x >> 3) : 0;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const double ninf = -std::numeric_limits<double>::infinity();
-    constexpr int NP = PTS > 0 ? PTS : 1, ND = PTS > 0 ? D : 1;
-    double xr[NP][ND], md[NP];
-    if (PTS > 0) {
+    const int64_t base = (int64_t)wg * FT * PTS;
+    double xr[PTS][D], md[PTS];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int64_t i = tid + (int64_t)FT * q;
+    for (int q = 0; q < PTS; ++q) {
+        const int64_t i = base + (int64_t)q * FT + tid;
 #pragma unroll
-            for (int k = 0; k < ND; ++k) xr[q][k] = (i < N) ? X[i * D + k] * ls.isc[k] : 0.0;
-            md[q] = std::numeric_limits<double>::infinity();
-        }
+        for (int k = 0; k < D; ++k) xr[q][k] = (i < N) ? X[i * D + k] * ls.isc[k] : 0.0;
+        md[q] = (i < N) ? std::numeric_limits<double>::infinity() : ninf;   // rows beyond N are never chosen
     }
-    // centroid (fixed-order reduction: per-thread partial sums, then thread 0 over the 1024 partials of each coordinate)
-    for (int k = 0; k < d; ++k) {
-        double s = 0.0;
-        for (int64_t i = tid; i < N; i += FT) s += X[i * d + k] * ls.isc[k];
-        reinterpret_cast<double *>(s_scan)[tid] = s;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-            for (int q = 0; q < FT; ++q) t += reinterpret_cast<double *>(s_scan)[q];
-            s_c[k] = t / (double)N;
+    if (tid < D) s_c[tid] = stt->centre[tid];
+    if (tid == 0) { s_member = -1; s_dead = 0; }
+    __syncthreads();
+    for (int64_t s = 0; s <= J; ++s) {   // sweep s folds member s - 1 in (s = 0: distances to the centroid) and picks member s
+        const int64_t member = s_member;
+        double bv = ninf;
+        int bi32 = 0x7fffffff;   // (N <= 1024 PTS G <= 65,536 here: the index fits 32 bits)
+        int bq = 0;
+#pragma unroll
+        for (int q = 0; q < PTS; ++q) {
+            const int64_t i = base + (int64_t)q * FT + tid;
+            double dist = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double df = xr[q][k] - s_c[k];
+                dist = fma(df, df, dist);
+            }
+            double m = dist;
+            if (member >= 0) {
+                m = fmin(md[q], dist);
+                if (i == member) m = ninf;  // a member is never chosen again (its duplicates: distance 0, chosen last)
+                md[q] = m;
+            }
+            if (i < N && fps_better(m, (int)i, bv, bi32)) { bv = m; bi32 = (int)i; bq = q; }
         }
+        if (s == J) break;                  // the last sweep only marks member J - 1
+        const int mine_i = bi32;            // this thread's own best (to recognise itself as the owner of the winner)
+        // (comparisons never select a NaN distance and fmax drops it: same candidates either way)
+        const double wmax = fps_wave_max(bv);
+        if (lane == 0) s_val[w] = wmax;
         __syncthreads();
-    }
-    // distance of this thread's points to s_c, folded into their running minimum; returns the thread's best (value, index)
-    auto sweep = [&](int64_t member, double &bv, int64_t &bi) {
-        bv = ninf;
-        bi = std::numeric_limits<int64_t>::max();
-        if (PTS > 0) {
+        const double gmax = fps_row_max(s_val[lane & (FT / 64 - 1)]);   // 16 wave results, one per lane of every row of 16
+        const int cand = (bv == gmax) ? bi32 : 0x7fffffff;              // lowest index among the points that attain it
+        const int wmin = fps_wave_min(cand);
+        if (lane == 0) s_idx[w] = wmin;
+        __syncthreads();
+        bi32 = fps_row_min((int)s_idx[lane & (FT / 64 - 1)]);
+        bv = gmax;
+        const int64_t bi = bi32 == 0x7fffffff ? std::numeric_limits<int64_t>::max() : (int64_t)bi32;
+        // every thread now holds the workgroup's best (bv, bi); its owner has the coordinates in registers
+        const bool have = bi != std::numeric_limits<int64_t>::max();
+        const bool owner = have ? (mine_i == bi32) : (tid == 0);
+        if (!COOP) {
+            if (owner) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const int64_t i = tid + (int64_t)FT * q;
-                double dist = 0.0;
+                for (int q = 0; q < PTS; ++q)
+                    if (bq == q) {
 #pragma unroll
-                for (int k = 0; k < ND; ++k) {
-                    const double df = xr[q][k] - s_c[k];
-                    dist = fma(df, df, dist);
-                }
-                double m = (member < 0) ? dist : fmin(md[q], dist);
-                if (member >= 0) {
-                    if (i == member) m = ninf;  // a member is never chosen again (its duplicates: distance 0, chosen last)
-                    md[q] = m;
-                }
-                if (i < N && gpbo_better(m, i, bv, bi)) { bv = m; bi = i; }
+                        for (int k = 0; k < D; ++k) s_c[k] = xr[q][k];
+                    }
+                s_member = bi;
+                perm[s] = bi;
             }
         } else {
-            for (int64_t i = tid; i < N; i += FT) {
-                double dist = 0.0;
-                for (int k = 0; k < d; ++k) {
-                    const double df = X[i * d + k] * ls.isc[k] - s_c[k];
-                    dist = fma(df, df, dist);
+            FpsSlot *set = slots + (size_t)(s & 1) * FPS_MAXW;
+            constexpr int NWORD = 3 + 2 * D;
+            const unsigned long long stamp = (unsigned long long)(unsigned)(s + 1) << 32;
+            // the winner's wave publishes the record: the owner's registers reach the other lanes through scalar registers
+            const int oloc = have ? (int)(bi - base) : 0;         // (a workgroup without a valid point: thread 0, value -inf)
+            const int ow = (oloc % FT) >> 6, olane = oloc & 63, oq = oloc / FT;   // all uniform
+            if (w == ow) {
+                unsigned data = 0;
+                if (lane == 0) data = (unsigned)__double2loint(bv);
+                if (lane == 1) data = (unsigned)__double2hiint(bv);
+                if (lane == 2) data = (unsigned)bi32;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    double ck = xr[0][k];
+#pragma unroll
+                    for (int q = 1; q < PTS; ++q) ck = (oq == q) ? xr[q][k] : ck;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(__double2loint(ck), olane);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(__double2hiint(ck), olane);
+                    if (lane == 3 + 2 * k) data = lo;
+                    if (lane == 4 + 2 * k) data = hi;
                 }
-                double m = dist;
-                if (member >= 0) {
-                    m = fmin(mind[i], dist);
-                    if (i == member) m = ninf;
-                    mind[i] = m;
-                } else {
-                    mind[i] = std::numeric_limits<double>::infinity();
+                if (lane < NWORD)
+                    __hip_atomic_store(&set[wg].w[lane], stamp | data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (w == 0) {
+                // lane w polls word w of every slot; a poll = G loads in flight; done when every word carries this step's stamp
+                const int wl = lane < NWORD ? lane : 0;
+                unsigned r[FPS_MAXW];   // payload halves; the stamps are checked as the words arrive
+                int polls = 0;
+                bool timed_out = false;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int g = 0; g < FPS_MAXW; ++g) {
+                        const unsigned long long v = (g < G) ? __hip_atomic_load(&set[g].w[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : stamp;
+                        r[g] = (unsigned)v;
+                        ok = ok && ((v >> 32) == (stamp >> 32));
+                    }
+                    if (__all(ok)) break;
+                    if (++polls > FPS_MAX_POLLS) { timed_out = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                if (gpbo_better(m, i, bv, bi)) { bv = m; bi = i; }
+                // winner over the slots (uniform arithmetic on values read from lanes 0 .. 2), then its coordinates
+                double gv = ninf;
+                int gi = 0x7fffffff, gw = 0;
+#pragma unroll
+                for (int g = 0; g < FPS_MAXW; ++g) {
+                    if (g < G) {
+                        const int dlo = __builtin_amdgcn_readlane((int)r[g], 0);
+                        const int dhi = __builtin_amdgcn_readlane((int)r[g], 1);
+                        const int oi = __builtin_amdgcn_readlane((int)r[g], 2);
+                        const double ov = __hiloint2double(dhi, dlo);
+                        if (fps_better(ov, oi, gv, gi)) { gv = ov; gi = oi; gw = g; }
+                    }
+                }
+                unsigned sel = r[0];
+#pragma unroll
+                for (int g = 1; g < FPS_MAXW; ++g) sel = (gw == g) ? r[g] : sel;
+                if (lane >= 3 && lane < NWORD) reinterpret_cast<unsigned *>(s_c)[lane - 3] = sel;   // lo / hi halves in place
+                if (lane == 0) {
+                    s_member = gi == 0x7fffffff ? std::numeric_limits<int64_t>::max() : (int64_t)gi;
+                    if (wg == 0) perm[s] = (int64_t)gi;
+                    if (timed_out) {
+                        s_dead = 1;
+                        __hip_atomic_store(&stt->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
         }
-    };
-    double bv;
-    int64_t bi;
-    sweep(-1, bv, bi);  // first member: farthest from the centroid
-    block_argmax(bv, bi, s_val, s_idx);
-    for (int64_t j = 0; j < J; ++j) {
-        const int64_t p = bi;
-        if (tid == 0) perm[j] = p;
-        if (tid < d) s_c[tid] = X[p * d + tid] * ls.isc[tid];
         __syncthreads();
-        sweep(p, bv, bi);
-        block_argmax(bv, bi, s_val, s_idx);
+        if (s_dead) return;   // a bounded wait ran out: every workgroup leaves (fps_check_kernel repairs perm)
     }
-    if (PTS > 0) {  // the extension below reads the membership from `mind`
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int64_t i = tid + (int64_t)FT * q;
-            if (i < N) mind[i] = md[q];
-        }
-        __syncthreads();
+    for (int q = 0; q < PTS; ++q) {   // the extension to the full order reads the membership from `mind`
+        const int64_t i = base + (int64_t)q * FT + tid;
+        if (i < N) mind[i] = md[q];
     }
-    fps_extend(N, J, J2, mind, perm, s_scan);
+}
+
+// after the cooperative form: a bounded wait ran out (never seen) -> the identity order (arrival order: exact, prunes less)
+__global__ __launch_bounds__(FT) void fps_check_kernel(const FpsState *__restrict__ stt, int64_t N, int64_t J,
+                                                       double *__restrict__ mind, int64_t *__restrict__ perm) {
+    if (!stt->error) return;
+    const double ninf = -std::numeric_limits<double>::infinity();
+    for (int64_t i = (int64_t)blockIdx.x * FT + threadIdx.x; i < N; i += (int64_t)gridDim.x * FT) {
+        if (i < J) perm[i] = i;
+        mind[i] = (i < J) ? ninf : 0.0;   // members 0 .. J-1; fps_extend_kernel appends the others in index order
+    }
 }
 
 // ---- the same selection as ONE LAUNCH PER STEP, for sizes whose points do not fit one workgroup's registers --------------
@@ -183,30 +301,39 @@ __global__ __launch_bounds__(FT) void fps_kernel(const double *__restrict__ X, i
 // reduces the partials in workgroup order and publishes the next member.  Same arithmetic, same tie rule (lowest index),
 // hence the same sequence as fps_kernel; the cost is a kernel boundary per member (~2.5 us).
 constexpr int FG = 256;
-struct FpsState {
-    int64_t member;        // newest member (read by the next launch)
-    unsigned int ticket;   // workgroups of the current launch that have finished
-    unsigned int pad;
-    double centre[GPBO_MAX_D];   // scaled coordinates the next launch measures distances to
-};
 
+// centroid of the scaled observations, every coordinate in one pass: per-thread partial sums (rows tid, tid + 1024, ...), a
+// butterfly over the lanes of each wave, then thread k adds the sixteen wave sums of coordinate k in wave order - a fixed
+// order of additions, so the same centroid (and the same first member) every time.  (One coordinate after the other with a
+// serial sum of the 1,024 partials cost 8 us per coordinate: 130 us of a 1.9-ms order at d = 16.)
 __global__ __launch_bounds__(FT) void fps_centroid_kernel(const double *__restrict__ X, int64_t N, int d, FpsLs ls,
                                                           FpsState *__restrict__ stt) {
-    __shared__ double s_part[FT];
-    const int tid = threadIdx.x;
-    for (int k = 0; k < d; ++k) {   // the fixed-order reduction of fps_kernel
-        double s = 0.0;
-        for (int64_t i = tid; i < N; i += FT) s += X[i * d + k] * ls.isc[k];
-        s_part[tid] = s;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-            for (int q = 0; q < FT; ++q) t += s_part[q];
-            stt->centre[k] = t / (double)N;
-        }
-        __syncthreads();
+    __shared__ double s_w[FT / 64][GPBO_MAX_D];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double acc[GPBO_MAX_D];
+#pragma unroll
+    for (int k = 0; k < GPBO_MAX_D; ++k) acc[k] = 0.0;
+    for (int64_t i = tid; i < N; i += FT) {
+#pragma unroll
+        for (int k = 0; k < GPBO_MAX_D; ++k)
+            if (k < d) acc[k] += X[i * d + k] * ls.isc[k];
     }
-    if (tid == 0) { stt->member = -1; stt->ticket = 0; }
+#pragma unroll
+    for (int k = 0; k < GPBO_MAX_D; ++k) {
+        if (k < d) {   // (uniform)
+            double v = acc[k];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+            if (lane == 0) s_w[w][k] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < d) {
+        double t = 0.0;
+        for (int q = 0; q < FT / 64; ++q) t += s_w[q][tid];
+        stt->centre[tid] = t / (double)N;
+    }
+    if (tid == 0) { stt->member = -1; stt->ticket = 0; stt->error = 0; }
 }
 
 __global__ __launch_bounds__(FG) void fps_step_kernel(const double *__restrict__ X, int64_t N, int d, FpsLs ls,
@@ -251,17 +378,17 @@ __global__ __launch_bounds__(FG) void fps_step_kernel(const double *__restrict__
     if (tid == 0) {
         for (int q = 1; q < FG / 64; ++q)
             if (gpbo_better(s_val[q], s_idx[q], bv, bi)) { bv = s_val[q]; bi = s_idx[q]; }
-        // The partials travel as device-scope (sc1, write-through) atomic stores, acknowledged before the ticket is taken; the
-        // last workgroup reads them with device-scope atomic loads.  No __threadfence: a release at device scope writes the
-        // whole L2's dirty lines back (the running minima this launch has just stored - which only the NEXT launch reads,
-        // after the kernel boundary): two such fences were most of a 7-us step.
+        // The partials are published by a RELEASE on the ticket and read behind an ACQUIRE fence by the workgroup that takes
+        // the last one (a proper release / acquire edge instead of relying on the cache policy of sc1 stores).
+        // The release writes this XCD's dirty L2 lines back (the running minima just stored): ~1 us per launch, accepted -
+        // since round 4 this form only serves N > 32,768, everything smaller runs in fps_coop_kernel.
         __hip_atomic_store(pval + blockIdx.x, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(pidx + blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = (__hip_atomic_fetch_add(&stt->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+        s_last = (__hip_atomic_fetch_add(&stt->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
-    if (s_last) {  // every workgroup's partial has been acknowledged: reduce them (the order does not matter: largest value,
+    if (s_last) {  // every workgroup's partial has been released: reduce them (the order does not matter: largest value,
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         double v = ninf;   // lowest index among equals) and publish the next member
         int64_t p = std::numeric_limits<int64_t>::max();
         for (unsigned b = tid; b < gridDim.x; b += FG) {
@@ -306,7 +433,7 @@ __global__ void gather_obs_kernel(const double *__restrict__ X, int d, const int
 }
 
 struct OrderLayout {
-    int64_t mind_off, fps_off, total;
+    int64_t mind_off, fps_off, slot_off, total;
 };
 constexpr int FPS_MAXG = 256;  // workgroups of a selection step at most
 
@@ -316,6 +443,7 @@ OrderLayout order_layout(int64_t N) {
     auto take = [&](int64_t bytes) { const int64_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     L.mind_off = take((int64_t)sizeof(double) * N);
     L.fps_off = take((int64_t)sizeof(FpsState) + (int64_t)FPS_MAXG * (sizeof(double) + sizeof(int64_t)) + 256);
+    L.slot_off = take((int64_t)sizeof(FpsSlot) * 2 * FPS_MAXW);
     L.total = off;
     return L;
 }
@@ -351,24 +479,44 @@ extern "C" int gpbo_fps_order_f64(const double *X, const double *y, int64_t N, i
     hipStream_t st = gpbo_stream(stream);
     char *w = reinterpret_cast<char *>(work);
     double *mind = reinterpret_cast<double *>(w + L.mind_off);
-    // one workgroup with every thread's observations in registers while that is the faster form (measured at N = 8192 /
-    // 6000: 8 points per thread at d = 4 - 116 bytes of spills - 3.1 ms against 4.3 by launches; at d = 8 - 404 bytes -
-    // 6.9 against 4.4; at d = 6 2.5 against 2.2); beyond: one launch per member (fps_step_kernel)
-#define GPBO_FPS(P, DD) hipLaunchKernelGGL((fps_kernel<P, DD>), dim3(1), dim3(FT), 0, st, X, N, (int)d, ls, J, N, mind, perm_out)
-    const int64_t pts = (N + FT - 1) / FT;
+    FpsState *stt = reinterpret_cast<FpsState *>(w + L.fps_off);
+    // Every observation in a register of one of G <= 16 workgroups of 1024 threads (fps_coop_kernel): PTS points per thread,
+    // as many as fit 64 registers of coordinates (PTS x d <= 32), G = ceil(N / (1024 PTS)).  Beyond 16 workgroups
+    // (N > 65,536 at d <= 8, > 32,768 above): one launch per member (fps_step_kernel).
+    // One workgroup: up to 4 points per thread (2 above d = 8: 64 registers of coordinates).  A step of one workgroup is
+    // issue-bound - measured 1.2 / 1.4 / 1.9 us at 1 / 2 / 4 points per thread, d = 8 - and a hand-off between workgroups
+    // costs more than that, so several workgroups share the points only when one cannot hold them, and then as many as
+    // possible (1 point per thread up to N = 16,384, 2 up to 32,768).  Beyond: one launch per member (fps_step_kernel).
+    const int pmax1 = d <= 8 ? 4 : 2;
+    int pts = 1;
+    while (pts < pmax1 && (int64_t)FT * pts < N) pts *= 2;
+    const bool coop = (int64_t)FT * pts < N;
+    if (coop) pts = ((int64_t)FT * FPS_MAXW < N) ? 2 : 1;
+    const int64_t G = (N + (int64_t)FT * pts - 1) / ((int64_t)FT * pts);
     bool launched = false;
-#define GPBO_FPS_D(DD)                                                                   \
-    if (!launched && d == DD) {                                                          \
-        if (pts <= 1) { GPBO_FPS(1, DD); launched = true; }                              \
-        else if (pts <= 2) { GPBO_FPS(2, DD); launched = true; }                         \
-        else if (pts <= 4 && DD <= 8) { GPBO_FPS(4, DD); launched = true; }              \
-        else if (pts <= 8 && DD <= 4) { GPBO_FPS(8, DD); launched = true; }              \
+    if (G <= FPS_MAXW) {
+        FpsSlot *slots = reinterpret_cast<FpsSlot *>(w + L.slot_off);
+        if (coop && hipMemsetAsync(slots, 0, sizeof(FpsSlot) * 2 * FPS_MAXW, st) != hipSuccess) return GPBO_ERR_LAUNCH;
+        hipLaunchKernelGGL(fps_centroid_kernel, dim3(1), dim3(FT), 0, st, X, N, (int)d, ls, stt);
+        const unsigned grid = coop ? (unsigned)(8 * G) : 1u;
+#define GPBO_FPS(P, DD, CO) hipLaunchKernelGGL((fps_coop_kernel<P, DD, CO>), dim3(grid), dim3(FT), 0, st, X, N, ls, J, (int)G, stt, slots, mind, perm_out)
+#define GPBO_FPS_D(DD)                                                              \
+    if (!launched && d == DD) {                                                     \
+        if (coop) { if (pts == 1) GPBO_FPS(1, DD, true); else GPBO_FPS(2, DD, true); }  \
+        else if (pts == 1) GPBO_FPS(1, DD, false);                                  \
+        else if (pts == 2) GPBO_FPS(2, DD, false);                                  \
+        else GPBO_FPS((DD <= 8 ? 4 : 2), DD, false);                                \
+        launched = true;                                                            \
     }
-    GPBO_FPS_D(1) GPBO_FPS_D(2) GPBO_FPS_D(3) GPBO_FPS_D(4) GPBO_FPS_D(5) GPBO_FPS_D(6) GPBO_FPS_D(7) GPBO_FPS_D(8)
-    GPBO_FPS_D(9) GPBO_FPS_D(10) GPBO_FPS_D(11) GPBO_FPS_D(12) GPBO_FPS_D(13) GPBO_FPS_D(14) GPBO_FPS_D(15) GPBO_FPS_D(16)
+        GPBO_FPS_D(1) GPBO_FPS_D(2) GPBO_FPS_D(3) GPBO_FPS_D(4) GPBO_FPS_D(5) GPBO_FPS_D(6) GPBO_FPS_D(7) GPBO_FPS_D(8)
+        GPBO_FPS_D(9) GPBO_FPS_D(10) GPBO_FPS_D(11) GPBO_FPS_D(12) GPBO_FPS_D(13) GPBO_FPS_D(14) GPBO_FPS_D(15) GPBO_FPS_D(16)
+#undef GPBO_FPS_D
+#undef GPBO_FPS
+        if (coop) hipLaunchKernelGGL(fps_check_kernel, dim3(8), dim3(FT), 0, st, stt, N, J, mind, perm_out);
+        hipLaunchKernelGGL(fps_extend_kernel, dim3(1), dim3(FT), 0, st, N, J, N, mind, perm_out);
+    }
     if (!launched) {
         // one launch per member (the state block: FpsState, then the workgroups' partial values and indices)
-        FpsState *stt = reinterpret_cast<FpsState *>(w + L.fps_off);
         double *pval = reinterpret_cast<double *>(w + L.fps_off + ((sizeof(FpsState) + 255) / 256) * 256);
         int64_t *pidx = reinterpret_cast<int64_t *>(pval + FPS_MAXG);
         int64_t G = (N + FG - 1) / FG;
@@ -378,8 +526,6 @@ extern "C" int gpbo_fps_order_f64(const double *X, const double *y, int64_t N, i
             hipLaunchKernelGGL(fps_step_kernel, dim3((unsigned)G), dim3(FG), 0, st, X, N, (int)d, ls, mind, stt, pval, pidx, perm_out, j, J);
         hipLaunchKernelGGL(fps_extend_kernel, dim3(1), dim3(FT), 0, st, N, J, N, mind, perm_out);
     }
-#undef GPBO_FPS_D
-#undef GPBO_FPS
     if (Xp_out) {
         const int64_t tot = N * d;
         hipLaunchKernelGGL(gather_obs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, (int)d, perm_out, N, Xp_out);

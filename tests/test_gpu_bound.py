@@ -352,6 +352,41 @@ def test_farthest_point_order_and_the_factorisation_of_the_permuted_problem(N, d
     assert np.array_equal(pr.cpu().numpy(), perm)
 
 
+@pytest.mark.parametrize("N,d,J", [(12000, 5, 96), (20000, 16, 64), (40000, 3, 48), (1024, 1, 1024), (1025, 2, 7)])
+def test_every_form_of_the_selection_gives_the_numpy_sequence(N, d, J):
+    """gpbo_fps_order_f64 alone (no factorisation at these sizes): several workgroups with one point (12,000 x 5) or two
+    points per thread (20,000 x 16) exchanging one record per member, one launch per member beyond 32,768 observations
+    (40,000 x 3), every observation a member (J = N), a ragged second point per thread (1,025) - the same sequence as NumPy,
+    the same every time, a permutation of 0 .. N-1, rows gathered in that order."""
+    import torch
+
+    rng = np.random.default_rng(N + d)
+    X = rng.uniform(0, 1, (N, d))
+    X[N // 3] = X[N // 7]                       # a duplicated row: distance 0 to a member, chosen last
+    y = rng.standard_normal(N)
+    ls = np.exp(rng.uniform(np.log(0.2), np.log(2.0), d))
+    gp = DeviceGP()
+    lib, t = gp.lib, torch
+    Xd, yd = gp._dev(X), gp._dev(y)
+    wb = int(lib.gpbo_fps_order_workspace_bytes(N))
+    w = t.empty(wb // 8 + 1, dtype=t.float64, device=gp.device)
+    lsp = np.ascontiguousarray(ls).ctypes.data_as(C.c_void_p)
+    ref = _fps_reference(X, ls, J)
+    first = None
+    for _ in range(3):
+        pr = t.full((N,), -1, dtype=t.int64, device=gp.device)
+        Xp, yp = t.empty_like(Xd), t.empty_like(yd)
+        assert lib.gpbo_fps_order_f64(gp._ptr(Xd), gp._ptr(yd), N, d, lsp, J, gp._ptr(pr), gp._ptr(Xp), gp._ptr(yp), gp._ptr(w), wb,
+                                      gp._stream()) == 0
+        t.cuda.synchronize()
+        perm = pr.cpu().numpy()
+        assert np.array_equal(perm[:J], ref)
+        assert np.array_equal(perm[J:], np.setdiff1d(np.arange(N), ref))
+        assert np.array_equal(Xp.cpu().numpy(), X[perm]) and np.array_equal(yp.cpu().numpy(), y[perm])
+        first = perm if first is None else first
+        assert np.array_equal(perm, first)
+
+
 @pytest.mark.parametrize("order", ["sobol", "sorted", "reversed", "clustered_first"])
 def test_pruning_does_not_depend_on_the_order_of_the_observations(order):
     """the literal prefix of a history sorted along an axis (or whose first rows sit in one
