@@ -380,6 +380,49 @@ __device__ __forceinline__ void upd_small(double *__restrict__ S, int64_t ld, co
 // nor Mbot and contains no barrier (wave 0's elimination is ~3000 cycles during which they would otherwise wait).
 // Returns (wave 0 only) the 1-based column of the first non-positive / non-finite pivot, or 0.
 // ---------------------------------------------------------------------------------------------------------------
+// DP-DPP helpers of the third form of the sixteen-column phase (eliminate_dpp below): gfx90a+ lets 64-bit VALU operations take
+// a DPP operand with ONE control, row_newbcast:k (every lane reads lane k of its row of 16).  Inline assembly: the
+// compiler's hazard recogniser does not look inside, so the two wait states "VALU writes a VGPR, DPP reads it" are written
+// out (s_nop 1) wherever the producer can be that close.
+template <int K>
+__device__ __forceinline__ double ci_bcast16(double v) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+template <int K, bool NOP>
+__device__ __forceinline__ void ci_fmac_nbcast(double &acc, double bsrc, double mul) {   // acc -= bsrc[lane K of the row] * mul
+    if (NOP)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(mul), "n"(K));
+    else
+        asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(mul), "n"(K));
+}
+template <int C, int K>
+struct CiDppUpd {   // columns K .. 15 of both 16-row blocks -= column C * L[K][C]
+    static __device__ __forceinline__ void run(double (&xt)[16], double (&xb)[16]) {
+        if constexpr (K < 16) {
+            ci_fmac_nbcast<K, K == C + 1>(xt[K], xt[C], xt[C]);
+            ci_fmac_nbcast<K, false>(xb[K], xt[C], xb[C]);
+            CiDppUpd<C, K + 1>::run(xt, xb);
+        }
+    }
+};
+template <int C>
+struct CiDppCol {
+    static __device__ __forceinline__ void run(double (&xt)[16], double (&xb)[16], int col0, int &first_bad) {
+        if constexpr (C < 16) {
+            const double piv = ci_bcast16<C>(xt[C]);
+            const bool ok = (piv > 0.0) && (piv < 1.0e300);
+            first_bad = (!ok && first_bad == 0) ? col0 + C + 1 : first_bad;
+            const double rs = rsqrt_refined(piv);
+            xt[C] *= rs;
+            xb[C] *= rs;
+            CiDppUpd<C, C + 1>::run(xt, xb);
+            CiDppCol<C + 1>::run(xt, xb, col0, first_bad);
+        }
+    }
+};
+
 // The waves that carry a caller's background work through an elimination: 1, 5, 6, 7 - none of them on wave 0's SIMD (waves
 // w and w + 4 share one; fp64 MFMAs and fp64 vector instructions of a SIMD do not overlap, and wave 0's sixteen-column
 // phase is bound by instruction issue: with the X strips on waves 4..7 the second elimination took 30.0k cycles against the
@@ -423,6 +466,99 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
             for (int k = 0; k < PB; ++k) row[k] = (lane < PB && k > lane) ? 0.0 : x[k];
         }
     };
+    // Round 4: the same sixteen columns in four MICRO-BLOCKS of four.  The register phase above is bound by instruction issue
+    // on this one wave (~650 instructions per sixteen columns at ~7 cycles: 120 column updates of two v_readlane + one fma
+    // each, sixteen pivot chains); here only the 6 updates INSIDE a micro-block stay in registers and the other columns of
+    // the sixteen get each micro-block as ONE rank-4 product per 16-row block on the matrix core
+    // (v_mfma_f64_16x16x4_f64: C[row][col] -= X[row][c0 + k] X[col][c0 + k], k < 4 - the A operand of the diagonal block,
+    // negated and masked to the columns still open, IS the B operand).  LDS is the transposer between the two layouts
+    // (lane = row for the register phase, the MFMA's fragments for the product); only this wave touches these rows and
+    // columns, LDS serves a wave's accesses in order, so no barrier is involved.
+    auto eliminate_mb = [&](int s) {
+        const int l31 = lane & 31;
+        double *row = ((l31 < PB) ? Mtop + (PB * s + l31) * LDM : Mbot + (PB * s + (l31 - PB)) * LDM) + PB * s;
+        double *ctop = Mtop + (PB * s + l4) * LDM + PB * s + l15;       // C fragments: rows l4 + 4 r, column l15
+        double *cbot = Mbot + (PB * s + l4) * LDM + PB * s + l15;
+        const double *atop = Mtop + (PB * s + l15) * LDM + PB * s + l4; // A fragments: row l15, k = l4 (+ c0)
+        const double *abot = Mbot + (PB * s + l15) * LDM + PB * s + l4;
+#pragma unroll
+        for (int mb = 0; mb < PB / 4; ++mb) {
+            const int c0 = 4 * mb;
+            double x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = row[c0 + k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double piv = readlane_f64(x[c], c0 + c);
+                const bool ok = (piv > 0.0) && (piv < 1.0e300);
+                first_bad = (!ok && first_bad == 0) ? PB * s + c0 + c + 1 : first_bad;
+                x[c] *= rsqrt_refined(piv);
+                double m[4];
+#pragma unroll
+                for (int k = c + 1; k < 4; ++k) m[k] = readlane_f64(x[c], c0 + k);
+#pragma unroll
+                for (int k = c + 1; k < 4; ++k) x[k] = fma(-x[c], m[k], x[k]);
+            }
+            if (lane < 2 * PB) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) row[c0 + k] = (lane < PB && c0 + k > lane) ? 0.0 : x[k];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (mb < PB / 4 - 1) {
+                const double at = atop[c0], ab = abot[c0];
+                const double b = (l15 >= c0 + 4) ? -at : 0.0;   // finished columns (and this micro-block's own) stay as they are
+                d4_t ct, cb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ct[r] = ctop[4 * r * LDM];
+                    cb[r] = cbot[4 * r * LDM];
+                }
+                ct = mfma_f64_16x16x4(at, b, ct);
+                cb = mfma_f64_16x16x4(ab, b, cb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ctop[4 * r * LDM] = ct[r];
+                    cbot[4 * r * LDM] = cb[r];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        // entries above the diagonal of the top block in LATER micro-blocks' columns were carried through the products:
+        // zero them, as eliminate() does (nothing reads them, but the factor that is stored must be a triangle)
+        if (lane < PB) {
+#pragma unroll
+            for (int k = 1; k < PB; ++k)
+                if (k > lane) row[k] = 0.0;
+        }
+    };
+    // Third form (round 4): both 16-row blocks of a row index in ONE lane's registers (lane l < 16: row l of the diagonal block
+    // in xt, identity row l in xb), multipliers by DP-DPP row_newbcast instead of v_readlane pairs: two instructions per
+    // column update instead of three, one instead of two for the pivot.  The four rows of 16 lanes compute the same thing.
+    auto eliminate_dpp = [&](int s) {
+        double *rt = Mtop + (PB * s + l15) * LDM + PB * s, *rb = Mbot + (PB * s + l15) * LDM + PB * s;
+        double xt[PB], xb[PB];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) {
+            xt[k] = rt[k];
+            xb[k] = rb[k];
+        }
+        int fb = first_bad;
+        CiDppCol<0>::run(xt, xb, PB * s, fb);
+        first_bad = __builtin_amdgcn_readfirstlane(fb);
+        if (lane < PB) {
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                rt[k] = (k > lane) ? 0.0 : xt[k];
+                rb[k] = xb[k];
+            }
+        }
+    };
+#ifndef GPBO_CI_DPP
+#define GPBO_CI_DPP 0   /* measured: 0.2 - 1.0 % faster than the register phase: not worth hand-written hazard slots */
+#endif
+#ifndef GPBO_CI_MICROBLOCK
+#define GPBO_CI_MICROBLOCK 0   /* measured: 2 - 5 % SLOWER than the register phase; tools/build_variant.sh ci_mb cholinv "-DGPBO_CI_MICROBLOCK=1" */
+#endif
     auto panel = [&](int R0, int s) {  // rows R0.. (16) of column block s  <-  (those rows) * L_ss^-T
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
         const double *ra = rowp(R0 + l15) + PB * s;
@@ -451,7 +587,7 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
     };
     constexpr int NS = NB / PB;  // 4
     F64_STAMP();
-    if (w == 0) eliminate(0);
+    if (w == 0) { if (GPBO_CI_DPP) eliminate_dpp(0); else if (GPBO_CI_MICROBLOCK) eliminate_mb(0); else eliminate(0); }
     F64_STAMP();
     __syncthreads();
     F64_STAMP();
@@ -467,7 +603,7 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
         if (w == 0) {  // (3)
             trail(PB * (s + 1), s + 1, s);
             if (s == 0) F64_STAMP();
-            eliminate(s + 1);
+            if (GPBO_CI_DPP) eliminate_dpp(s + 1); else if (GPBO_CI_MICROBLOCK) eliminate_mb(s + 1); else eliminate(s + 1);
             if (s == 0) F64_STAMP();
         } else if (has_bg && ci_is_bg_wave(w)) {
             bg(s);
