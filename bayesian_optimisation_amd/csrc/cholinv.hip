@@ -602,6 +602,9 @@ __device__ __forceinline__ int factor64(double *Mtop, double *Mbot, int w, int l
         if (s == NS - 1) break;
         if (w == 0) {  // (3)
             trail(PB * (s + 1), s + 1, s);
+            // (same wave, LDS in order: no barrier - but the COMPILER must not move the loads below above these stores; it did
+            //  exactly that between the phases of eliminate_mb until a memory clobber stood between them)
+            asm volatile("" ::: "memory");
             if (s == 0) F64_STAMP();
             if (GPBO_CI_DPP) eliminate_dpp(s + 1); else if (GPBO_CI_MICROBLOCK) eliminate_mb(s + 1); else eliminate(s + 1);
             if (s == 0) F64_STAMP();
