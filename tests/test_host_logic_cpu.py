@@ -94,3 +94,38 @@ def test_precision_and_q_ei_argument_checks():
     ps = PointSelector()
     with pytest.raises(RuntimeError):
         ps.lower_confidence_bound()                                      # before update_surrogate()
+
+
+def test_replayed_pmc_figures_belong_to_todays_kernel_sources():
+    """bench.py replays roofline.traffic / kstar_roofline.valu from the committed rocprofv3 --pmc pass of the headline shape
+    (counters cannot be read inside an un-profiled run).  The entry stores the hash of the kernel sources it was collected on
+    (profiles/source_hash.py); this test fails when those sources have changed since - re-run profiles/collect.sh and
+    profiles/summarise.py - and bench.py reports `traffic_stale: true` in that case."""
+    import importlib.util
+    import json
+    import os
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("source_hash", os.path.join(repo, "profiles", "source_hash.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    shapes = json.load(open(os.path.join(repo, "profiles", "pmc_sigma_acq.json")))
+    head = shapes["N=4096,d=8,dtype=f64,candidates_per_launch=131072"]
+    assert "kernel_source_hash" in head, "the headline entry must say which sources it was collected on"
+    for key, e in shapes.items():
+        if "kernel_source_hash" in e:
+            dtype = key.split("dtype=")[1].split(",")[0]
+            assert e["kernel_source_hash"] == sh.kernel_source_hash(dtype), \
+                f"{key}: kernel sources changed since {e['source']} was collected: re-run profiles/collect.sh + summarise.py"
+    # and bench.py's helper says the same thing
+    import sys
+
+    sys.path.insert(0, repo)
+    import bench
+
+    e, stale = bench._pmc_entry(4096, 8, "f64", 131072)
+    assert e is head or e == head
+    assert stale is False
+    e, stale = bench._pmc_entry(4096, 8, "i8", 131072)     # collected before hashes were stored: unknown, not "fresh"
+    assert e is not None and stale is None
+    assert bench._pmc_entry(123, 8, "f64", 131072) == (None, None)
