@@ -53,3 +53,14 @@ def test_random_case_all_routes_vs_oracle(seed):
             assert np.max(np.abs(r.sigma.cpu().numpy() - sig_o)) <= sig_tol, route
         if clear:
             assert r.best_idx == off + want, route
+    # the same case factorised in farthest-point order (what the exact-bound route runs on): same posterior, same point
+    gf = DeviceGP(chunk=chunk).factorise(X, y, ls, order="fps")
+    r = gf.score(Xs, dense=True, idx_offset=off, **kw)
+    assert (gf.order == "fps") == (X.shape[0] > 128)
+    assert np.max(np.abs(r.mu.cpu().numpy() - mu_o)) <= 2e-9 * ys and np.max(np.abs(r.sigma.cpu().numpy() - sig_o)) <= 1e-8
+    rb = gf.score_bound(Xs, idx_offset=off, **kw)
+    assert rb.best_idx == r.best_idx and rb.nan_count == 0
+    if clear:
+        assert r.best_idx == off + want
+    Xa, ya = gf.observations_host()
+    assert np.array_equal(Xa, X) and np.array_equal(ya, y)
