@@ -167,6 +167,10 @@ __global__ __launch_bounds__(FT) void fps_coop_kernel(const double *__restrict__
                 const double df = xr[q][k] - s_c[k];
                 dist = fma(df, df, dist);
             }
+            // a NaN coordinate (in this row, or - first sweep - anywhere: the centroid) gives a NaN distance, which no
+            // comparison selects: such a row counts as -1, below every real distance and above a member's -inf, so a sweep
+            // always has a winner with a valid index (the factorisation then reports the NaN; the order must not fault)
+            if (!(dist == dist)) dist = -1.0;
             double m = dist;
             if (member >= 0) {
                 m = fmin(md[q], dist);
@@ -357,6 +361,7 @@ __global__ __launch_bounds__(FG) void fps_step_kernel(const double *__restrict__
             const double df = X[i * d + k] * ls.isc[k] - s_c[k];
             dist = fma(df, df, dist);
         }
+        if (!(dist == dist)) dist = -1.0;   // NaN coordinates: see fps_coop_kernel
         double m = dist;
         if (member >= 0) {
             m = fmin(mind[i], dist);
@@ -425,11 +430,14 @@ __global__ __launch_bounds__(FT) void fps_extend_kernel(int64_t N, int64_t J, in
     fps_extend(N, J, J2, mind, perm, s_scan);
 }
 
+// (an index outside [0, n) cannot come out of the selection; if it ever did, the row is NaN - the factorisation then fails
+//  loudly - instead of an out-of-bounds read)
 __global__ void gather_obs_kernel(const double *__restrict__ X, int d, const int64_t *__restrict__ perm, int64_t n,
                                   double *__restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * d) return;
-    out[e] = X[perm[e / d] * d + (e % d)];
+    const int64_t r = perm[e / d];
+    out[e] = (r >= 0 && r < n) ? X[r * d + (e % d)] : std::numeric_limits<double>::quiet_NaN();
 }
 
 struct OrderLayout {
@@ -450,7 +458,10 @@ OrderLayout order_layout(int64_t N) {
 
 __global__ void gather_y_kernel(const double *__restrict__ y, const int64_t *__restrict__ perm, int64_t n, double *__restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) out[e] = y[perm[e]];
+    if (e < n) {
+        const int64_t r = perm[e];
+        out[e] = (r >= 0 && r < n) ? y[r] : std::numeric_limits<double>::quiet_NaN();
+    }
 }
 
 }  // namespace

@@ -387,6 +387,41 @@ def test_every_form_of_the_selection_gives_the_numpy_sequence(N, d, J):
         assert np.array_equal(perm, first)
 
 
+@pytest.mark.parametrize("N,d", [(900, 3), (3000, 8), (9000, 4)])
+def test_nan_observations_never_break_the_order(N, d):
+    """A NaN coordinate makes the centroid - and with it every first-sweep distance - NaN; rows of NaN never have a real
+    distance.  The order must still be a permutation (such rows count as -1: picked last) and the gathered copies the
+    caller's rows; the factorisation of such data then fails the way the arrival-order one does (LinAlgError)."""
+    import torch
+
+    rng = np.random.default_rng(N)
+    X = rng.uniform(0, 1, (N, d))
+    y = rng.standard_normal(N)
+    ls = np.full(d, 0.4)
+    gp = DeviceGP()
+    lib, t = gp.lib, torch
+    lsp = np.ascontiguousarray(ls).ctypes.data_as(C.c_void_p)
+    wb = int(lib.gpbo_fps_order_workspace_bytes(N))
+    w = t.empty(wb // 8 + 1, dtype=t.float64, device=gp.device)
+    for bad_rows in ([5], list(range(0, N, 2)), list(range(N))):
+        Xn = X.copy()
+        Xn[bad_rows, 0] = np.nan
+        Xd, yd = gp._dev(Xn), gp._dev(y)
+        pr = t.full((N,), -1, dtype=t.int64, device=gp.device)
+        Xp, yp = t.empty_like(Xd), t.empty_like(yd)
+        J = 128
+        assert lib.gpbo_fps_order_f64(gp._ptr(Xd), gp._ptr(yd), N, d, lsp, J, gp._ptr(pr), gp._ptr(Xp), gp._ptr(yp), gp._ptr(w), wb,
+                                      gp._stream()) == 0
+        t.cuda.synchronize()
+        perm = pr.cpu().numpy()
+        assert np.array_equal(np.sort(perm), np.arange(N))
+        assert np.array_equal(yp.cpu().numpy(), y[perm]) and np.array_equal(Xp.cpu().numpy(), Xn[perm], equal_nan=True)
+        with pytest.raises(np.linalg.LinAlgError):
+            DeviceGP().factorise(Xn, y, ls, order="fps")
+        with pytest.raises(np.linalg.LinAlgError):
+            DeviceGP().factorise(Xn, y, ls)
+
+
 @pytest.mark.parametrize("order", ["sobol", "sorted", "reversed", "clustered_first"])
 def test_pruning_does_not_depend_on_the_order_of_the_observations(order):
     """the literal prefix of a history sorted along an axis (or whose first rows sit in one
