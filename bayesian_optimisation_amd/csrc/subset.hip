@@ -14,6 +14,8 @@
 // own, chol(K_SS): the same members, but two different sets of rounding errors to compare.)
 #include "gpbo_internal.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 
 namespace {
@@ -101,6 +103,11 @@ __device__ __forceinline__ void fps_extend(int64_t N, int64_t J, int64_t J2, con
 // coordinates).  Same arithmetic and tie rule as the one-launch-per-member form below (distance = fma chain over the
 // coordinates in index order; largest value, lowest index), hence the same sequence.
 //
+// A step is bound by instruction ISSUE, not by latency: every wave runs the same ~65 instructions of reductions plus ~26 per
+// point (d = 8), and the waves of a SIMD take turns - measured 1.15 / 1.4 / 1.9 us per member with 1,024 threads and 1 / 2 / 4
+// points per thread.  Few waves with many points each are therefore the faster shape: 256 threads (one wave per SIMD) with up
+// to 8 points per thread, 512 threads when one workgroup has to hold up to 4,096 points (TH, PTS below).
+//
 // The hand-off needs no fence: a record is 3 + 2 D WORDS of 64 bits, each a relaxed device-scope atomic that carries 32
 // bits of payload AND the step's stamp (step + 1) - (value lo | stamp), (value hi | stamp), (index | stamp), then the
 // halves of the coordinates.  A reader accepts a record when EVERY word shows the stamp it waits for: each word validates
@@ -128,12 +135,12 @@ struct FpsState {
     double centre[GPBO_MAX_D];   // scaled coordinates the next sweep measures distances to (first: the centroid)
 };
 
-template <int PTS, int D, bool COOP>
-__global__ __launch_bounds__(FT) void fps_coop_kernel(const double *__restrict__ X, int64_t N, FpsLs ls, int64_t J, int G,
+template <int TH, int PTS, int D, bool COOP>
+__global__ __launch_bounds__(TH) void fps_coop_kernel(const double *__restrict__ X, int64_t N, FpsLs ls, int64_t J, int G,
                                                       FpsState *__restrict__ stt, FpsSlot *__restrict__ slots,
                                                       double *__restrict__ mind, int64_t *__restrict__ perm) {
-    __shared__ double s_val[FT / 64];
-    __shared__ int64_t s_idx[FT / 64];
+    __shared__ double s_val[TH / 64];
+    __shared__ int64_t s_idx[TH / 64];
     __shared__ double s_c[D];
     __shared__ int64_t s_member;
     __shared__ int s_dead;
@@ -141,11 +148,11 @@ __global__ __launch_bounds__(FT) void fps_coop_kernel(const double *__restrict__
     const int wg = COOP ? (int)(blockIdx.x >> 3) : 0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const double ninf = -std::numeric_limits<double>::infinity();
-    const int64_t base = (int64_t)wg * FT * PTS;
+    const int64_t base = (int64_t)wg * TH * PTS;
     double xr[PTS][D], md[PTS];
 #pragma unroll
     for (int q = 0; q < PTS; ++q) {
-        const int64_t i = base + (int64_t)q * FT + tid;
+        const int64_t i = base + (int64_t)q * TH + tid;
 #pragma unroll
         for (int k = 0; k < D; ++k) xr[q][k] = (i < N) ? X[i * D + k] * ls.isc[k] : 0.0;
         md[q] = (i < N) ? std::numeric_limits<double>::infinity() : ninf;   // rows beyond N are never chosen
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(FT) void fps_coop_kernel(const double *__restrict__
         int bq = 0;
 #pragma unroll
         for (int q = 0; q < PTS; ++q) {
-            const int64_t i = base + (int64_t)q * FT + tid;
+            const int64_t i = base + (int64_t)q * TH + tid;
             double dist = 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) {
@@ -185,12 +192,12 @@ __global__ __launch_bounds__(FT) void fps_coop_kernel(const double *__restrict__
         const double wmax = fps_wave_max(bv);
         if (lane == 0) s_val[w] = wmax;
         __syncthreads();
-        const double gmax = fps_row_max(s_val[lane & (FT / 64 - 1)]);   // 16 wave results, one per lane of every row of 16
+        const double gmax = fps_row_max(s_val[lane & (TH / 64 - 1)]);   // 16 wave results, one per lane of every row of 16
         const int cand = (bv == gmax) ? bi32 : 0x7fffffff;              // lowest index among the points that attain it
         const int wmin = fps_wave_min(cand);
         if (lane == 0) s_idx[w] = wmin;
         __syncthreads();
-        bi32 = fps_row_min((int)s_idx[lane & (FT / 64 - 1)]);
+        bi32 = fps_row_min((int)s_idx[lane & (TH / 64 - 1)]);
         bv = gmax;
         const int64_t bi = bi32 == 0x7fffffff ? std::numeric_limits<int64_t>::max() : (int64_t)bi32;
         // every thread now holds the workgroup's best (bv, bi); its owner has the coordinates in registers
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(FT) void fps_coop_kernel(const double *__restrict__
             const unsigned long long stamp = (unsigned long long)(unsigned)(s + 1) << 32;
             // the winner's wave publishes the record: the owner's registers reach the other lanes through scalar registers
             const int oloc = have ? (int)(bi - base) : 0;         // (a workgroup without a valid point: thread 0, value -inf)
-            const int ow = (oloc % FT) >> 6, olane = oloc & 63, oq = oloc / FT;   // all uniform
+            const int ow = (oloc % TH) >> 6, olane = oloc & 63, oq = oloc / TH;   // all uniform
             if (w == ow) {
                 unsigned data = 0;
                 if (lane == 0) data = (unsigned)__double2loint(bv);
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(FT) void fps_coop_kernel(const double *__restrict__
     }
 #pragma unroll
     for (int q = 0; q < PTS; ++q) {   // the extension to the full order reads the membership from `mind`
-        const int64_t i = base + (int64_t)q * FT + tid;
+        const int64_t i = base + (int64_t)q * TH + tid;
         if (i < N) mind[i] = md[q];
     }
 }
@@ -494,34 +501,58 @@ extern "C" int gpbo_fps_order_f64(const double *X, const double *y, int64_t N, i
     // Every observation in a register of one of G <= 16 workgroups of 1024 threads (fps_coop_kernel): PTS points per thread,
     // as many as fit 64 registers of coordinates (PTS x d <= 32), G = ceil(N / (1024 PTS)).  Beyond 16 workgroups
     // (N > 65,536 at d <= 8, > 32,768 above): one launch per member (fps_step_kernel).
-    // One workgroup: up to 4 points per thread (2 above d = 8: 64 registers of coordinates).  A step of one workgroup is
-    // issue-bound - measured 1.2 / 1.4 / 1.9 us at 1 / 2 / 4 points per thread, d = 8 - and a hand-off between workgroups
-    // costs more than that, so several workgroups share the points only when one cannot hold them, and then as many as
-    // possible (1 point per thread up to N = 16,384, 2 up to 32,768).  Beyond: one launch per member (fps_step_kernel).
-    const int pmax1 = d <= 8 ? 4 : 2;
-    int pts = 1;
-    while (pts < pmax1 && (int64_t)FT * pts < N) pts *= 2;
-    const bool coop = (int64_t)FT * pts < N;
-    if (coop) pts = ((int64_t)FT * FPS_MAXW < N) ? 2 : 1;
-    const int64_t G = (N + (int64_t)FT * pts - 1) / ((int64_t)FT * pts);
+    // Shape of the selection (see fps_coop_kernel): PTS points per thread, as many as 128 registers of coordinates hold
+    // (8 up to d = 8, 4 above); one workgroup of 256 threads while it can hold the points, of 512 up to 4,096 (2,048)
+    // points.  Beyond, workgroups of 512 threads share the points, EIGHT of them while 8 x 512 x pmax points suffice
+    // (measured at N = 8192, d = 8, us per member: 512 x 2 x 8 workgroups 2.96, 256 x 4 x 8 3.13, 1024 x 1 x 8 3.2,
+    // 256 x 2 x 16 3.43, 256 x 8 x 4 3.48: the hand-off grows with the number of slots a reader polls, the local part
+    // with the points per SIMD), sixteen up to 16 x 512 x pmax = 65,536 (32,768) points.
+    // GPBO_FPS_SHAPE="threads,points" overrides the choice (A/B runs; ignored when the points do not fit).
+    const int pmax = d <= 8 ? 8 : 4;
+    int th = 256, pts = 1;
+    while (pts < pmax && (int64_t)th * pts < N) pts *= 2;
+    if ((int64_t)th * pts < N) th = 512;
+    bool coop = (int64_t)th * pts < N;
+    if (coop) {
+        th = 512;
+        pts = 1;
+        while (pts < pmax && (int64_t)th * pts * 8 < N) pts *= 2;
+    }
+    static const char *shape_env = getenv("GPBO_FPS_SHAPE");
+    if (shape_env) {
+        int eth = 0, epts = 0;
+        if (sscanf(shape_env, "%d,%d", &eth, &epts) == 2 && (eth == 256 || eth == 512) &&
+            (epts == 1 || epts == 2 || epts == 4 || epts == 8) && epts <= pmax && (int64_t)eth * epts * FPS_MAXW >= N) {
+            th = eth;
+            pts = epts;
+            coop = (int64_t)th * pts < N;
+        }
+    }
+    const int64_t G = (N + (int64_t)th * pts - 1) / ((int64_t)th * pts);
     bool launched = false;
     if (G <= FPS_MAXW) {
         FpsSlot *slots = reinterpret_cast<FpsSlot *>(w + L.slot_off);
         if (coop && hipMemsetAsync(slots, 0, sizeof(FpsSlot) * 2 * FPS_MAXW, st) != hipSuccess) return GPBO_ERR_LAUNCH;
         hipLaunchKernelGGL(fps_centroid_kernel, dim3(1), dim3(FT), 0, st, X, N, (int)d, ls, stt);
         const unsigned grid = coop ? (unsigned)(8 * G) : 1u;
-#define GPBO_FPS(P, DD, CO) hipLaunchKernelGGL((fps_coop_kernel<P, DD, CO>), dim3(grid), dim3(FT), 0, st, X, N, ls, J, (int)G, stt, slots, mind, perm_out)
+#define GPBO_FPS(T, P, DD, CO) hipLaunchKernelGGL((fps_coop_kernel<T, P, DD, CO>), dim3(grid), dim3(T), 0, st, X, N, ls, J, (int)G, stt, slots, mind, perm_out)
+#define GPBO_FPS_P(T, DD, CO)                                                      \
+    do {                                                                            \
+        if (pts == 1) GPBO_FPS(T, 1, DD, CO);                                       \
+        else if (pts == 2) GPBO_FPS(T, 2, DD, CO);                                  \
+        else if (pts == 4 || DD > 8) GPBO_FPS(T, 4, DD, CO);                        \
+        else GPBO_FPS(T, (DD <= 8 ? 8 : 4), DD, CO);                                \
+    } while (0)
 #define GPBO_FPS_D(DD)                                                              \
     if (!launched && d == DD) {                                                     \
-        if (coop) { if (pts == 1) GPBO_FPS(1, DD, true); else GPBO_FPS(2, DD, true); }  \
-        else if (pts == 1) GPBO_FPS(1, DD, false);                                  \
-        else if (pts == 2) GPBO_FPS(2, DD, false);                                  \
-        else GPBO_FPS((DD <= 8 ? 4 : 2), DD, false);                                \
+        if (th == 256) { if (coop) GPBO_FPS_P(256, DD, true); else GPBO_FPS_P(256, DD, false); }  \
+        else { if (coop) GPBO_FPS_P(512, DD, true); else GPBO_FPS_P(512, DD, false); }            \
         launched = true;                                                            \
     }
         GPBO_FPS_D(1) GPBO_FPS_D(2) GPBO_FPS_D(3) GPBO_FPS_D(4) GPBO_FPS_D(5) GPBO_FPS_D(6) GPBO_FPS_D(7) GPBO_FPS_D(8)
         GPBO_FPS_D(9) GPBO_FPS_D(10) GPBO_FPS_D(11) GPBO_FPS_D(12) GPBO_FPS_D(13) GPBO_FPS_D(14) GPBO_FPS_D(15) GPBO_FPS_D(16)
 #undef GPBO_FPS_D
+#undef GPBO_FPS_P
 #undef GPBO_FPS
         if (coop) hipLaunchKernelGGL(fps_check_kernel, dim3(8), dim3(FT), 0, st, stt, N, J, mind, perm_out);
         hipLaunchKernelGGL(fps_extend_kernel, dim3(1), dim3(FT), 0, st, N, J, N, mind, perm_out);
