@@ -54,7 +54,7 @@ def test_every_compute_entry_point_rejects_null_arguments():
 
     lib = _lib.load()
     skip = {"gpbo_version", "gpbo_nlml_grid_max_n", "gpbo_gemm_f64",  # gemm: M = 0 is a valid empty product
-            "gpbo_profile_create", "gpbo_profile_read", "gpbo_profile_read_kstar", "gpbo_profile_reset",
+            "gpbo_profile_create", "gpbo_profile_read", "gpbo_profile_read_kstar", "gpbo_profile_read_qei", "gpbo_profile_reset",
             "gpbo_profile_destroy"}
     checked = 0
     for name, (res, args) in _lib.SIGNATURES.items():
