@@ -6,10 +6,11 @@ NAME=$1; FILE=$2; EXTRA=${3:-}
 cd "$(dirname "$0")/../bayesian_optimisation_amd/csrc"
 mkdir -p ../../ab_libs build
 X=""; [ $FILE = cholinv ] && X="-mllvm -amdgpu-kernarg-preload-count=16"   # as build.sh does
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $X $EXTRA -c $FILE.hip -o build/${FILE}_$NAME.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $X $EXTRA -c $FILE.hip -o ../../ab_libs/${FILE}_$NAME.o
 objs=""
 for f in api kernel_build kstar_mfma gemm_f64 factor cholinv subset update sigma_acq ard posterior_f32 rescore ozaki host_api; do
-  if [ $f = $FILE ]; then objs="$objs build/${FILE}_$NAME.o"; else objs="$objs build/$f.o"; fi
+  if [ $f = $FILE ]; then objs="$objs ../../ab_libs/${FILE}_$NAME.o"; else objs="$objs build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab_libs/$NAME.so $objs
+rm -f ../../ab_libs/${FILE}_$NAME.o   # (the variant object is not kept: csrc/build/ holds the 14 production objects only)
 echo "built ab_libs/$NAME.so"
