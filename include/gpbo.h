@@ -237,7 +237,12 @@ int gpbo_rescore_f64(const double *Xs, int64_t M, const double *mu, const double
  * gpbo_bound_select_f64: the strided sample goes through the fp64 kernels (a lower bound of the maximum), every
  * candidate whose bound reaches it survives and is re-scored by the fp64 kernels, which decide (maximum, lowest index,
  * NaN count as the plain pass); too many survivors -> stats->fallback = 1 and the caller runs gpbo_posterior_acq_f64.
- * work: gpbo_rescore_workspace_bytes(Np, cap, chunk64).  This call synchronises the stream. */
+ * work: gpbo_rescore_workspace_bytes(Np, cap, chunk64).  This call synchronises the stream.
+ * When the bound is one: U, X, alpha must be ONE factorisation (the same the plain pass would use): the bound's |v[:J]|^2 is
+ * then a partial sum of the squares gpbo_posterior_acq_f64 adds up.  The plain pass takes sqrt(|var|) (point_selector.py:98),
+ * and a NEGATIVE computed variance - possible only when its rounding error exceeds the jitter tau of K = k(X,X) + tau I,
+ * since the true variance is >= tau for prior_var >= 1 + tau - is the one value a prefix cannot bound: callers take this route
+ * for tau >= 1e-6 (DeviceGP.BOUND_MIN_JITTER, gpbo_select_next_host_f64) and the plain pass otherwise. */
 int gpbo_posterior_prefix_f64(const double *Xs, int64_t M, const double *X, int64_t N, int64_t Np, int32_t d,
                               const double *ls_host, const double *U, const double *alpha, double prior_var,
                               int32_t acq_kind, double p0, double p1, int64_t idx_offset, int64_t chunk, int64_t n_prefix,
