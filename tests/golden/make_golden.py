@@ -217,6 +217,39 @@ def main():
     save("g9_d24_n96_m512", N=np.array(96), M=np.array(512), d=np.array(24), ls=ls, y=y, **out)
 
 
+def main_g10():
+    """G10 (round 4): randomised full-path cases shaped like the DAG's own data - observations drawn from the 50 x 50 (or
+    50-point) grids of select_parameters.py:62-75, objectives of a few hundred, the LAST row carrying the placeholder
+    objective 10000 that select_parameters.py:163,299 appends until time_residuals.py overwrites it, duplicated rows
+    (the grid is finite), several exploration weights.  Each runs the reference's update_surrogate() with its ARD search."""
+    rng = np.random.default_rng(1010)
+    ls2 = np.array([L1, L2])
+    for k, (n, explore, placeholder, dup) in enumerate([(3, None, True, False), (9, 1, True, True), (17, None, False, True),
+                                                        (28, 0.5, True, False), (45, None, False, False)]):
+        pick = rng.choice(2500, size=n, replace=False)
+        X = np.stack([T1[pick // 50], T2[pick % 50]], 1)
+        if dup:
+            X[-2] = X[0]
+        y = synth_y2(X, rng)
+        if placeholder:
+            y[-1] = 10000.0
+        Xs = grid2(T1, T2)
+        out, _ = run_reference(X, y, Xs, [50, 50], length_scales=ls2, explore=explore, name=np.array(["T1", "T2"]), iteration=k)
+        save(f"g10_2d_{k}", X=X, y=y, Xs=Xs, feature_domain=np.array([50, 50]), length_scales=ls2,
+             explore=np.array(4.0 if explore is None else float(explore)), nlogml=nlml_grid_reference(X, y, ls2), **out)
+    for k, (dom, lsg, n, explore, placeholder) in enumerate([(TR, L1, 35, None, True), (W56, LTHETA, 8, 2, False),
+                                                             (TR, L1, 50, None, False)]):
+        pick = rng.choice(50, size=n, replace=(n > 40))      # n = 50 with repeats: the DAG revisits grid points
+        X = dom[pick].reshape(n, 1)
+        y = 400.0 * (1.0 + (X[:, 0] - dom[17]) ** 2) + 20.0 * rng.standard_normal(n)
+        if placeholder:
+            y[-1] = 10000.0
+        Xs = dom.reshape(50, 1)
+        out, _ = run_reference(X, y, Xs, [50], length_scales=lsg, explore=explore, name="TR", iteration=k)
+        save(f"g10_1d_{k}", X=X, y=y, Xs=Xs, feature_domain=np.array([50]), length_scales=lsg,
+             explore=np.array(4.0 if explore is None else float(explore)), nlogml=nlml_grid_reference(X, y, lsg), **out)
+
+
 def copy_state_file():
     """The DAG's state file as shipped by the reference (opto_log_clean.JSON: data, not code) - the driver
     tests start from it so the JSON schema they exercise is the reference's own."""
@@ -229,6 +262,9 @@ def copy_state_file():
 
 
 if __name__ == "__main__":
-    main()
+    if not ONLY or any(o.startswith("g10") for o in ONLY):
+        main_g10()
+    if not ONLY or any(not o.startswith("g10") for o in ONLY):
+        main()
     if not ONLY:
         copy_state_file()

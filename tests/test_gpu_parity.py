@@ -131,12 +131,14 @@ def _run_dropin(g, preset=False):
     else:
         ps.length_scales = g["length_scales"]
     ps.update_surrogate()
-    idx = ps.lower_confidence_bound()
+    idx = ps.lower_confidence_bound(float(g["explore"])) if "explore" in g else ps.lower_confidence_bound()
     return ps, idx
 
 
+# (G10, round 4: randomised DAG-shaped cases run through the reference - placeholder objective 10000 in the last row,
+#  duplicated grid points, exploration weights 0.5 / 1 / 2 / 4, 1,514- and 10-way ties)
 @pytest.mark.parametrize("name", ["g1_m32", "g1_m50", "g4_ard_n2", "g2_n1_tr", "g2_n5_a", "g2_n20_tr", "g2_n12_a",
-                                  "g3_n1_2d"])
+                                  "g3_n1_2d", "g10_2d_0", "g10_2d_1", "g10_2d_2", "g10_2d_3", "g10_2d_4", "g10_1d_0", "g10_1d_1", "g10_1d_2"])
 def test_dropin_full_path_with_ard(golden, name):
     g = golden(name)
     ps, idx = _run_dropin(g)
