@@ -32,7 +32,7 @@ def _run_host(g, preset=False):
     else:
         ps.length_scales = g["length_scales"]
     ps.update_surrogate()
-    return ps, ps.lower_confidence_bound()
+    return ps, (ps.lower_confidence_bound(float(g["explore"])) if "explore" in g else ps.lower_confidence_bound())
 
 
 @pytest.mark.parametrize("N,M,d", [(1, 50, 1), (37, 2500, 2), (300, 5000, 8)])
@@ -74,7 +74,8 @@ def test_host_call_without_dense_outputs_takes_the_exact_prefix_bound_and_return
     assert (only["best_idx"], only["best_val"]) == (full["best_idx"], full["best_val"])
 
 
-@pytest.mark.parametrize("name", ["g1_m32", "g1_m50", "g4_ard_n2", "g2_n1_tr", "g2_n5_a", "g2_n20_tr", "g3_n1_2d"])
+@pytest.mark.parametrize("name", ["g1_m32", "g1_m50", "g4_ard_n2", "g2_n1_tr", "g2_n5_a", "g2_n20_tr", "g3_n1_2d",
+                                  "g10_2d_0", "g10_2d_1", "g10_2d_3", "g10_2d_4", "g10_1d_0", "g10_1d_2"])
 def test_host_class_full_path_with_ard_vs_reference_golden(golden, name):
     g = golden(name)
     ps, idx = _run_host(g)
