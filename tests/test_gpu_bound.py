@@ -617,3 +617,37 @@ def test_routes_the_bound_must_not_take_with_a_permuted_factorisation():
     r = g0.score_bound(Xs2, prior_var=1.0 + 1e-8)
     assert g0.last_screen["fallback"] and "jitter" in g0.last_screen["reason"]
     assert r.best_idx == g0.score(Xs2, prior_var=1.0 + 1e-8).best_idx
+
+
+def test_a_workgroup_that_never_answers_ends_in_the_identity_order_not_in_a_hang():
+    """The co-operating workgroups of the selection wait for each other's records with BOUNDED polls.  GPBO_FPS_MUTE makes one
+    of them stay silent (as if it had never been scheduled): the others give up after ~2 s, every workgroup leaves, and the order
+    that comes back is the identity - the arrival order, with which the route is still exact.  (A child process: the switch is
+    read once per process.)"""
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, time; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "from bayesian_optimisation_amd import DeviceGP\n"
+        "from bayesian_optimisation_amd.synthetic import make_problem\n"
+        "X, y, Xs, ls = make_problem(9000, 40000, 4)\n"
+        "t = time.time(); gp = DeviceGP(chunk=8192).factorise(X, y, ls, order='fps'); torch.cuda.synchronize(); dt = time.time() - t\n"
+        "perm = gp.perm.cpu().numpy()\n"
+        "rb, r64 = gp.score_bound(Xs), gp.score(Xs)\n"
+        "print('RESULT', bool(np.array_equal(perm, np.arange(9000))), rb.best_idx == r64.best_idx, round(dt, 2))\n" % repo)
+    env = dict(os.environ, GPBO_FPS_MUTE="3")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    assert line[1] == "True" and line[2] == "True", out.stdout
+    assert float(line[3]) < 60.0
+    # and without the switch the same call gives the farthest-point order
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env={k: v for k, v in os.environ.items() if k != "GPBO_FPS_MUTE"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    assert line[1] == "False" and line[2] == "True" and float(line[3]) < 20.0, out.stdout
