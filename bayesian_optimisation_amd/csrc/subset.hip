@@ -164,7 +164,7 @@ __global__ __launch_bounds__(TH) void fps_coop_kernel(const double *__restrict__
     for (int64_t s = 0; s <= J; ++s) {   // sweep s folds member s - 1 in (s = 0: distances to the centroid) and picks member s
         const int64_t member = s_member;
         double bv = ninf;
-        int bi32 = 0x7fffffff;   // (N <= 1024 PTS G <= 65,536 here: the index fits 32 bits)
+        int bi32 = 0x7fffffff;   // (N <= TH x PTS x 16 <= 65,536 here: the index fits 32 bits)
         int bq = 0;
 #pragma unroll
         for (int q = 0; q < PTS; ++q) {

@@ -74,6 +74,18 @@ def test_host_call_without_dense_outputs_takes_the_exact_prefix_bound_and_return
     assert (only["best_idx"], only["best_val"]) == (full["best_idx"], full["best_val"])
 
 
+def test_failed_factorisation_is_reported_by_the_callers_row_in_either_order():
+    """An observation with a NaN coordinate: the covariance matrix has a NaN pivot in that row, nothing is scored
+    (best_idx = -1) and info names the row - the CALLER's row, also when the call had put the observations in
+    farthest-point order for the exact bound (no dense outputs)."""
+    X, y, Xs, ls = make_problem(1300, 40000, 5)
+    X = X.copy()
+    X[777, 2] = np.nan
+    for dense in (True, False):
+        r = H.select_next(X, y, ls, Xs, dense=dense)
+        assert r["info"] == 778 and r["best_idx"] == -1, (dense, r["info"])
+
+
 @pytest.mark.parametrize("name", ["g1_m32", "g1_m50", "g4_ard_n2", "g2_n1_tr", "g2_n5_a", "g2_n20_tr", "g3_n1_2d",
                                   "g10_2d_0", "g10_2d_1", "g10_2d_3", "g10_2d_4", "g10_1d_0", "g10_1d_2"])
 def test_host_class_full_path_with_ard_vs_reference_golden(golden, name):
