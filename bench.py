@@ -264,8 +264,12 @@ def kernel_rooflines(gp, N, d, dtype, qei=False, event_stride=1):
         if q_launches:
             q_avg = q_ms / q_launches
             gbs = 8.0 * N * (q_cands / q_launches) / (q_avg * 1e-3) / 1e9
+            eq, stale_q = _pmc_entry(N, d, dtype, q_cands / q_launches)
             qei_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=round(gbs / HBM_PEAK_GBS, 4), kernel="qei_kernel", launches=int(q_launches),
+                                traffic=(eq or {}).get("qei_hbm_bytes_per_launch"), traffic_stale=stale_q,
+                                traffic_source=(f"committed PMC pass {eq['source']} (FETCH_SIZE x2 + WRITE_SIZE), not this run"
+                                                if eq and "qei_hbm_bytes_per_launch" in eq else None),
                                 avg_launch_ms=round(q_avg, 4), bytes_per_candidate=8.0 * N,
                                 note="algorithmic bytes = the rows of V the stage reads (8 N per candidate); 36 N / 8 flop "
                                      "per candidate + S x 44 / 8 beside them")

@@ -34,7 +34,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 keep = ("sigma_acq_kernel", "kstar_mu_kernel", "sigma_acq_f32_kernel", "sigma_i8_kernel", "sigma_i8c_kernel", "kstar_slices_kernel", "kstar_mu_mfma_kernel", "bound_select_kernel",
         "split_finish_kernel", "u_slices_kernel", "u_colscale_kernel", "potrf_diag_kernel", "gemm_f64_kernel", "kxx_kernel", "utv_kernel",
-        "uv_kernel", "cholinv_kernel", "transpose_w_kernel", "fps_kernel", "gather_obs_kernel")
+        "uv_kernel", "cholinv_kernel", "transpose_w_kernel", "fps_coop_kernel", "gather_obs_kernel", "qei_kernel")
 with open(os.path.join(here, f"{out}_pmc_summary.csv"), "w") as fo:
     fo.write("# rocprofv3 --pmc passes (one pass per counter group, profiles/collect.sh), bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also,\n")
     fo.write(f"# MI355X; per-launch means; a sigma/kstar launch = one chunk of {cands} candidates, N={N}, d={d}, {dtype}\n")
@@ -77,6 +77,11 @@ if "SQ_INSTS_VALU" in ks:
     # the K(X*,X) build beside its stores: vector instructions issued per launch (wave instructions; x64 = lane instructions)
     shapes[f"N={N},d={d},dtype={dtype},candidates_per_launch={cands}"]["kstar_valu_wave_instructions_per_launch"] = \
         sum(ks["SQ_INSTS_VALU"]) / len(ks["SQ_INSTS_VALU"])
+qk = agg.get("qei_kernel", {})
+if "FETCH_SIZE" in qk and "WRITE_SIZE" in qk:
+    # the qEI stage of BASELINE config 5: HBM bytes per launch (its algorithmic bytes: the rows of V, 8 N per candidate)
+    shapes[f"N={N},d={d},dtype={dtype},candidates_per_launch={cands}"]["qei_hbm_bytes_per_launch"] = \
+        sum(qk["FETCH_SIZE"]) / len(qk["FETCH_SIZE"]) * 1024 * 2 + sum(qk["WRITE_SIZE"]) / len(qk["WRITE_SIZE"]) * 1024
 json.dump(shapes, open(path, "w"), indent=1)
 if len(sys.argv) > 3:
     line = [l for l in open(sys.argv[3]) if l.startswith("{")][-1]
