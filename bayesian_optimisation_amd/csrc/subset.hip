@@ -256,7 +256,7 @@ __global__ __launch_bounds__(TH) void fps_coop_kernel(const double *__restrict__
                     }
                     if (__all(ok)) break;
                     if (++polls > FPS_MAX_POLLS) { timed_out = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(1);   // (polling without it: no difference, 2.97 against 2.99 us per member)
                 }
                 // winner over the slots (uniform arithmetic on values read from lanes 0 .. 2), then its coordinates
                 double gv = ninf;
