@@ -25,8 +25,8 @@
 // form's is ABSOLUTE: every one of the d + 2 fused steps rounds at the size of the partial sum, <= 2 (|a|^2 + |b|^2), so
 //     |dt_ci| <= gamma (|a_c|^2 + |b_i|^2),   gamma = 2 (2 (d + 2) + 8) 2^-53   (inputs' own roundings included, x2 to spare)
 // and since |dk| <= k |dt| and k <= 1, the mean  mu_c = sum_i k_ci alpha_i  is off by at most
-//     slack_c = gamma (|a_c|^2 S0 + S1) + eps_exp S0,      S0 = sum_i |alpha_i|,   S1 = sum_i |alpha_i| |b_i|^2
-// (eps_exp: the error of this file's shorter exp, see exp_neg_m)
+//     slack_c = gamma (|a_c|^2 S0 + S1) + (eps_exp + eps_acc) S0,      S0 = sum_i |alpha_i|,   S1 = sum_i |alpha_i| |b_i|^2
+// (eps_exp: the error of this file's shorter exp, see exp_neg_m; eps_acc: the rounding of the two kernels' summations)
 // (N = 4096 benchmark problem: S0 = 7.8e4, slack ~ 1e-9; the 5e-15 entry bound of tests/test_kstar_mu cannot be met).
 // The prefix-bound route only needs mu from BELOW (both acquisitions decrease with the mean): this kernel reports
 // mu_c - slack_c, so the upper bound it feeds stays an upper bound; the entries it stores (first `store_rows` observations)
@@ -131,6 +131,11 @@ __device__ const double kExp2TabM[256] = {
 // the EXP_ABS_ERR / EXP_REL_ERR that the caller adds to its slack.  19 instead of 25 VALU instructions per pair with the
 // clamp below instead of the compare-and-select pair.
 constexpr double EXP_REL_ERR = 4.0 * 1.1102230246251565e-16, EXP_ABS_ERR = 1e-16;
+// Round 4: the SUMMATION of the mean is rounded too - here (64 products per lane, two shuffles, Np / 256 partials) and in the
+// plain pass this mean must stay below (kstar_mu_kernel: 64 products per slice, Np / 64 partials).  |fl(sum) - sum| <=
+// n 2^-53 sum |terms| <= n 2^-53 S0 for each chain of n additions: eps_acc = (2 x 64 + 4 + Np / 64 + Np / 256) x 2^-53 x 2
+// (gpbo_kstar_mu_mfma).  Without it the report "from below" rested on the distance term alone, which vanishes for a
+// candidate at the centroid of observations that all lie within a length scale of it.
 __device__ __forceinline__ double exp_neg_m(double t, const double *tab) {
     const double z = fma(-t, 369.3299304675746, 6755399441055744.0);
     const int ni = __double2loint(z);
@@ -220,6 +225,7 @@ template <int KQ /* ceil(d / 4): MFMAs per 16 x 16 pairs */>
 __global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__restrict__ Xs, int64_t Mc, int d, IscArgs ls,
                                                             const double *__restrict__ Bp, const ObsPrep *__restrict__ prep,
                                                             const double *__restrict__ alpha, int N, double gamma,
+                                                            double eps_acc /* rounding of the means' summations */,
                                                             double *__restrict__ KsT, int64_t ldk,
                                                             double *__restrict__ mu_part, int store_rows,
                                                             int OB /* observations per workgroup = per mean partial */,
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__rest
         // such a candidate is reported like a NaN one here - its bound is NaN, so it always survives to the fp64 kernels
         bad = bad || !(na < __builtin_inf());
         nac[tc] = na;
-        slack[tc] = gamma * fma(na, prep->S0, prep->S1) + (EXP_REL_ERR + EXP_ABS_ERR) * prep->S0;
+        slack[tc] = gamma * fma(na, prep->S0, prep->S1) + (EXP_REL_ERR + EXP_ABS_ERR + eps_acc) * prep->S0;
         isnan_c[tc] = bad;
     }
     __syncthreads();
@@ -372,6 +378,7 @@ int gpbo_kstar_mu_mfma(const double *Xs, int64_t Mc, int64_t N, int64_t Np, int3
     for (int k = 0; k < d; ++k) ls.isc[k] = 1.0 / (ls_host[k] * 1.4142135623730950488);
     const int KQ = (d + 3) / 4, KP = (d + 2 + 3) / 4 * 4;
     const double gamma = 2.0 * (2.0 * (d + 2) + 8.0) * 1.1102230246251565e-16;   // 2^-53
+    const double eps_acc = 2.0 * (2.0 * 64.0 + 4.0 + (double)(Np / 64) + (double)(Np / 256)) * 1.1102230246251565e-16;
     const double *Bp = reinterpret_cast<const double *>(prep_buf);
     const ObsPrep *prep = reinterpret_cast<const ObsPrep *>(reinterpret_cast<const char *>(prep_buf) +
                                                             align_up((int64_t)sizeof(double) * Np * KP_MAX, 256));
@@ -380,7 +387,7 @@ int gpbo_kstar_mu_mfma(const double *Xs, int64_t Mc, int64_t N, int64_t Np, int3
     dim3 grid((unsigned)(used / 256), (unsigned)(Np / OB));
 #define GPBO_KM_LAUNCH(Q)                                                                                              \
     hipLaunchKernelGGL((kstar_mu_mfma_kernel<Q>), grid, dim3(256), 0, gpbo_stream(stream), Xs, Mc, (int)d, ls, Bp, prep, alpha, \
-                       (int)N, gamma, KsT, ldk, mu_part, (int)store_rows, OB, KP)
+                       (int)N, gamma, eps_acc, KsT, ldk, mu_part, (int)store_rows, OB, KP)
     switch (KQ) {
         case 1: GPBO_KM_LAUNCH(1); break;
         case 2: GPBO_KM_LAUNCH(2); break;

@@ -494,7 +494,7 @@ def _ill_conditioned(N, M, d, seed):
     return X, y, Xs, ls
 
 
-@pytest.mark.parametrize("problem", ["sobol", "raw_1e3", "raw_5e4", "tiny_ls", "ill_conditioned", "sorted_history"])
+@pytest.mark.parametrize("problem", ["sobol", "raw_1e3", "raw_5e4", "tiny_ls", "ill_conditioned", "sorted_history", "tight_cluster"])
 def test_shipping_bound_holds_for_every_candidate_at_both_levels(problem):
     """factorise(order="fps") + gpbo_posterior_prefix_f64 at J = 128 / 256 / 1024 (the first level of N = 2048 / 4096 and
     the second level of N = 4096) and J = N/4 (this problem's second level): sigma_ub >= sigma and acq_ub >= acq of the plain
@@ -518,6 +518,15 @@ def test_shipping_bound_holds_for_every_candidate_at_both_levels(problem):
         X, y, Xs, ls = _ill_conditioned(N, M, d, 5)
         K = O.kernel_rbf(X, X, ls) + 1e-6 * np.eye(N)
         assert np.linalg.cond(K) > 3e6
+    elif problem == "tight_cluster":
+        # every observation and candidate within a hundredth of a length scale of one point: k ~ 1 everywhere, the mean is a
+        # sum of N terms of size |alpha_i| that cancel to O(1), and the expanded distance's slack term (|a|^2 S0 + S1)
+        # vanishes - what keeps the first pass's mean BELOW the plain pass's is the summation term of its slack (round 4)
+        X = 0.5 + 0.01 * rng.uniform(-1, 1, (N, d))
+        Xs = 0.5 + 0.01 * rng.uniform(-1, 1, (M, d))
+        Xs[:300] = X[:300]
+        ls = np.full(d, 1.0)
+        y = np.sin(40 * X[:, 0]) + X[:, 1:].sum(1)
     else:
         X, y, Xs, ls = make_problem(N, M, d)
         o = np.argsort(X[:, 0])
