@@ -122,3 +122,41 @@ def test_bad_pivot_is_reported(env):
     A[200, 200] = -1.0  # the Schur complement at column 201 cannot be positive
     _, info = run_gpu(env, A)
     assert info == 201
+
+
+@pytest.mark.parametrize("N", [16384, 32768 + 200])
+def test_factorise_at_sizes_no_other_test_reaches(N):
+    """N = 16,384: the fused sweep with 128 pairs and far rank 384 (LAPACK on the host would take minutes: the inverse factor is
+    checked by probing U^T K U = I with random vectors on the device).  N = 32,968: beyond the fused plan's cap (Np <= 32,768)
+    gpbo_factorise_f64 must fall back to the two-pass chain (it used to return an argument error), same check."""
+    import torch
+
+    from bayesian_optimisation_amd import DeviceGP
+
+    rng = np.random.default_rng(N)
+    d = 3
+    X = rng.uniform(0, 1, (N, d))
+    ls = np.full(d, 0.05)          # short length scales: K is far from singular at any N, the check is about the kernels
+    y = rng.standard_normal(N)
+    gp = DeviceGP().factorise(X, y, ls)
+    assert int(gp.info.item()) == 0 and gp.Np == (N + 127) // 128 * 128
+    K, U = gp.K[:N, :N], gp.U[:N, :N]
+    assert torch.equal(torch.tril(U, -1), torch.zeros_like(U))
+    g = torch.Generator(device="cpu").manual_seed(N)
+    Z = torch.randn(N, 4, dtype=torch.float64, generator=g).to(gp.device)
+    R = U.T @ (K @ (U @ Z)) - Z                      # (U^T K U - I) Z
+    assert float(R.abs().max()) <= 1e-9 * float(Z.abs().max()) * max(1.0, float(U.abs().max()))
+    alpha = gp.alpha[:N]
+    yd = gp._dev(y)
+    assert float((K @ alpha - yd).abs().max()) <= 1e-8 * max(1.0, float(alpha.abs().max()))
+    del K, U, Z, R
+    # and the posterior of a few candidates against the oracle's formula evaluated with torch (no host factorisation)
+    Xs = rng.uniform(0, 1, (2000, d))
+    r = gp.score(Xs, dense=True)
+    Xd, Xsd = gp._dev(X), gp._dev(Xs)
+    ks = torch.exp(-0.5 * (((Xsd[:, None, :] - Xd[None, :, :]) / gp._dev(ls)) ** 2).sum(-1))
+    mu = ks @ alpha
+    assert float((r.mu - mu).abs().max()) <= 1e-9 * max(1.0, float(np.abs(y).max()))
+    v = gp.U[:N, :N].T @ ks.T
+    var = 1.000101 - (v * v).sum(0)
+    assert float((r.sigma - var.abs().sqrt()).abs().max()) <= 1e-8
