@@ -139,3 +139,34 @@ def test_config5_full_size_qei_n2048_m2e20():
     top2 = np.sort(ref)[-2:]
     if top2[1] - top2[0] > 1e-7:
         assert batches[_first_argmax(ref)] == r.best_idx
+
+
+@pytest.mark.parametrize("N,M,d", [(4096, 1 << 21, 8), (8192, 1 << 19, 16)])
+def test_exact_bound_at_the_per_gpu_full_size_of_configs_3_and_4(N, M, d):
+    """The route bench.py --dtype f64b times (farthest-point-ordered factorisation + two bound levels + the fp64 kernels on the
+    survivors) at the full per-GPU size: the same index and NaN count as the plain pass of the SAME factorisation and as the
+    plain pass of the arrival-order one, for LCB and EI, as one call and as 8 shards reduced; no fall-back; and the
+    candidates it prunes really are below the maximum (the dense acquisition of the plain pass is at hand)."""
+    X, y, Xs, ls = make_problem(N, M, d)
+    gp = DeviceGP(chunk=1 << 17).factorise(X, y, ls, order="fps")
+    ga = DeviceGP(chunk=1 << 17).factorise(X, y, ls)
+    Xsd = gp._dev(Xs)
+    f_best = float(y.min())
+    for kw in (dict(acquisition="lcb", explore=4.0), dict(acquisition="ei", f_best=f_best, xi=0.0)):
+        full = gp.score(Xsd, dense=True, **kw)
+        acq = full.acq.cpu().numpy()
+        rb = gp.score_bound(Xsd, **kw)
+        st = dict(gp.last_screen)
+        assert not st["fallback"] and st["order"] == "fps" and st["rescored"] < M // 16, st
+        assert rb.best_idx == full.best_idx == _first_argmax(acq) and rb.nan_count == 0
+        assert abs(rb.best_val - full.best_val) <= 1e-12 * max(1.0, abs(full.best_val))
+        assert ga.score(Xsd, **kw).best_idx == rb.best_idx
+        recs = []
+        for rank in range(8):
+            lo, hi = D.shard_bounds(M, 8, rank)
+            rr = gp.score_bound(Xsd[lo:hi], idx_offset=lo, **kw)
+            recs.append((rr.best_val, rr.best_idx, rr.nan_count))
+        assert D.reduce_records(recs)[1] == rb.best_idx
+        # the threshold the route ended with is an exact value: nothing above it was left unscored
+        assert st["threshold"] <= acq.max() + 1e-12 * max(1.0, abs(acq.max()))
+        del full
