@@ -623,6 +623,75 @@ def test_dropin_sharded_at_m_2e22_gathers_the_dense_outputs_as_tensors():
         assert idx == ref_idx and h == ref_h and tuple(shape) == (1 << 22,)
 
 
+def _sharded_select_only_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, y, Xs, ls = make_problem(1500, 90000, 5)
+        X = X[np.argsort(X[:, 0])]           # a sorted history: the arrival prefix would prune little
+        ps = PointSelector(dense_outputs=False)
+        ps.measured_pts, ps.measured_vals = X, y
+        ps.feature_domain, ps.predicted_pts = [300, 300], Xs
+        ps.set_kernel_params(ls)
+        ps.update_surrogate()
+        i4 = ps.lower_confidence_bound().tolist()
+        scr = dict(ps._gp.last_screen)
+        ie = ps.expected_improvement().tolist()
+        perm = ps._gp.perm.cpu().numpy()
+        q.put((rank, i4, ie, scr["mode"], scr["order"], bool(scr["fallback"]), int(scr["candidates"]), perm[:8].tolist(),
+               ps.mean_func is None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_next_point_only_sharded_over_two_ranks():
+    """PointSelector(dense_outputs=False) with the candidates sharded over two ranks (gloo, both on the one GPU): every rank
+    puts the observations in the same farthest-point order (the selection is deterministic), bounds its own 45,000
+    candidates, and the one exchange step gives both the single process's multi-index - for LCB and EI."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    X, y, Xs, ls = make_problem(1500, 90000, 5)
+    X = X[np.argsort(X[:, 0])]
+    ref = PointSelector()
+    ref.measured_pts, ref.measured_vals = X, y
+    ref.feature_domain, ref.predicted_pts = [300, 300], Xs
+    ref.set_kernel_params(ls)
+    ref.update_surrogate()
+    want4 = ref.lower_confidence_bound().tolist()
+    wante = ref.expected_improvement().tolist()
+    one = PointSelector(dense_outputs=False)
+    one.measured_pts, one.measured_vals = X, y
+    one.feature_domain, one.predicted_pts = [300, 300], Xs
+    one.set_kernel_params(ls)
+    one.update_surrogate()
+    assert one.lower_confidence_bound().tolist() == want4 and one._gp.order == "fps"
+    perm_ref = one._gp.perm.cpu().numpy()[:8].tolist()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_select_only_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, i4, ie, mode, order, fallback, cands, perm8, no_dense in res:
+        assert i4 == want4 and ie == wante
+        assert mode == "bound" and order == "fps" and not fallback and cands == 45000 and no_dense
+        assert perm8 == perm_ref
+
+
 def test_dropin_q_expected_improvement():
     X, y, Xs, ls = make_problem(30, 1600, 2)
     ps = PointSelector()
