@@ -183,3 +183,52 @@ def test_point_selector_refreshes_after_many_appended_columns(monkeypatch):
         ps.update_surrogate()
         seen.append(ps.last_update)
     assert seen == ["factorise", "append", "append", "append", "factorise", "append", "append"]
+
+
+def test_next_point_only_selector_keeps_its_ordered_factorisation_across_jobs(tmp_path):
+    """PointSelector(dense_outputs=False, state_path=...): the first job factorises the observations in farthest-point order
+    and saves that state (order included); the next jobs - new objects, a few more rows in the CALLER's order - recognise the
+    old rows through the permutation, append, and select what a stateless full-evaluation object selects; a dense job that
+    hits the N == M quirk with such a state refactorises in arrival order instead of appending."""
+    from bayesian_optimisation_amd import PointSelector
+
+    rng = np.random.default_rng(15)
+    d, n0 = 3, 1100
+    X = rng.uniform(0, 1, (n0 + 3, d))
+    X[:n0] = X[:n0][np.argsort(X[:n0, 0])]                       # a sorted history
+    y = np.sin(5 * X[:, 0]) * np.cos(3 * X[:, 1]) + X[:, 2] + 0.01 * rng.standard_normal(n0 + 3)
+    g = 34
+    axes = [np.linspace(0, 1, g)] * d
+    Xs = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, d)   # 39,304 candidates
+    ls = np.array([0.2, 0.3, 0.5])
+    path = str(tmp_path / "ordered_state.npz")
+
+    def run(ps, n):
+        ps.name, ps.iteration = "t", n
+        ps.measured_pts, ps.measured_vals = X[:n].copy(), y[:n].copy()
+        ps.feature_domain, ps.predicted_pts = [g] * d, Xs
+        ps.set_kernel_params(ls)
+        ps.update_surrogate()
+        return ps.lower_confidence_bound(), ps.expected_improvement()
+
+    for n, want in [(n0, "factorise"), (n0 + 1, "append"), (n0 + 3, "append")]:
+        job = PointSelector(dense_outputs=False, state_path=path)   # a fresh object per job, as in the DAG
+        i4, ie = run(job, n)
+        assert job.last_update == want and job._gp.order == "fps" and job._gp.last_screen["mode"] == "bound"
+        plain = PointSelector()
+        p4, pe = run(plain, n)
+        assert np.array_equal(i4, p4) and np.array_equal(ie, pe)
+        Xa, ya = job._gp.observations_host()
+        assert np.array_equal(Xa, X[:n]) and np.array_equal(ya, y[:n])
+    st = dict(np.load(path))
+    assert "perm" in st and len(st["perm"]) == n0 + 3 and st["perm"][-1] == n0 + 2
+    # a dense job whose candidates have the observations' shape (the N == M quirk): the ordered state cannot serve it
+    quirk = PointSelector(state_path=path)
+    Xq = rng.uniform(0, 1, (n0 + 4, d))
+    quirk.name, quirk.iteration = "t", 0
+    quirk.measured_pts = np.concatenate([X[:n0 + 3], rng.uniform(0, 1, (1, d))])
+    quirk.measured_vals = np.concatenate([y[:n0 + 3], [0.3]])
+    quirk.feature_domain, quirk.predicted_pts = [n0 + 4], Xq
+    quirk.set_kernel_params(ls)
+    quirk.update_surrogate()
+    assert quirk.last_update == "factorise" and quirk._gp.order == "arrival"
