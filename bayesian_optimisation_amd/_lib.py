@@ -46,6 +46,7 @@ SIGNATURES = {
     "gpbo_select_qei_host_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _f64, _f64, _p, _i64, _f64, _f64, _p, _i32, _i64, _p,
                                            _p, _p]),
     "gpbo_nlml_grid_host_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p]),
+    "gpbo_nlml_grid_logdet_host_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p]),
     "gpbo_append_workspace_bytes": (_i64, [_i64]),
     "gpbo_append_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _f64, _f64, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "gpbo_scale_points_f64": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "gpbo_nlml_grid_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p, _p]),
     "gpbo_nlml_grid_batched_workspace_bytes": (_i64, [_i64, _i64]),
     "gpbo_nlml_grid_batched_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p, _p, _i64, _p]),
+    "gpbo_nlml_grid_batched_logdet_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p, _p, _i64, _p]),
     "gpbo_nlml_cell_f64": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p, _p]),
     "gpbo_gemm_f64": (C.c_int, [_i32, _i64, _i64, _i64, _f64, _p, _i64, _i64, _p, _i64, _i64, _f64, _p, _i64, _i64,
                                 _i32, _i32, _p]),

@@ -11,6 +11,8 @@
 // and log det K = 2 sum log L_ii.  NumPy's det is sign * exp(logdet) (LAPACK getrf), so the reference's
 // underflow of det to 0 (-> -inf cells for N >~ 100) is reproduced by evaluating log(exp(logdet)).
 #include "gpbo_internal.h"
+#include "exp_neg.h"
+#include "potrf_diag64.h"
 
 #include <cmath>
 #include <limits>
@@ -116,131 +118,373 @@ __global__ __launch_bounds__(256) void nlml_cell_kernel(const double *__restrict
     }
 }
 
-// ---- any N: all cells of a batch through one blocked Cholesky (factor.hip, gpbo_potrf_batched) ----------------------
-// Cell g owns a bordered matrix [Ne x Ne], Ne = 64 ceil(N/64) + 64:
-//     rows/cols < N            k(x_i, x_j) with the cell's length scales, + jitter on the diagonal
-//     rows N .. Nf-1           identity (padding of the factorised part, Nf = 64 ceil(N/64))
-//     row  Nf                  y^T (columns < N), zero elsewhere: after Nf columns of the factorisation it holds
-//                              (L^-1 y)^T and entry (Nf, Nf) holds -y^T K^-1 y - the bordered-matrix identity the
-//                              in-LDS kernel above uses, here carried by the panel solve / trailing update GEMMs
-//     rows > Nf                identity, never factorised.
-// grid (Ne/256 up, Ne/8, cells), block 256: thread = column, 8 rows per workgroup (as kxx_kernel).
+// ---- any N: one workgroup per grid cell, the whole factorisation in ONE launch (round 5) ------------------------------
+// Left-looking blocked Cholesky of the cell's K, 64 columns (one PANEL) at a time, K's entries generated on the fly:
+//     C' = K[rows, panel]^T - L[panel rows, :J0] L[rows, :J0]^T      matrix cores, operands straight from memory
+//     D  = C' of the panel's own 64 rows -> L_jj, W = inv(L_jj)       potrf_diag64_lds (LDS)
+//     L[rows below, panel]^T = W C'                                   matrix cores, A operand from LDS, B = the accumulators
+// y rides along as one more row (the bordered matrix of nlml_grid_kernel): its row of L is z^T = (L^-1 y)^T, and
+// y^T K^-1 y = |z|^2.  log det K = 2 sum log L_ii.
+//
+// Everything is computed TRANSPOSED (C'[panel column][row]) because of how v_mfma_f64_16x16x4_f64 lays its operands out:
+// register r of lane l of a result tile is C'[(l >> 4) + 4r][l & 15], which is exactly what lane l must supply as the B
+// operand of k-group r - so the accumulators of the first product ARE the B operands of the second, and the second product's
+// accumulators ARE the fragments later panels load as operands.  Nothing is transposed through LDS, and L lives in memory
+// in FRAGMENT ORDER:   frag(rt, kg)[lane] = L[16 rt + (lane & 15)][4 kg + (lane >> 4)], two k-groups interleaved per lane
+// (one 16-byte load / store per lane, 1 KiB contiguous per wave instruction).
+// The workgroup is persistent (cells g = blockIdx.x, + gridDim.x, ...) and owns one scratch slot of (Nf + 16) x Nf
+// doubles, written once and read (N / 64) / 3 times on average per cell - the matrices of the launch-chain version of
+// rounds 2-4 (up to 8 GiB per sub-batch, swept once per panel by three launches) are gone.
+namespace fused {
+
+constexpr int TH = 256;                 // 4 waves; two workgroups per CU (LDS), up to 256 registers per lane
+constexpr int WAVES = TH / 64;
+constexpr int LDM = gpbo_pd::LDM;       // 66
+constexpr int SLOTS = 512;              // workgroups of one launch = scratch slots (2 per CU on 256 CUs)
+constexpr int DMAX = 16;                // widest feature bucket (GPBO_MAX_D)
+constexpr int64_t WORK_CAP = 16ll << 30;
+
+// what depends on the value is recomputed where it is used instead of being kept in registers across the whole kernel
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// The elimination of the diagonal block as a real call (M sits at the start of the dynamic LDS): inlined into the
+// persistent loops, its lane masks and per-lane addresses were hoisted to the kernel's entry and held there; a call
+// costs one save of the accumulators per panel.
+__device__ __attribute__((noinline)) int potrf_panel_call() {
+    extern __shared__ double smem_[];
+    return gpbo_pd::potrf_diag64_lds(smem_, threadIdx.x);
+}
+
 template <int D>
-__global__ __launch_bounds__(256) void nlml_build_kernel(const double *__restrict__ X, const double *__restrict__ y, int N,
-                                                         int Nf, int Ne, const double *__restrict__ ls_cells,
-                                                         double jitter, double *__restrict__ Ab,
-                                                         int32_t *__restrict__ info) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int64_t g = blockIdx.z;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) info[g] = 0;
-    if (j >= Ne) return;
-    const double *ls = ls_cells + g * D;
-    double il2[D], xj[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        il2[k] = 1.0 / (ls[k] * ls[k]);
-        xj[k] = (j < N) ? X[(int64_t)j * D + k] : 0.0;
-    }
-    double *A = Ab + g * (int64_t)Ne * Ne;
-    const int i0 = blockIdx.y * 8;
-    for (int i = i0; i < i0 + 8; ++i) {
-        double v;
-        if (i < N && j < N) {
-            double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const double diff = xj[k] - X[(int64_t)i * D + k];
-                acc = fma(diff * diff, il2[k], acc);
-            }
-            v = exp(-0.5 * acc);
-            if (i == j) v += jitter;
-        } else if (i == Nf) {
-            v = (j < N) ? y[j] : 0.0;
+struct Lds {
+    double M[2 * 64 * LDM];   // [D_jj ; I] -> [L_jj ; L_jj^-T]
+    double Xc[64 * D];        // coordinates of the panel's 64 columns
+    double yc[64];            // y of the panel's columns
+    double tab[GPBO_EXP_E];   // exp_neg's table
+    double red[2 * WAVES];    // final reductions
+    int bad;
+};
+
+// Padded inputs, once per call: Xp [(Nf + 16) x D] (features beyond d and rows beyond N are zero), yp [Nf],
+// il2p [G x D] = 1 / l^2 (0 for the padded features: they add fma(0, 0, acc) = acc to a distance).
+__global__ __launch_bounds__(256) void nlml_prep_kernel(const double *__restrict__ X, const double *__restrict__ y, int N,
+                                                        int d, int D, int Nf, const double *__restrict__ ls_cells,
+                                                        int64_t G, double *__restrict__ Xp, double *__restrict__ yp,
+                                                        double *__restrict__ il2p) {
+    const int64_t nx = (int64_t)(Nf + 16) * D, nl = G * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nx + Nf + nl; e += (int64_t)gridDim.x * 256) {
+        if (e < nx) {
+            const int64_t r = e / D;
+            const int k = (int)(e - r * D);
+            Xp[e] = (r < N && k < d) ? X[r * d + k] : 0.0;
+        } else if (e < nx + Nf) {
+            const int64_t r = e - nx;
+            yp[r] = (r < N) ? y[r] : 0.0;
         } else {
-            v = (i == j) ? 1.0 : 0.0;
+            const int64_t q = e - nx - Nf, g = q / D;
+            const int k = (int)(q - g * D);
+            double v = 0.0;
+            if (k < d) {
+                const double l = ls_cells[g * d + k];
+                v = 1.0 / (l * l);
+            }
+            il2p[q] = v;
         }
-        A[(int64_t)i * Ne + j] = v;
     }
 }
 
-// one workgroup per cell: log det K = 2 sum log L_ii, y^T K^-1 y = -A[Nf][Nf]; NaN when a pivot failed
-__global__ __launch_bounds__(256) void nlml_finish_kernel(const double *__restrict__ Ab, int N, int Nf, int Ne,
-                                                          const int32_t *__restrict__ info, float *__restrict__ out) {
-    __shared__ double s_ld[256];
-    const int tid = threadIdx.x;
-    const double *A = Ab + (int64_t)blockIdx.x * Ne * Ne;
-    double ld = 0.0;
-    for (int i = tid; i < N; i += 256) ld += log(A[(int64_t)i * Ne + i]);
-    s_ld[tid] = ld;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) s_ld[tid] += s_ld[tid + off];
+// MODE 0: the reference's likelihood, float32, log(exp(logdet)) (point_selector.py:117-119: np.log(np.linalg.det(K)));
+// MODE 1: fp64, log det straight from the factor (no underflow), NaN when a pivot fails.
+template <int D, int MODE>
+__global__ __launch_bounds__(TH, 2) void nlml_fused_kernel(const double *__restrict__ Xp, const double *__restrict__ yp, int N,
+                                                         int Nf, const double *__restrict__ il2p, int G, double jitter,
+                                                         void *__restrict__ out_, double *scratch) {
+    extern __shared__ double smem_[];
+    Lds<D> &S = *reinterpret_cast<Lds<D> *>(smem_);
+    const int tid0 = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int KP = Nf >> 3;            // k-group pairs per row tile
+    const int RTY = Nf >> 4;           // the row tile that carries y (row 0 of it)
+    const int nbf = Nf >> 6;
+    d2_t *Lf = reinterpret_cast<d2_t *>(scratch) + (int64_t)blockIdx.x * (int64_t)(RTY + 1) * KP * 64;
+
+    if (tid0 < GPBO_EXP_E) S.tab[tid0] = kExp2Tab256[tid0 * (256 / GPBO_EXP_E)];
+
+    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        __syncthreads();   // the previous cell's reductions have been read
+        double il2[D];     // wave-uniform (scalar loads)
+#pragma unroll
+        for (int k = 0; k < D; ++k) il2[k] = il2p[(int64_t)g * D + k];
+        if (tid0 == 0) S.bad = 0;
+        double logdet_t = 0.0, quad_t = 0.0;
+
+        for (int j = 0; j < nbf; ++j) {
+            const int J0 = j << 6;
+            // (opaque: lane masks and per-lane addresses are recomputed per panel, not kept in registers across the kernel)
+            const int tid = opaque(tid0);
+            const int lane = tid & 63, l15_ = lane & 15, l4_ = lane >> 4;
+            // the panel's columns: coordinates, y; the identity under the diagonal block
+            for (int e = tid; e < 64 * D; e += TH) S.Xc[e] = Xp[(int64_t)J0 * D + e];
+            if (tid < 64) S.yc[tid] = yp[J0 + tid];
+            for (int e = tid; e < 64 * 64; e += TH) S.M[(64 + (e >> 6)) * LDM + (e & 63)] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+            __syncthreads();
+
+            // rows of the panel in blocks of 32 (two row tiles): blocks 0, 1 = the diagonal block, block nblk = y's tile.
+            // Wave w takes blocks w, w + 4, ...; the elimination of the diagonal block sits between the two products of
+            // every wave's FIRST block (all waves pass through iteration 0, with or without a block).
+            const int nblk = (Nf - J0) >> 5;
+            const int jt0 = J0 >> 4;
+            const int nkp = J0 >> 3;
+            for (int it = 0;; ++it) {
+                const int b = w + WAVES * it;
+                const bool has = (b <= nblk);
+                if (it > 0 && !has) break;
+                const bool yblk = (b == nblk);
+                const int rt0 = jt0 + 2 * b;
+                const int rt1 = yblk ? rt0 : rt0 + 1;       // y's block has one tile (computed twice, stored once)
+                d4_t acc[4][2];
+                if (has) {
+                    // ---- C' = K^T - L_j L_b^T: operands straight from memory, the next k-group pair in flight ----
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) { acc[ct][0] = d4_t{0.0, 0.0, 0.0, 0.0}; acc[ct][1] = d4_t{0.0, 0.0, 0.0, 0.0}; }
+                    if (nkp > 0) {
+                        const d2_t *pa = Lf + ((int64_t)jt0 * KP) * 64 + lane;    // + ct * KP * 64
+                        const d2_t *pb0 = Lf + ((int64_t)rt0 * KP) * 64 + lane;
+                        const d2_t *pb1 = Lf + ((int64_t)rt1 * KP) * 64 + lane;
+                        const int64_t sa = (int64_t)KP * 64;
+                        // two register sets in turn (nkp is a multiple of 8): the loads of one pair are in flight while the
+                        // sixteen products of the other issue; the scheduling barriers keep that order
+                        struct Frag { d2_t f0, f1, f2, f3, g0, g1; } A, B;
+                        auto load = [&](Frag &F, int k) {
+                            F.f0 = pa[k * 64]; F.f1 = pa[sa + k * 64]; F.f2 = pa[2 * sa + k * 64]; F.f3 = pa[3 * sa + k * 64];
+                            F.g0 = pb0[k * 64]; F.g1 = pb1[k * 64];
+                        };
+                        auto mult = [&](const Frag &F) {
+                            acc[0][0] = mfma_f64_16x16x4(F.f0.x, F.g0.x, acc[0][0]); acc[0][1] = mfma_f64_16x16x4(F.f0.x, F.g1.x, acc[0][1]);
+                            acc[1][0] = mfma_f64_16x16x4(F.f1.x, F.g0.x, acc[1][0]); acc[1][1] = mfma_f64_16x16x4(F.f1.x, F.g1.x, acc[1][1]);
+                            acc[2][0] = mfma_f64_16x16x4(F.f2.x, F.g0.x, acc[2][0]); acc[2][1] = mfma_f64_16x16x4(F.f2.x, F.g1.x, acc[2][1]);
+                            acc[3][0] = mfma_f64_16x16x4(F.f3.x, F.g0.x, acc[3][0]); acc[3][1] = mfma_f64_16x16x4(F.f3.x, F.g1.x, acc[3][1]);
+                            acc[0][0] = mfma_f64_16x16x4(F.f0.y, F.g0.y, acc[0][0]); acc[0][1] = mfma_f64_16x16x4(F.f0.y, F.g1.y, acc[0][1]);
+                            acc[1][0] = mfma_f64_16x16x4(F.f1.y, F.g0.y, acc[1][0]); acc[1][1] = mfma_f64_16x16x4(F.f1.y, F.g1.y, acc[1][1]);
+                            acc[2][0] = mfma_f64_16x16x4(F.f2.y, F.g0.y, acc[2][0]); acc[2][1] = mfma_f64_16x16x4(F.f2.y, F.g1.y, acc[2][1]);
+                            acc[3][0] = mfma_f64_16x16x4(F.f3.y, F.g0.y, acc[3][0]); acc[3][1] = mfma_f64_16x16x4(F.f3.y, F.g1.y, acc[3][1]);
+                        };
+                        load(A, 0);
+                        for (int kp = 0; kp < nkp; kp += 2) {
+                            load(B, kp + 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mult(A);
+                            __builtin_amdgcn_sched_barrier(0);
+                            load(A, (kp + 2 < nkp) ? kp + 2 : kp + 1);   // (the last step re-loads a pair it has)
+                            __builtin_amdgcn_sched_barrier(0);
+                            mult(B);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    // K's entries: register r of tile (ct, t) of lane l is column J0 + 16 ct + l4 + 4 r, row 16 rt_t + l15
+                    const int l15 = opaque(l15_), l4 = opaque(l4_);
+                    const bool interior = b >= 2 && !yblk && (rt1 << 4) + 15 < N && J0 + 63 < N;
+                    if (interior) {   // every row and column is an observation, no diagonal entry
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const double *xp = Xp + (int64_t)(((t ? rt1 : rt0) << 4) + l15) * D;
+                            double xr[D];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) xr[k] = xp[k];
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const double *xc = S.Xc + (16 * ct + l4 + 4 * r) * D;
+                                    double a = 0.0;
+#pragma unroll
+                                    for (int k = 0; k < D; ++k) {
+                                        const double diff = xc[k] - xr[k];
+                                        a = fma(diff * diff, il2[k], a);
+                                    }
+                                    acc[ct][t][r] = exp_neg(0.5 * a, S.tab) - acc[ct][t][r];
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    } else {          // the diagonal block, rows / columns of the padding, y's tile
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int rt = t ? rt1 : rt0;
+                            const int row = (rt << 4) + l15;
+                            const double *xp = Xp + (int64_t)row * D;
+                            double xr[D];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) xr[k] = xp[k];
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int jc = 16 * ct + l4 + 4 * r, col = J0 + jc;
+                                    double a = 0.0;
+#pragma unroll
+                                    for (int k = 0; k < D; ++k) {
+                                        const double diff = S.Xc[jc * D + k] - xr[k];
+                                        a = fma(diff * diff, il2[k], a);
+                                    }
+                                    double v = exp_neg(0.5 * a, S.tab);
+                                    if (row == col) v += jitter;
+                                    if (row >= N || col >= N) v = (row == col) ? 1.0 : 0.0;
+                                    if (rt == RTY) v = (l15 == 0) ? S.yc[jc] : 0.0;
+                                    acc[ct][t][r] = v - acc[ct][t][r];
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                }
+                if (it == 0) {
+                    if (has && b < 2) {   // the diagonal block's rows: lower triangle into LDS
+                        const int l15 = opaque(l15_), l4 = opaque(l4_);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int lrow = 32 * b + 16 * t + l15, jc = 16 * ct + l4 + 4 * r;
+                                    S.M[lrow * LDM + jc] = (jc <= lrow) ? acc[ct][t][r] : 0.0;
+                                }
+                    }
+                    __syncthreads();
+                    const int fbad = potrf_panel_call();
+                    if (tid == 0 && fbad) S.bad = 1;
+                    if (tid < 64) logdet_t += log(S.M[tid * LDM + tid]);
+                }
+                if (has && b >= 2) {
+                    // ---- L^T = W C': stored in fragment order; y's row adds its squares to |z|^2 ----
+                    const int l15 = opaque(l15_), l4 = opaque(l4_);
+#pragma unroll
+                    for (int cq = 0; cq < 4; ++cq) {        // output column tile: panel columns 16 cq ..
+                        d4_t o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int ct = 0; ct <= cq; ++ct)    // W is lower triangular
+#pragma unroll
+                            for (int kg = 0; kg < 4; ++kg) {
+                                const double a = S.M[(64 + 16 * ct + 4 * kg + l4) * LDM + 16 * cq + l15];   // W[16cq + l15][16ct + 4kg + l4]
+                                o0 = mfma_f64_16x16x4(a, acc[ct][0][kg], o0);
+                                o1 = mfma_f64_16x16x4(a, acc[ct][1][kg], o1);
+                            }
+                        const int kp0 = nkp + 2 * cq;
+                        d2_t *q0 = Lf + ((int64_t)rt0 * KP + kp0) * 64 + lane;
+                        q0[0] = d2_t{o0[0], o0[1]};
+                        q0[64] = d2_t{o0[2], o0[3]};
+                        if (!yblk) {
+                            d2_t *q1 = Lf + ((int64_t)(rt0 + 1) * KP + kp0) * 64 + lane;
+                            q1[0] = d2_t{o1[0], o1[1]};
+                            q1[64] = d2_t{o1[2], o1[3]};
+                        } else if (l15 == 0) {
+                            quad_t = fma(o0[0], o0[0], quad_t); quad_t = fma(o0[1], o0[1], quad_t);
+                            quad_t = fma(o0[2], o0[2], quad_t); quad_t = fma(o0[3], o0[3], quad_t);
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // the panel's fragments are visible to every wave; M and Xc are free
+        }
+
+        // log det K = 2 sum log L_ii (threads 0..63 = wave 0), |z|^2 from whichever waves owned y's tile
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            logdet_t += __shfl_xor(logdet_t, off);
+            quad_t += __shfl_xor(quad_t, off);
+        }
+        if ((tid0 & 63) == 0) { S.red[w] = logdet_t; S.red[WAVES + w] = quad_t; }
         __syncthreads();
-    }
-    if (tid == 0) {
-        const double logdet = 2.0 * s_ld[0];
-        const double quad = -A[(int64_t)Nf * Ne + Nf];
-        const double logdet_ref = log(exp(logdet));  // the reference takes log of a det that under/overflows
-        double nlml = 0.5 * (quad + logdet_ref + (double)N * 1.8378770664093453);
-        if (info[blockIdx.x] != 0) nlml = __builtin_nan("");
-        out[blockIdx.x] = (float)nlml;
+        if (tid0 == 0) {
+            double quad = 0.0;
+            for (int k = 0; k < WAVES; ++k) quad += S.red[WAVES + k];
+            const double logdet = 2.0 * S.red[0];
+            double nlml;
+            if (MODE == 0) {
+                const double logdet_ref = log(exp(logdet));  // the reference takes log of a det that under/overflows
+                nlml = 0.5 * (quad + logdet_ref + (double)N * 1.8378770664093453);  // log(2 pi)
+            } else {
+                nlml = 0.5 * (quad + logdet + (double)N * 1.8378770664093453);
+            }
+            if (S.bad) nlml = __builtin_nan("");   // not positive definite: the reference's log(det < 0) is NaN
+            if (MODE == 0) reinterpret_cast<float *>(out_)[g] = (float)nlml;
+            else reinterpret_cast<double *>(out_)[g] = nlml;
+        }
     }
 }
 
-inline int64_t nlml_batch_cells(int64_t Ne, int64_t G) {
-    // matrices of one sub-batch stay under 8 GiB (2,500 cells at N = 512 are 6.6 GB: one batch)
-    int64_t cap = (int64_t)(8ll << 30) / (Ne * Ne * 8);
-    if (cap < 1) cap = 1;
-    if (cap > 32768) cap = 32768;
-    return G < cap ? G : cap;
+inline int64_t slot_bytes(int64_t Nf) { return (Nf + 16) * Nf * 8; }
+inline int64_t slots_for(int64_t Nf, int64_t G) {
+    int64_t s = WORK_CAP / slot_bytes(Nf);
+    if (s > SLOTS) s = SLOTS;
+    if (s > G) s = G;
+    return s < 1 ? 1 : s;
 }
+// padded inputs in front of the slots: Xp, yp, il2p (sized for the widest bucket), rounded up to 256 bytes
+inline int64_t head_bytes(int64_t Nf, int64_t G) {
+    const int64_t b = ((Nf + 16) * DMAX + Nf + G * DMAX) * 8;
+    return (b + 255) / 256 * 256;
+}
+
+template <int D, int MODE>
+int launch(const double *Xp, const double *yp, int64_t N, int64_t Nf, const double *il2p, int64_t G, double jitter, void *out,
+           double *scratch, hipStream_t st) {
+    const void *fn = reinterpret_cast<const void *>(nlml_fused_kernel<D, MODE>);
+    const size_t lds = sizeof(Lds<D>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPBO_ERR_LAUNCH;
+    hipLaunchKernelGGL((nlml_fused_kernel<D, MODE>), dim3((unsigned)slots_for(Nf, G)), dim3(TH), lds, st, Xp, yp, (int)N, (int)Nf,
+                       il2p, (int)G, jitter, out, scratch);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
+template <int MODE>
+int run(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells, int64_t G, double jitter, void *out,
+        void *work, int64_t work_bytes, void *stream) {
+    if (!X || !y || !ls_cells || !out || !work || N < 1 || N > (1 << 15) || d < 1 || d > GPBO_MAX_D || G < 1 || G > (1 << 30))
+        return GPBO_ERR_ARG;
+    const int64_t Nf = (N + GPBO_NB - 1) / GPBO_NB * GPBO_NB;
+    if (work_bytes < head_bytes(Nf, G) + slots_for(Nf, G) * slot_bytes(Nf) || ((uintptr_t)work & 255)) return GPBO_ERR_WORKSPACE;
+    hipStream_t st = gpbo_stream(stream);
+    const int D = d <= 2 ? 2 : d <= 4 ? 4 : d <= 8 ? 8 : 16;
+    double *Xp = reinterpret_cast<double *>(work);
+    double *yp = Xp + (Nf + 16) * D;
+    double *il2p = yp + Nf;
+    double *scratch = reinterpret_cast<double *>(reinterpret_cast<char *>(work) + head_bytes(Nf, G));
+    const int64_t total = (Nf + 16) * D + Nf + G * D;
+    const unsigned pg = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(nlml_prep_kernel, dim3(pg), dim3(256), 0, st, X, y, (int)N, (int)d, D, (int)Nf, ls_cells, G, Xp, yp, il2p);
+    GPBO_CHECK_LAUNCH();
+    if (D == 2) return launch<2, MODE>(Xp, yp, N, Nf, il2p, G, jitter, out, scratch, st);
+    if (D == 4) return launch<4, MODE>(Xp, yp, N, Nf, il2p, G, jitter, out, scratch, st);
+    if (D == 8) return launch<8, MODE>(Xp, yp, N, Nf, il2p, G, jitter, out, scratch, st);
+    return launch<16, MODE>(Xp, yp, N, Nf, il2p, G, jitter, out, scratch, st);
+}
+
+}  // namespace fused
 
 }  // namespace
 
 extern "C" int64_t gpbo_nlml_grid_batched_workspace_bytes(int64_t N, int64_t G) {
     if (N < 1 || G < 1 || N > (1 << 15)) return GPBO_ERR_ARG;
-    const int64_t Nf = (N + GPBO_NB - 1) / GPBO_NB * GPBO_NB, Ne = Nf + GPBO_NB;
-    const int64_t B = nlml_batch_cells(Ne, G);
-    return B * (Ne * Ne * 8 + (Nf / GPBO_NB) * GPBO_NB * GPBO_NB * 8 + 256) + 256;
+    const int64_t Nf = (N + GPBO_NB - 1) / GPBO_NB * GPBO_NB;
+    return fused::head_bytes(Nf, G) + fused::slots_for(Nf, G) * fused::slot_bytes(Nf);
 }
 
 extern "C" int gpbo_nlml_grid_batched_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells,
                                           int64_t G, double jitter, float *out, void *work, int64_t work_bytes,
                                           void *stream) {
-    if (!X || !y || !ls_cells || !out || !work || N < 1 || d < 1 || d > GPBO_MAX_D || G < 1) return GPBO_ERR_ARG;
-    const int64_t need = gpbo_nlml_grid_batched_workspace_bytes(N, G);
-    if (need < 0) return GPBO_ERR_ARG;
-    if (work_bytes < need || ((uintptr_t)work & 255)) return GPBO_ERR_WORKSPACE;
-    const int64_t Nf = (N + GPBO_NB - 1) / GPBO_NB * GPBO_NB, Ne = Nf + GPBO_NB;
-    const int64_t B = nlml_batch_cells(Ne, G);
-    const int nbf = (int)(Nf / GPBO_NB);
-    char *w = reinterpret_cast<char *>(work);
-    double *Ab = reinterpret_cast<double *>(w);
-    double *dinv = Ab + B * Ne * Ne;
-    int32_t *info = reinterpret_cast<int32_t *>(dinv + B * nbf * GPBO_NB * GPBO_NB);
-    hipStream_t st = gpbo_stream(stream);
-    for (int64_t g0 = 0; g0 < G; g0 += B) {
-        const int64_t nb = (G - g0 < B) ? (G - g0) : B;
-        dim3 grid((unsigned)((Ne + 255) / 256), (unsigned)(Ne / 8), (unsigned)nb);
-#define CALL(DD)                                                                                                       \
-    hipLaunchKernelGGL(nlml_build_kernel<DD>, grid, dim3(256), 0, st, X, y, (int)N, (int)Nf, (int)Ne, ls_cells + g0 * d,   \
-                       jitter, Ab, info)
-        switch (d) {
-            case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;   case 4: CALL(4); break;
-            case 5: CALL(5); break;   case 6: CALL(6); break;   case 7: CALL(7); break;   case 8: CALL(8); break;
-            case 9: CALL(9); break;   case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break;
-            case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break;
-            default: return GPBO_ERR_ARG;
-        }
-#undef CALL
-        GPBO_CHECK_LAUNCH();
-        int rc = gpbo_potrf_batched(Ab, Ne, nbf, (int)nb, dinv, info, st);
-        if (rc != GPBO_OK) return rc;
-        hipLaunchKernelGGL(nlml_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, Ab, (int)N, (int)Nf, (int)Ne, info,
-                           out + g0);
-        GPBO_CHECK_LAUNCH();
-    }
-    return GPBO_OK;
+    return fused::run<0>(X, y, N, d, ls_cells, G, jitter, out, work, work_bytes, stream);
+}
+
+extern "C" int gpbo_nlml_grid_batched_logdet_f64(const double *X, const double *y, int64_t N, int32_t d,
+                                                 const double *ls_cells, int64_t G, double jitter, double *out, void *work,
+                                                 int64_t work_bytes, void *stream) {
+    return fused::run<1>(X, y, N, d, ls_cells, G, jitter, out, work, work_bytes, stream);
 }
 
 extern "C" int gpbo_nlml_cell_f64(const double *U, const double *alpha, const double *y, int64_t N, int64_t Np,

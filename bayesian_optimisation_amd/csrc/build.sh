@@ -10,7 +10,7 @@ if [ "${GPBO_DIAG:-0}" = "1" ]; then FLAGS="$FLAGS -DGPBO_DIAGNOSTICS"; fi
 mkdir -p build
 pids=()
 for f in api kernel_build kstar_mfma gemm_f64 factor cholinv subset update sigma_acq ard posterior_f32 rescore ozaki host_api; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ gpbo_internal.h -nt build/$f.o ] || [ cholinv_plan.h -nt build/$f.o ] || [ exp_neg.h -nt build/$f.o ] || [ ../../include/gpbo.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ gpbo_internal.h -nt build/$f.o ] || [ cholinv_plan.h -nt build/$f.o ] || [ exp_neg.h -nt build/$f.o ] || [ potrf_diag64.h -nt build/$f.o ] || [ ../../include/gpbo.h -nt build/$f.o ]; then
     X=""; [ $f = cholinv ] && X="-mllvm -amdgpu-kernarg-preload-count=16"   # cholinv.hip: see cholinv_kernel
     $HIPCC $FLAGS $X -c $f.hip -o build/$f.o &
     pids+=($!)

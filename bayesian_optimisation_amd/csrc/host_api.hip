@@ -222,16 +222,18 @@ extern "C" int gpbo_select_qei_host_f64(const double *X, const double *y, int64_
     return GPBO_OK;
 }
 
-extern "C" int gpbo_nlml_grid_host_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells,
-                                       int64_t G, double jitter, float *out) {
+// mode 0: the reference's float32 likelihood; mode 1: fp64, log det from the factor (gpbo.h)
+static int nlml_grid_host(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells, int64_t G,
+                          double jitter, void *out, int mode) {
     if (!X || !y || !ls_cells || !out || N < 1 || d < 1 || d > GPBO_MAX_D || G < 1 || G > (1 << 30))
         return GPBO_ERR_ARG;
     for (int64_t e = 0; e < G * d; ++e)
         if (!(ls_cells[e] > 0.0)) return GPBO_ERR_ARG;
     DeviceArena A;
     if (!A.ok) return GPBO_ERR_LAUNCH;
+    const size_t osz = mode ? sizeof(double) : sizeof(float);
     double *dX = A.alloc<double>(N * d), *dy = A.alloc<double>(N);
-    float *dout = A.alloc<float>(G);
+    char *dout = A.alloc<char>((int64_t)(G * osz));
     void *st = reinterpret_cast<void *>(A.stream);
     if (!A.ok) return GPBO_ERR_WORKSPACE;
     if (!A.h2d(dX, X, sizeof(double) * N * d) || !A.h2d(dy, y, sizeof(double) * N)) return GPBO_ERR_LAUNCH;
@@ -239,17 +241,28 @@ extern "C" int gpbo_nlml_grid_host_f64(const double *X, const double *y, int64_t
     double *dcells = A.alloc<double>(G * d);
     if (!A.ok) return GPBO_ERR_WORKSPACE;
     if (!A.h2d(dcells, ls_cells, sizeof(double) * G * d)) return GPBO_ERR_LAUNCH;
-    if (N <= 64) {   // the in-LDS kernel (DeviceGP.ARD_LDS_MAX_N: the same switch as the tensor-resident binding)
-        rc = gpbo_nlml_grid_f64(dX, dy, N, d, dcells, G, jitter, dout, st);
+    if (N <= 64 && mode == 0) {   // the in-LDS kernel (DeviceGP.ARD_LDS_MAX_N: the same switch as the tensor-resident binding)
+        rc = gpbo_nlml_grid_f64(dX, dy, N, d, dcells, G, jitter, reinterpret_cast<float *>(dout), st);
         if (rc != GPBO_OK) return rc;
-    } else {         // every cell's bordered matrix through one batched blocked Cholesky
+    } else {         // one persistent workgroup per cell, the whole factorisation in one launch
         const int64_t wb = gpbo_nlml_grid_batched_workspace_bytes(N, G);
         if (wb < 0) return GPBO_ERR_ARG;
         char *dwork = A.alloc<char>(wb);
         if (!A.ok) return GPBO_ERR_WORKSPACE;
-        rc = gpbo_nlml_grid_batched_f64(dX, dy, N, d, dcells, G, jitter, dout, dwork, wb, st);
+        rc = mode ? gpbo_nlml_grid_batched_logdet_f64(dX, dy, N, d, dcells, G, jitter, reinterpret_cast<double *>(dout), dwork, wb, st)
+                  : gpbo_nlml_grid_batched_f64(dX, dy, N, d, dcells, G, jitter, reinterpret_cast<float *>(dout), dwork, wb, st);
         if (rc != GPBO_OK) return rc;
     }
-    if (!A.d2h(out, dout, sizeof(float) * G) || !A.sync()) return GPBO_ERR_LAUNCH;
+    if (!A.d2h(out, dout, G * osz) || !A.sync()) return GPBO_ERR_LAUNCH;
     return GPBO_OK;
+}
+
+extern "C" int gpbo_nlml_grid_host_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells,
+                                       int64_t G, double jitter, float *out) {
+    return nlml_grid_host(X, y, N, d, ls_cells, G, jitter, out, 0);
+}
+
+extern "C" int gpbo_nlml_grid_logdet_host_f64(const double *X, const double *y, int64_t N, int32_t d,
+                                              const double *ls_cells, int64_t G, double jitter, double *out) {
+    return nlml_grid_host(X, y, N, d, ls_cells, G, jitter, out, 1);
 }

@@ -758,34 +758,39 @@ class DeviceGP:
     # -- ARD grid ------------------------------------------------------------------------------------
     ARD_LDS_MAX_N = 64   # above: the batched blocked Cholesky (faster from here on; see nlml_grid)
 
-    def nlml_grid(self, X, y, ls_cells, jitter: float = JITTER_KERNEL) -> np.ndarray:
-        """float32 -log marginal likelihood of every row of ls_cells [G x d]  (point_selector.py:111-156)."""
+    def nlml_grid(self, X, y, ls_cells, jitter: float = JITTER_KERNEL, likelihood: str = "reference") -> np.ndarray:
+        """-log marginal likelihood of every row of ls_cells [G x d]  (point_selector.py:111-156).
+
+        likelihood="reference": the reference's value - float32, log det K taken as np.log(np.linalg.det(K)), which
+        underflows to -inf beyond N ~ 100 (reproduced for parity).  likelihood="logdet": fp64, log det K = 2 sum log L_ii
+        from the factor - finite at any N, NaN where a pivot is not positive (a documented departure)."""
+        if likelihood not in ("reference", "logdet"):
+            raise ValueError(f"likelihood must be 'reference' or 'logdet', got {likelihood!r}")
         torch = self.torch
         Xd, yd = self._dev(X), self._dev(y).reshape(-1)
         N, d = int(Xd.shape[0]), int(Xd.shape[1])
         cells = self._dev(np.asarray(ls_cells, dtype=np.float64).reshape(-1, d))
         G = int(cells.shape[0])
-        if N > self.ARD_LDS_MAX_N:
-            # every cell's bordered matrix through one batched blocked Cholesky: measured on MI355X, 2,500 cells take
-            # 0.30 / 0.80 / 1.43 / 11.9 / 62 ms at N = 64 / 128 / 176 / 512 / 1024 (the one-workgroup-per-cell in-LDS kernel:
-            # 0.52 / 5.4 / 11.7 ms at N = 64 / 128 / 176, and it stops at 176); small N stays on the in-LDS kernel, whose
-            # elimination order is the one pinned against the reference's float32 ties (golden g4_ard_n2).
-            # (the reference's det-based likelihood is -inf for most cells beyond N ~ 100: log(exp(logdet)) reproduces it)
+        logdet = likelihood == "logdet"
+        if N > self.ARD_LDS_MAX_N or logdet:
+            # one persistent workgroup per cell, the whole factorisation in one launch (csrc/ard.hip, round 5); small N in
+            # reference mode stays on the in-LDS kernel, whose elimination order is the one pinned against the reference's
+            # float32 ties (golden g4_ard_n2).
             with torch.cuda.device(self.device):
-                out = torch.empty(G, dtype=torch.float32, device=self.device)
+                out = torch.empty(G, dtype=torch.float64 if logdet else torch.float32, device=self.device)
                 need = int(self.lib.gpbo_nlml_grid_batched_workspace_bytes(N, G))
                 if need < 0:
                     raise _lib.GpboError("gpbo_nlml_grid_batched_workspace_bytes: invalid sizes")
                 if getattr(self, "_work_ard", None) is None or self._work_ard.numel() * 8 < need:
                     self._work_ard = None
                     self._work_ard = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
-                st = self.lib.gpbo_nlml_grid_batched_f64(self._ptr(Xd), self._ptr(yd), N, d, self._ptr(cells), G,
-                                                         float(jitter), self._ptr(out), self._ptr(self._work_ard), need,
-                                                         self._stream())
-                _lib.check(st, "gpbo_nlml_grid_batched_f64")
+                fn = self.lib.gpbo_nlml_grid_batched_logdet_f64 if logdet else self.lib.gpbo_nlml_grid_batched_f64
+                st = fn(self._ptr(Xd), self._ptr(yd), N, d, self._ptr(cells), G, float(jitter), self._ptr(out),
+                        self._ptr(self._work_ard), need, self._stream())
+                _lib.check(st, "gpbo_nlml_grid_batched_logdet_f64" if logdet else "gpbo_nlml_grid_batched_f64")
                 res = out.cpu().numpy()   # synchronises: the workspace is no longer in use
-                # the sub-batch workspace can be GiBs (up to 8): kept between the calls of one search (a coordinate-wise
-                # ARD search calls this once per axis and sweep) only while it is small
+                # the scratch slots can be GiBs (512 x (N + 16) x N x 8 bytes): kept between the calls of one search (a
+                # coordinate-wise ARD search calls this once per axis and sweep) only while they are small
                 if self._work_ard.numel() * 8 > self.ARD_KEEP_WORKSPACE_BYTES:
                     self._work_ard = None
                 return res

@@ -30,16 +30,21 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
 
 
-def nlml_grid(X, y, ls_cells, jitter: float = JITTER_KERNEL, lib=None) -> np.ndarray:
-    """float32 -log marginal likelihood of every row of ls_cells [G x d]  (point_selector.py:111-156)."""
+def nlml_grid(X, y, ls_cells, jitter: float = JITTER_KERNEL, lib=None, likelihood: str = "reference") -> np.ndarray:
+    """-log marginal likelihood of every row of ls_cells [G x d]  (point_selector.py:111-156): float32 with the
+    reference's det underflow (likelihood="reference") or fp64 with log det from the factor ("logdet")."""
+    if likelihood not in ("reference", "logdet"):
+        raise ValueError(f"likelihood must be 'reference' or 'logdet', got {likelihood!r}")
     lib = lib or _lib.load()
     X, y = _f64(X), _f64(y).reshape(-1)
     N, d = X.shape
     cells = _f64(np.asarray(ls_cells, dtype=np.float64).reshape(-1, d))
-    out = np.empty(len(cells), dtype=np.float32)
+    logdet = likelihood == "logdet"
+    out = np.empty(len(cells), dtype=np.float64 if logdet else np.float32)
     _lib.note_hip_use()
-    _lib.check(lib.gpbo_nlml_grid_host_f64(_ptr(X), _ptr(y), N, d, _ptr(cells), len(cells), float(jitter), _ptr(out)),
-               "gpbo_nlml_grid_host_f64")
+    fn = lib.gpbo_nlml_grid_logdet_host_f64 if logdet else lib.gpbo_nlml_grid_host_f64
+    _lib.check(fn(_ptr(X), _ptr(y), N, d, _ptr(cells), len(cells), float(jitter), _ptr(out)),
+               "gpbo_nlml_grid_logdet_host_f64" if logdet else "gpbo_nlml_grid_host_f64")
     return out
 
 
@@ -84,15 +89,15 @@ class _GridOnly:
     def __init__(self, lib):
         self.lib = lib
 
-    def nlml_grid(self, X, y, ls_cells, jitter: float = JITTER_KERNEL):
-        return nlml_grid(X, y, ls_cells, jitter, self.lib)
+    def nlml_grid(self, X, y, ls_cells, jitter: float = JITTER_KERNEL, likelihood: str = "reference"):
+        return nlml_grid(X, y, ls_cells, jitter, self.lib, likelihood)
 
 
 class PointSelectorHost(PointSelector):
     """`PointSelector` with the same attribute protocol (point_selector.py:13-207), on the host-pointer entry points."""
 
-    def __init__(self, verbose: bool = False, chunk: int = 0):
-        super().__init__(device=None, verbose=verbose, shard_candidates=False)
+    def __init__(self, verbose: bool = False, chunk: int = 0, likelihood: str = "reference"):
+        super().__init__(device=None, verbose=verbose, shard_candidates=False, likelihood=likelihood)
         self.lib = _lib.load()
         self._gp = _GridOnly(self.lib)
         self._chunk = int(chunk)

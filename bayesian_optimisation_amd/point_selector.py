@@ -59,7 +59,7 @@ def _plot_hooks():
 
 class PointSelector:
     def __init__(self, device=None, verbose: bool = False, shard_candidates: bool = True, precision: str = "fp64",
-                 incremental: bool = False, state_path=None, dense_outputs: bool = True):
+                 incremental: bool = False, state_path=None, dense_outputs: bool = True, likelihood: str = "reference"):
         # attribute protocol of point_selector.py:15-40
         self.feature_domain = None
         self.predicted_pts = None
@@ -86,6 +86,12 @@ class PointSelector:
             raise ValueError("precision must be 'fp64' (reference arithmetic), 'fp32', 'i8' or 'i8c' (fp64 factorisation, "
                              "means and decision; variance product screened in fp32 / in int8 slices / in three int8 digits)")
         self._precision = precision
+        # likelihood="reference" (default): tune_kernel's grid holds the reference's float32 values, det underflow
+        # included (point_selector.py:117-119: -inf beyond N ~ 100, where the search then returns its first cell);
+        # "logdet" (not in the reference): fp64 grid with log det K from the Cholesky factor - finite at any N.
+        if likelihood not in ("reference", "logdet"):
+            raise ValueError("likelihood must be 'reference' (the reference's np.log(np.linalg.det(K))) or 'logdet'")
+        self._likelihood = likelihood
         # dense_outputs=False (not in the reference): a caller that needs the next point only.  mean_func / cov_func /
         # acq_func_eval stay None and the acquisition calls return the same multi-index through the exact prefix bound
         # (DeviceGP.score_bound: fp64 branch and bound, the full pass when the bound does not separate the candidates).
@@ -289,10 +295,11 @@ class PointSelector:
         """The likelihood of every grid cell; with several ranks each evaluates a contiguous block of cells
         (independent factorisations) and the float32 values are concatenated on every rank."""
         world, rank = self._world()
+        kw = {} if self._likelihood == "reference" else {"likelihood": self._likelihood}
         if world == 1 or len(cells) < world:
-            return self._gp.nlml_grid(X, y, cells)
+            return self._gp.nlml_grid(X, y, cells, **kw)
         lo, hi = D.shard_bounds(len(cells), world, rank)
-        return D.gather_concat(self._gp.nlml_grid(X, y, cells[lo:hi]), len(cells))
+        return D.gather_concat(self._gp.nlml_grid(X, y, cells[lo:hi], **kw), len(cells))
 
     # ------------------------------------------------------------------------------------------
     def tune_kernel(self):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPBO_VERSION 140 /* 0.4.0: the prefix bound on ONE factorisation of the farthest-point-ordered observations (gpbo_fps_order_f64 replaces gpbo_*_subset_f64) */
+#define GPBO_VERSION 150 /* 0.5.0: the likelihood grid of any N in one launch (one workgroup per cell), a second likelihood mode (log det from the factor: gpbo_nlml_grid_*logdet*) */
 
 #define GPBO_OK 0
 #define GPBO_ERR_ARG (-1)      /* null pointer, bad size/alignment, unsupported d */
@@ -315,8 +315,8 @@ int gpbo_acq_argmax_f64(const double *mu, const double *sigma, int64_t M, int32_
  *   info (host): 0, or the 1-based failing pivot (the reference's inv() raises LinAlgError or returns garbage) -
  *   then nothing is scored and result->best_idx = -1.
  * gpbo_nlml_grid_host_f64 = tune_kernel()'s float32 likelihood grid (point_selector.py:104-163): ls_cells [G x d]
- *   host, out [G] host float32; any N (the in-LDS kernel up to gpbo_nlml_grid_max_n(), one factorisation per cell
- *   beyond). */
+ *   host, out [G] host float32; any N (the in-LDS kernel up to 64 observations, the one-launch workgroup-per-cell
+ *   kernel beyond). */
 /* (When mu_out, sigma_out and acq_out are all NULL, M >= 32768, N > 896 and the acquisition increases with sigma, the next
  * point is found by branch and bound on the exact prefix bound - gpbo_posterior_prefix_f64 / gpbo_bound_select_f64 below -
  * instead of computing every variance: same index and NaN count, the value within 1e-12 relative of the plain pass.) */
@@ -333,6 +333,9 @@ int gpbo_select_qei_host_f64(const double *X_host, const double *y_host, int64_t
                              gpbo_result *result_host, int32_t *info_host);
 int gpbo_nlml_grid_host_f64(const double *X_host, const double *y_host, int64_t N, int32_t d,
                             const double *ls_cells_host, int64_t G, double jitter, float *out_host);
+/* the log-det likelihood mode (gpbo_nlml_grid_batched_logdet_f64) on host arrays: out_host [G] fp64 */
+int gpbo_nlml_grid_logdet_host_f64(const double *X_host, const double *y_host, int64_t N, int32_t d,
+                                   const double *ls_cells_host, int64_t G, double jitter, double *out_host);
 
 /* K9 - replaces tune_kernel / eval_log_marginal (point_selector.py:104-163): float32 grid of
  * nlml = 0.5 (y^T K^-1 y + log det K + N log 2pi), K = k(X,X) + jitter I, one value per grid cell.
@@ -342,13 +345,24 @@ int gpbo_nlml_grid_max_n(void);
 int gpbo_nlml_grid_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells, int64_t G,
                        double jitter, float *out, void *stream);
 
-/* The same grid for ANY N: every cell's bordered matrix [K y; y^T 0] goes through one batched blocked Cholesky
- * (batched potrf_diag + strided-batched MFMA GEMMs; sub-batches of at most 8 GiB of matrices).  Same value per cell
- * as gpbo_nlml_grid_f64 up to the rounding of a blocked elimination order.  work: ..._workspace_bytes(N, G), 256-byte
- * aligned. */
+/* The same grid for ANY N, one launch: a persistent workgroup per cell runs a left-looking blocked Cholesky of the
+ * cell's K (entries generated on the fly, the factor kept in MFMA fragment order in a scratch slot of the workspace,
+ * y carried as one more row so that y^T K^-1 y = |L^-1 y|^2).  Same value per cell as gpbo_nlml_grid_f64 up to the
+ * rounding of a blocked elimination order.  work: ..._workspace_bytes(N, G), 256-byte aligned.
+ *
+ * Two likelihood modes (INTEGRATION.md "ARD likelihood modes"):
+ *   gpbo_nlml_grid_batched_f64         the REFERENCE's value: float32, log det K evaluated as log(exp(logdet)) because
+ *                                      point_selector.py:118 takes np.log(np.linalg.det(K)) - det underflows to 0 beyond
+ *                                      N ~ 100 and the cell becomes -inf (reproduced on purpose: parity);
+ *   gpbo_nlml_grid_batched_logdet_f64  a documented DEPARTURE for the sizes where that is useless: fp64 output,
+ *                                      log det K = 2 sum log L_ii straight from the factor (finite at any N), NaN when a
+ *                                      pivot is not positive.  Any N >= 1 (small N included). */
 int64_t gpbo_nlml_grid_batched_workspace_bytes(int64_t N, int64_t G);
 int gpbo_nlml_grid_batched_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells,
                                int64_t G, double jitter, float *out, void *work, int64_t work_bytes, void *stream);
+int gpbo_nlml_grid_batched_logdet_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells,
+                                      int64_t G, double jitter, double *out, void *work, int64_t work_bytes,
+                                      void *stream);
 
 /* One cell of the same grid for any N, from a factorisation made with (jitter1, jitter2) = (1e-4, 0):
  * log det K = -2 sum log U_ii, y^T K^-1 y = y . alpha; NaN when info != 0 (the reference's log of a negative det). */

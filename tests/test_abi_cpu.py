@@ -22,7 +22,7 @@ def _header_functions():
 def test_library_is_built_and_loads_without_gpu():
     assert os.path.exists(_lib.LIB_PATH), "run bayesian_optimisation_amd/csrc/build.sh (or __graft_entry__.build())"
     lib = _lib.load()
-    assert lib.gpbo_version() == 140
+    assert lib.gpbo_version() == 150
     assert lib.gpbo_padded_n(1) == 128 and lib.gpbo_padded_n(128) == 128 and lib.gpbo_padded_n(129) == 256
     assert b"workspace" in lib.gpbo_strerror(-3)
 
