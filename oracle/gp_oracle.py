@@ -146,7 +146,7 @@ def nlml_cells_logdet(X: np.ndarray, y: np.ndarray, cells: np.ndarray) -> np.nda
     return out
 
 
-def coordinate_search(X, y, axes, sweeps: int = 2):
+def coordinate_search(X, y, axes, sweeps: int = 2, nlml=None):
     """Length-scale search for d > 2 (not in the reference, whose tune_kernel handles one or two axes only): start
     from the middle of every axis (the reference's own choice when it cannot tune, point_selector.py:63-73), then for
     each axis in turn evaluate the likelihood with that coordinate running over its grid and keep the FIRST minimum
@@ -158,7 +158,7 @@ def coordinate_search(X, y, axes, sweeps: int = 2):
         for k, a in enumerate(axes):
             cells = np.tile(ls, (len(a), 1))
             cells[:, k] = a
-            g = nlml_cells(X, y, cells)
+            g = (nlml or nlml_cells)(X, y, cells)     # nlml=nlml_cells_logdet: the build's second likelihood mode
             grids[k] = g
             ls[k] = a[int(first_min_index(g)[0])]
     return ls, grids

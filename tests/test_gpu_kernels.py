@@ -284,3 +284,93 @@ def test_nlml_batched_large_n_vs_oracle(env, N, d, G):
     fin = np.isfinite(stable)
     if fin.all():
         assert int(np.flatnonzero(out == out.min())[0]) == int(np.flatnonzero(stable.astype(np.float32) == stable.astype(np.float32).min())[0])
+
+
+# ---- round 5: the one-launch grid (a persistent workgroup per cell) and the log-det likelihood mode ----------------------
+@pytest.mark.parametrize("N,d,G", [(300, 2, 60), (512, 8, 48), (1030, 2, 12), (1030, 8, 10), (700, 5, 24)])
+def test_nlml_logdet_mode_vs_oracle(env, N, d, G):
+    """likelihood="logdet" (not in the reference, whose np.log(np.linalg.det(K)) is -inf at these sizes): fp64 values of
+    0.5 (|L^-1 y|^2 + 2 sum log L_ii + N log 2 pi) against the oracle's Cholesky restatement, rtol 1e-10; every cell finite;
+    the reference mode of the same kernel on the same cells keeps the reference's -inf pattern."""
+    from bayesian_optimisation_amd import DeviceGP
+
+    X, y, _, _ = make_problem(N, 8, d)
+    rng = np.random.default_rng(N * 31 + d)
+    cells = np.exp(rng.uniform(np.log(0.05), np.log(3.0), size=(G, d)))
+    gp = DeviceGP()
+    out = gp.nlml_grid(X, y, cells, likelihood="logdet")
+    assert out.dtype == np.float64 and out.shape == (G,) and np.isfinite(out).all()
+    want = O.nlml_cells_logdet(X, y, cells)
+    np.testing.assert_allclose(out, want, rtol=1e-10, atol=0)
+    assert int(np.argmin(out)) == int(np.argmin(want))
+    ref_mode = gp.nlml_grid(X, y, cells)
+    stable = O.nlml_cells_stable(X, y, cells)
+    fin = np.isfinite(stable)
+    assert np.array_equal(np.isfinite(ref_mode), fin)
+    np.testing.assert_allclose(ref_mode[fin], stable[fin].astype(np.float32), rtol=3e-6)
+    assert np.array_equal(ref_mode[~fin], stable[~fin].astype(np.float32))
+    # wherever the reference's determinant is a normal number the two modes are the same quantity
+    np.testing.assert_allclose(out[fin], ref_mode[fin], rtol=3e-6)
+
+
+@pytest.mark.parametrize("N", [1, 2, 17, 63, 64, 65, 127, 128, 129, 191, 192, 193, 257])
+@pytest.mark.parametrize("d", [1, 3, 4, 5, 9, 16])
+def test_nlml_one_launch_grid_every_panel_edge_and_feature_bucket(env, N, d):
+    """Ragged sizes around the 64-column panels and the 32-row blocks, every feature bucket of the kernel (2 / 4 / 8 / 16):
+    the log-det mode against the oracle, the reference mode against the in-LDS kernel's route where that exists."""
+    from bayesian_optimisation_amd import DeviceGP
+
+    X, y, _, _ = make_problem(N, 8, d)
+    rng = np.random.default_rng(N * 7 + d)
+    cells = np.exp(rng.uniform(np.log(0.1), np.log(2.0), size=(9, d)))
+    gp = DeviceGP()
+    out = gp.nlml_grid(X, y, cells, likelihood="logdet")
+    np.testing.assert_allclose(out, O.nlml_cells_logdet(X, y, cells), rtol=1e-10, atol=1e-11)
+    b = _nlml_direct(gp, X, y, cells, batched=True)
+    stable = O.nlml_cells_stable(X, y, cells)
+    fin = np.isfinite(stable)
+    assert np.array_equal(np.isfinite(b), fin)
+    np.testing.assert_allclose(b[fin], stable[fin], rtol=3e-6, atol=1e-5)
+
+
+def test_nlml_one_launch_grid_more_cells_than_workgroups(env):
+    """2,600 cells on 512 persistent workgroups: every workgroup takes several cells in turn (its scratch slot, its LDS
+    and its reductions are reused); cell g of the output is cell g of the input."""
+    from bayesian_optimisation_amd import DeviceGP
+
+    X, y, _, _ = make_problem(150, 8, 3)
+    rng = np.random.default_rng(11)
+    base = np.exp(rng.uniform(np.log(0.1), np.log(2.0), size=(13, 3)))
+    cells = np.tile(base, (200, 1))
+    out = DeviceGP().nlml_grid(X, y, cells, likelihood="logdet")
+    want = O.nlml_cells_logdet(X, y, base)
+    np.testing.assert_allclose(out.reshape(200, 13), np.tile(want, (200, 1)), rtol=1e-10)
+    assert np.array_equal(out.reshape(200, 13), np.tile(out[:13], (200, 1)))     # the same cell gives the same bits anywhere
+
+
+def test_nlml_logdet_mode_reports_a_failed_pivot_as_nan(env):
+    """K = k(X,X) + jitter I with jitter = -0.5 is not positive definite: NaN in that cell (the reference's log of a
+    negative determinant is NaN too), the cells of a second call unaffected."""
+    from bayesian_optimisation_amd import DeviceGP
+
+    X, y, _, _ = make_problem(200, 8, 2)
+    cells = np.array([[0.3, 0.3], [1.0, 2.0], [0.05, 0.05]])
+    gp = DeviceGP()
+    bad = gp.nlml_grid(X, y, cells, jitter=-0.5, likelihood="logdet")
+    assert np.isnan(bad).all()
+    assert np.isnan(gp.nlml_grid(X, y, cells, jitter=-0.5)).all()
+    good = gp.nlml_grid(X, y, cells, likelihood="logdet")
+    np.testing.assert_allclose(good, O.nlml_cells_logdet(X, y, cells), rtol=1e-10)
+
+
+def test_nlml_logdet_host_entry_point_equals_the_device_one(env):
+    from bayesian_optimisation_amd import DeviceGP
+    from bayesian_optimisation_amd import host_binding as H
+
+    X, y, _, _ = make_problem(333, 8, 6)
+    cells = np.exp(np.random.default_rng(2).uniform(np.log(0.1), np.log(2.0), size=(20, 6)))
+    a = DeviceGP().nlml_grid(X, y, cells, likelihood="logdet")
+    b = H.nlml_grid(X, y, cells, likelihood="logdet")
+    assert b.dtype == np.float64 and np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        H.nlml_grid(X, y, cells, likelihood="det")

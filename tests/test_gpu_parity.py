@@ -892,3 +892,35 @@ def test_large_call_column_groups_agree_with_the_ungrouped_kernel_and_the_oracle
     assert np.max(np.abs(big.sigma.cpu().numpy()[sub] - sig_o)) <= 1e-8
     other = DeviceGP(chunk=1 << 13).factorise(X, y, ls).score(Xs, dense=True)
     assert np.array_equal(other.sigma.cpu().numpy(), big.sigma.cpu().numpy()) and other.best_idx == big.best_idx
+
+
+def test_ard_coordinate_search_d8_n512_logdet_mode_picks_finite_cells():
+    """d = 8, N = 512 (BASELINE config 2's surrogate): in the reference's likelihood most cells are -inf here (its determinant
+    underflows) and the search returns the first such cell; PointSelector(likelihood="logdet") searches the same axes on
+    finite fp64 values - the oracle's coordinate search with its Cholesky likelihood gives the same length scales, and the
+    selected point is the oracle's for them."""
+    N, d = 512, 8
+    X, y, Xs, _ = make_problem(N, 4096, d)
+    axes = [np.geomspace(0.1, 3.0, 12 + (k % 3)) for k in range(d)]
+    ps = PointSelector(likelihood="logdet")
+    ps.name, ps.iteration = "t", 0
+    ps.measured_pts, ps.measured_vals = X, y
+    ps.feature_domain, ps.predicted_pts = [len(Xs)], Xs
+    ps.length_scales = axes
+    ps.update_surrogate()
+    idx = ps.lower_confidence_bound()
+    ls_o, grids_o = O.coordinate_search(X, y, axes, sweeps=2, nlml=O.nlml_cells_logdet)
+    assert np.array_equal(ps.kernel_params, ls_o)
+    for g, go in zip(ps.nlogml, grids_o):
+        assert g.dtype == np.float64 and np.isfinite(g).all()
+        np.testing.assert_allclose(g, go, rtol=1e-10)
+    mu_o, sig_o = O.posterior_chol(X, y, Xs, ls_o)
+    assert idx[0] == _first_argmax(O.lcb(mu_o, sig_o, 4))
+    # the reference's likelihood on the same axes: -inf cells, so its "search" cannot tell the axes' cells apart
+    ref = PointSelector()
+    ref.name, ref.iteration = "t", 0
+    ref.measured_pts, ref.measured_vals = X, y
+    ref.feature_domain, ref.predicted_pts = [len(Xs)], Xs
+    ref.length_scales = axes
+    ref.update_surrogate()
+    assert any(np.isneginf(g).any() for g in ref.nlogml)

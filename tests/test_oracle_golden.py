@@ -129,3 +129,19 @@ def test_randomised_dag_shaped_cases(golden, name):
     _check(out, g, tight=0.1)
     if g["n_max_ties"] > 1:   # exact ties survive the restatement bit for bit: the same first index
         assert np.array_equal(out["index"], g["index"])
+
+
+@pytest.mark.parametrize("name", ["g1_m32", "g1_m50", "g4_ard_n2", "g2_n5_a", "g2_n20_tr", "g2_n12_a"])
+def test_logdet_likelihood_is_the_references_value_where_its_determinant_is_normal(golden, name):
+    """`nlml_cells_logdet` (the checker of the build's likelihood="logdet" mode) is NOT a restatement of the reference - it
+    takes log det K from a Cholesky factor instead of np.log(np.linalg.det(K)) - so it is pinned where the two must agree:
+    on every fixture whose reference grid is finite it reproduces the reference's float32 values to float32 rounding, with
+    the same first minimum."""
+    g = golden(name)
+    lsg = g["length_scales"]
+    cells = (np.stack(np.meshgrid(lsg[0], lsg[1], indexing="ij"), -1).reshape(-1, 2) if lsg.ndim == 2 else lsg.reshape(-1, 1))
+    ref = np.asarray(g["nlogml"], dtype=np.float32).ravel()
+    assert np.isfinite(ref).all()
+    got = O.nlml_cells_logdet(g["X"], g["y"], cells)
+    np.testing.assert_allclose(got, ref, rtol=2e-6)
+    assert int(np.argmin(got.astype(np.float32))) == int(np.flatnonzero(ref == ref.min())[0])
