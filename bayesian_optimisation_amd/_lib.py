@@ -81,6 +81,7 @@ SIGNATURES = {
                                         _i64, _i64, _i64, _i64, _p, _p, _p, _i64, _p]),
     "gpbo_fps_order_workspace_bytes": (_i64, [_i64]),
     "gpbo_fps_order_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i64, _p]),
+    "gpbo_fps_order_status": (C.c_int, [_p, _i64, _p, _p]),
     "gpbo_rescore_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gpbo_rescore_f64": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _f64, _i32, _f64, _f64, _i64,
                                    _f64, _i64, _i64, _i64, _p, _p, _p, _i64, _p]),

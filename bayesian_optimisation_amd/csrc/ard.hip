@@ -137,10 +137,37 @@ __global__ __launch_bounds__(256) void nlml_cell_kernel(const double *__restrict
 // rounds 2-4 (up to 8 GiB per sub-batch, swept once per panel by three launches) are gone.
 namespace fused {
 
-constexpr int TH = 256;                 // 4 waves; two workgroups per CU (LDS), up to 256 registers per lane
+// Timing-only variants (wrong results; tools/build_variant.sh ... "-DGPBO_DIAGNOSTICS -DGPBO_ARD_SKIP=bits"): what each phase
+// costs the whole launch - 1: no elimination of the diagonal block, 2: no kernel entries, 4: no second product,
+// 8: no first product.  Never in the shipped library.
+#if defined(GPBO_DIAGNOSTICS) && defined(GPBO_ARD_SKIP)
+constexpr int SKIP = GPBO_ARD_SKIP;
+#else
+constexpr int SKIP = 0;
+#endif
+
+#if defined(GPBO_DIAGNOSTICS) && defined(GPBO_ARD_STAMPS)
+// in-kernel timeline of workgroup 0's first cell: (tag << 56 | s_memtime) words per wave, tools/ard_stamps.py
+__device__ unsigned long long g_stamps[4][2048];
+__device__ int g_nstamps[4];
+#define ARD_STAMP(TAG)                                                                                                  \
+    do {                                                                                                               \
+        if (blockIdx.x == 0 && g == 0 && (threadIdx.x & 63) == 0) {                                                    \
+            const int n_ = g_nstamps[w];                                                                               \
+            if (n_ < 2048) { g_stamps[w][n_] = ((unsigned long long)(TAG) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffull); g_nstamps[w] = n_ + 1; } \
+        }                                                                                                              \
+    } while (0)
+#else
+#define ARD_STAMP(TAG) do { } while (0)
+#endif
+
+#ifndef GPBO_ARD_OCC
+#define GPBO_ARD_OCC 3                  /* workgroups (= waves per SIMD) the register budget of the kernel allows per CU */
+#endif
+constexpr int TH = 256;                 // 4 waves, one per SIMD; several workgroups per CU fill each other's serial phases
 constexpr int WAVES = TH / 64;
 constexpr int LDM = gpbo_pd::LDM;       // 66
-constexpr int SLOTS = 512;              // workgroups of one launch = scratch slots (2 per CU on 256 CUs)
+constexpr int SLOTS = 1024;             // most workgroups of one launch = scratch slots (4 per CU on 256 CUs)
 constexpr int DMAX = 16;                // widest feature bucket (GPBO_MAX_D)
 constexpr int64_t WORK_CAP = 16ll << 30;
 
@@ -155,12 +182,12 @@ __device__ __forceinline__ int opaque(int v) {
 // costs one save of the accumulators per panel.
 __device__ __attribute__((noinline)) int potrf_panel_call() {
     extern __shared__ double smem_[];
-    return gpbo_pd::potrf_diag64_lds(smem_, threadIdx.x);
+    return gpbo_pd::potrf_diag64_packed(smem_, threadIdx.x);
 }
 
 template <int D>
 struct Lds {
-    double M[2 * 64 * LDM];   // [D_jj ; I] -> [L_jj ; L_jj^-T]
+    double M[64 * LDM];       // packed (potrf_diag64_packed): (r, c <= r) D_jj -> L_jj; (r, c + 1 >= r + 1) I -> L_jj^-T
     double Xc[64 * D];        // coordinates of the panel's 64 columns
     double yc[64];            // y of the panel's columns
     double tab[GPBO_EXP_E];   // exp_neg's table
@@ -199,7 +226,7 @@ __global__ __launch_bounds__(256) void nlml_prep_kernel(const double *__restrict
 // MODE 0: the reference's likelihood, float32, log(exp(logdet)) (point_selector.py:117-119: np.log(np.linalg.det(K)));
 // MODE 1: fp64, log det straight from the factor (no underflow), NaN when a pivot fails.
 template <int D, int MODE>
-__global__ __launch_bounds__(TH, 2) void nlml_fused_kernel(const double *__restrict__ Xp, const double *__restrict__ yp, int N,
+__global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const double *__restrict__ Xp, const double *__restrict__ yp, int N,
                                                          int Nf, const double *__restrict__ il2p, int G, double jitter,
                                                          void *__restrict__ out_, double *scratch) {
     extern __shared__ double smem_[];
@@ -229,8 +256,11 @@ __global__ __launch_bounds__(TH, 2) void nlml_fused_kernel(const double *__restr
             // the panel's columns: coordinates, y; the identity under the diagonal block
             for (int e = tid; e < 64 * D; e += TH) S.Xc[e] = Xp[(int64_t)J0 * D + e];
             if (tid < 64) S.yc[tid] = yp[J0 + tid];
-            for (int e = tid; e < 64 * 64; e += TH) S.M[(64 + (e >> 6)) * LDM + (e & 63)] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+            ARD_STAMP(1);
+            for (int e = tid; e < 64 * 64; e += TH)
+                if ((e & 63) >= (e >> 6)) S.M[(e >> 6) * LDM + (e & 63) + 1] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
             __syncthreads();
+            ARD_STAMP(2);
 
             // rows of the panel in blocks of 32 (two row tiles): blocks 0, 1 = the diagonal block, block nblk = y's tile.
             // Wave w takes blocks w, w + 4, ...; the elimination of the diagonal block sits between the two products of
@@ -250,7 +280,7 @@ __global__ __launch_bounds__(TH, 2) void nlml_fused_kernel(const double *__restr
                     // ---- C' = K^T - L_j L_b^T: operands straight from memory, the next k-group pair in flight ----
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) { acc[ct][0] = d4_t{0.0, 0.0, 0.0, 0.0}; acc[ct][1] = d4_t{0.0, 0.0, 0.0, 0.0}; }
-                    if (nkp > 0) {
+                    if (nkp > 0 && !(SKIP & 8)) {
                         const d2_t *pa = Lf + ((int64_t)jt0 * KP) * 64 + lane;    // + ct * KP * 64
                         const d2_t *pb0 = Lf + ((int64_t)rt0 * KP) * 64 + lane;
                         const d2_t *pb1 = Lf + ((int64_t)rt1 * KP) * 64 + lane;
@@ -284,10 +314,12 @@ __global__ __launch_bounds__(TH, 2) void nlml_fused_kernel(const double *__restr
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+                    ARD_STAMP(3);
                     // K's entries: register r of tile (ct, t) of lane l is column J0 + 16 ct + l4 + 4 r, row 16 rt_t + l15
                     const int l15 = opaque(l15_), l4 = opaque(l4_);
                     const bool interior = b >= 2 && !yblk && (rt1 << 4) + 15 < N && J0 + 63 < N;
-                    if (interior) {   // every row and column is an observation, no diagonal entry
+                    if (SKIP & 2) {
+                    } else if (interior) {   // every row and column is an observation, no diagonal entry
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             const double *xp = Xp + (int64_t)(((t ? rt1 : rt0) << 4) + l15) * D;
@@ -341,6 +373,7 @@ __global__ __launch_bounds__(TH, 2) void nlml_fused_kernel(const double *__restr
                         }
                     }
                 }
+                ARD_STAMP(4);
                 if (it == 0) {
                     if (has && b < 2) {   // the diagonal block's rows: lower triangle into LDS
                         const int l15 = opaque(l15_), l4 = opaque(l4_);
@@ -351,15 +384,18 @@ __global__ __launch_bounds__(TH, 2) void nlml_fused_kernel(const double *__restr
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int lrow = 32 * b + 16 * t + l15, jc = 16 * ct + l4 + 4 * r;
-                                    S.M[lrow * LDM + jc] = (jc <= lrow) ? acc[ct][t][r] : 0.0;
+                                    if (jc <= lrow) S.M[lrow * LDM + jc] = acc[ct][t][r];
                                 }
                     }
                     __syncthreads();
-                    const int fbad = potrf_panel_call();
+                    ARD_STAMP(5);
+                    const int fbad = (SKIP & 1) ? 0 : potrf_panel_call();
+                    ARD_STAMP(6);
                     if (tid == 0 && fbad) S.bad = 1;
                     if (tid < 64) logdet_t += log(S.M[tid * LDM + tid]);
                 }
-                if (has && b >= 2) {
+                ARD_STAMP(7);
+                if (has && b >= 2 && !(SKIP & 4)) {
                     // ---- L^T = W C': stored in fragment order; y's row adds its squares to |z|^2 ----
                     const int l15 = opaque(l15_), l4 = opaque(l4_);
 #pragma unroll
@@ -369,7 +405,9 @@ __global__ __launch_bounds__(TH, 2) void nlml_fused_kernel(const double *__restr
                         for (int ct = 0; ct <= cq; ++ct)    // W is lower triangular
 #pragma unroll
                             for (int kg = 0; kg < 4; ++kg) {
-                                const double a = S.M[(64 + 16 * ct + 4 * kg + l4) * LDM + 16 * cq + l15];   // W[16cq + l15][16ct + 4kg + l4]
+                                // W[16cq + l15][16ct + 4kg + l4] = (L_jj^-T)[16ct + 4kg + l4][16cq + l15]: the packed image's upper half
+                                const double wv = S.M[(16 * ct + 4 * kg + l4) * LDM + 16 * cq + l15 + 1];
+                                const double a = (ct < cq || 4 * kg + l4 <= l15) ? wv : 0.0;
                                 o0 = mfma_f64_16x16x4(a, acc[ct][0][kg], o0);
                                 o1 = mfma_f64_16x16x4(a, acc[ct][1][kg], o1);
                             }
@@ -388,7 +426,9 @@ __global__ __launch_bounds__(TH, 2) void nlml_fused_kernel(const double *__restr
                     }
                 }
             }
+            ARD_STAMP(8);
             __syncthreads();   // the panel's fragments are visible to every wave; M and Xc are free
+            ARD_STAMP(9);
         }
 
         // log det K = 2 sum log L_ii (threads 0..63 = wave 0), |z|^2 from whichever waves owned y's tile
@@ -436,7 +476,19 @@ int launch(const double *Xp, const double *yp, int64_t N, int64_t Nf, const doub
     const void *fn = reinterpret_cast<const void *>(nlml_fused_kernel<D, MODE>);
     const size_t lds = sizeof(Lds<D>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPBO_ERR_LAUNCH;
-    hipLaunchKernelGGL((nlml_fused_kernel<D, MODE>), dim3((unsigned)slots_for(Nf, G)), dim3(TH), lds, st, Xp, yp, (int)N, (int)Nf,
+    // as many persistent workgroups as are resident at once (registers and LDS decide), never more than there are slots
+    static int resident = 0;   // per template instance; the device's answer does not change
+    if (resident == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TH, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        resident = per_cu * cus;
+    }
+    int64_t grid = slots_for(Nf, G);
+    if (grid > resident) grid = resident;
+    hipLaunchKernelGGL((nlml_fused_kernel<D, MODE>), dim3((unsigned)grid), dim3(TH), lds, st, Xp, yp, (int)N, (int)Nf,
                        il2p, (int)G, jitter, out, scratch);
     GPBO_CHECK_LAUNCH();
     return GPBO_OK;
@@ -486,6 +538,16 @@ extern "C" int gpbo_nlml_grid_batched_logdet_f64(const double *X, const double *
                                                  int64_t work_bytes, void *stream) {
     return fused::run<1>(X, y, N, d, ls_cells, G, jitter, out, work, work_bytes, stream);
 }
+
+#if defined(GPBO_DIAGNOSTICS) && defined(GPBO_ARD_STAMPS)
+extern "C" int gpbo_diag_ard_stamps(unsigned long long *out, int *counts) {   // host buffers [4][2048], [4]
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fused::g_stamps), sizeof(unsigned long long) * 4 * 2048) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(counts, HIP_SYMBOL(fused::g_nstamps), sizeof(int) * 4) != hipSuccess) return -1;
+    int z[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fused::g_nstamps), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 extern "C" int gpbo_nlml_cell_f64(const double *U, const double *alpha, const double *y, int64_t N, int64_t Np,
                                   const int32_t *info, float *out, void *stream) {

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(TH) void fps_coop_kernel(const double *__restrict__
         const double wmax = fps_wave_max(bv);
         if (lane == 0) s_val[w] = wmax;
         __syncthreads();
-        const double gmax = fps_row_max(s_val[lane & (TH / 64 - 1)]);   // 16 wave results, one per lane of every row of 16
+        const double gmax = fps_row_max(s_val[lane & (TH / 64 - 1)]);   // the TH / 64 wave results, repeated along every row of 16 lanes
         const int cand = (bv == gmax) ? bi32 : 0x7fffffff;              // lowest index among the points that attain it
         const int wmin = fps_wave_min(cand);
         if (lane == 0) s_idx[w] = wmin;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(FT) void fps_check_kernel(const FpsState *__restric
 constexpr int FG = 256;
 
 // centroid of the scaled observations, every coordinate in one pass: per-thread partial sums (rows tid, tid + 1024, ...), a
-// butterfly over the lanes of each wave, then thread k adds the sixteen wave sums of coordinate k in wave order - a fixed
+// butterfly over the lanes of each wave, then thread k adds the FT / 64 wave sums of coordinate k in wave order - a fixed
 // order of additions, so the same centroid (and the same first member) every time.  (One coordinate after the other with a
 // serial sum of the 1,024 partials cost 8 us per coordinate: 130 us of a 1.9-ms order at d = 16.)
 __global__ __launch_bounds__(FT) void fps_centroid_kernel(const double *__restrict__ X, int64_t N, int d, FpsLs ls,
@@ -479,6 +479,22 @@ extern "C" int64_t gpbo_fps_order_workspace_bytes(int64_t N) {
     return order_layout(N).total;
 }
 
+// 1 into *fell_back (device int32) when the last gpbo_fps_order_f64 on this workspace gave up its co-operative selection (a
+// bounded wait ran out: a workgroup was never scheduled) and installed the arrival order instead - still an exact route, but
+// a caller whose peers must hold the SAME factorisation (candidate shards of one step) has to know.  Enqueued on `stream`.
+namespace {
+__global__ void fps_status_kernel(const FpsState *__restrict__ stt, int32_t *__restrict__ out) { *out = stt->error ? 1 : 0; }
+}  // namespace
+
+extern "C" int gpbo_fps_order_status(const void *work, int64_t N, int32_t *fell_back, void *stream) {
+    if (!work || !fell_back || N < 1 || ((uintptr_t)work & 255)) return GPBO_ERR_ARG;
+    const OrderLayout L = order_layout(N);
+    const FpsState *stt = reinterpret_cast<const FpsState *>(reinterpret_cast<const char *>(work) + L.fps_off);
+    hipLaunchKernelGGL(fps_status_kernel, dim3(1), dim3(1), 0, gpbo_stream(stream), stt, fell_back);
+    GPBO_CHECK_LAUNCH();
+    return GPBO_OK;
+}
+
 // perm_out [N] int64: perm[0 .. J) = the farthest-point sequence, perm[J .. N) = every other observation in index order.
 // Xp_out [N x d] / yp_out [N] (optional; y may be NULL when yp_out is): rows perm[i] of X / y.  All device memory.
 extern "C" int gpbo_fps_order_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_host, int64_t J,
@@ -499,16 +515,13 @@ extern "C" int gpbo_fps_order_f64(const double *X, const double *y, int64_t N, i
     char *w = reinterpret_cast<char *>(work);
     double *mind = reinterpret_cast<double *>(w + L.mind_off);
     FpsState *stt = reinterpret_cast<FpsState *>(w + L.fps_off);
-    // Every observation in a register of one of G <= 16 workgroups of 1024 threads (fps_coop_kernel): PTS points per thread,
-    // as many as fit 64 registers of coordinates (PTS x d <= 32), G = ceil(N / (1024 PTS)).  Beyond 16 workgroups
-    // (N > 65,536 at d <= 8, > 32,768 above): one launch per member (fps_step_kernel).
     // Shape of the selection (see fps_coop_kernel): PTS points per thread, as many as 128 registers of coordinates hold
     // (8 up to d = 8, 4 above); one workgroup of 256 threads while it can hold the points, of 512 up to 4,096 (2,048)
     // points.  Beyond, workgroups of 512 threads share the points, EIGHT of them while 8 x 512 x pmax points suffice
     // (measured at N = 8192, d = 8, us per member: 512 x 2 x 8 workgroups 2.96, 256 x 4 x 8 3.13, 1024 x 1 x 8 3.2,
     // 256 x 2 x 16 3.43, 256 x 8 x 4 3.48: the hand-off grows with the number of slots a reader polls, the local part
-    // with the points per SIMD), sixteen up to 16 x 512 x pmax = 65,536 (32,768) points.
-    // GPBO_FPS_SHAPE="threads,points" overrides the choice (A/B runs; ignored when the points do not fit).
+    // with the points per SIMD), sixteen up to 16 x 512 x pmax = 65,536 (32,768) points.  Beyond those 16 workgroups: one
+    // launch per member (fps_step_kernel).
     const int pmax = d <= 8 ? 8 : 4;
     int th = 256, pts = 1;
     while (pts < pmax && (int64_t)th * pts < N) pts *= 2;
@@ -519,11 +532,16 @@ extern "C" int gpbo_fps_order_f64(const double *X, const double *y, int64_t N, i
         pts = 1;
         while (pts < pmax && (int64_t)th * pts * 8 < N) pts *= 2;
     }
-    // GPBO_FPS_MUTE=k (tests of the safety net only): co-operating workgroup k never publishes its record, as if it had never
-    // been scheduled - the others' bounded waits run out (~2 s), every workgroup leaves, fps_check_kernel installs the
-    // identity order.  The result is still a valid order (the arrival order: an exact route, it only prunes less).
-    static const int mute_wg = getenv("GPBO_FPS_MUTE") ? atoi(getenv("GPBO_FPS_MUTE")) : -1;
+    int mute_wg = -1;
+#ifdef GPBO_DIAGNOSTICS
+    // Diagnostics builds only (never the shipped library; tests load one through GPBO_LIB):
+    // GPBO_FPS_MUTE=k: co-operating workgroup k never publishes its record, as if it had never been scheduled - the others'
+    // bounded waits run out (~1 s), every workgroup leaves, fps_check_kernel installs the identity order (the arrival order:
+    // an exact route, it only prunes less) and gpbo_fps_order_status reports the fall-back.
+    // GPBO_FPS_SHAPE="threads,points" overrides the shape (A/B runs; ignored when the points do not fit).
+    static const int mute_env = getenv("GPBO_FPS_MUTE") ? atoi(getenv("GPBO_FPS_MUTE")) : -1;
     static const char *shape_env = getenv("GPBO_FPS_SHAPE");
+    mute_wg = mute_env;
     if (shape_env) {
         int eth = 0, epts = 0;
         if (sscanf(shape_env, "%d,%d", &eth, &epts) == 2 && (eth == 256 || eth == 512) &&
@@ -533,6 +551,7 @@ extern "C" int gpbo_fps_order_f64(const double *X, const double *y, int64_t N, i
             coop = (int64_t)th * pts < N;
         }
     }
+#endif
     const int64_t G = (N + (int64_t)th * pts - 1) / ((int64_t)th * pts);
     bool launched = false;
     if (G <= FPS_MAXW) {

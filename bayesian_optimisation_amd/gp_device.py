@@ -158,6 +158,12 @@ class DeviceGP:
                                                  self._ptr(perm), self._ptr(Xp), self._ptr(yp), self._ptr(self._work_order),
                                                  wob, self._stream())
                 _lib.check(st, "gpbo_fps_order_f64")
+                # did the co-operative selection give up (a workgroup never scheduled) and install the arrival order?  The
+                # flag stays on the device until somebody asks (order_fell_back(), last_screen): no synchronisation here
+                if getattr(self, "_order_flag", None) is None:
+                    self._order_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+                _lib.check(self.lib.gpbo_fps_order_status(self._ptr(self._work_order), N, self._ptr(self._order_flag),
+                                                          self._stream()), "gpbo_fps_order_status")
                 Xd, yd, self.perm = Xp, yp, perm
             self.X, self.y, self.ls_h = Xd, yd, ls_h
             self.N, self.Np, self.d = N, Np, d
@@ -185,8 +191,10 @@ class DeviceGP:
             if check:
                 info = int(self.info.item())  # synchronises
                 if info != 0:
+                    # the failing pivot as a row of the CALLER's arrays (gpbo_select_next_host_f64 reports the same row)
+                    row = info if self.perm is None or info > N else int(self.perm[info - 1].item()) + 1
                     raise np.linalg.LinAlgError(
-                        f"covariance matrix is not positive definite (pivot {info} of {N}); "
+                        f"covariance matrix is not positive definite (pivot {row} of {N}); "
                         "the reference's np.linalg.inv would raise or return garbage here")
         return self
 
@@ -203,6 +211,14 @@ class DeviceGP:
     @property
     def order(self) -> str:
         return "arrival" if self.perm is None else "fps"
+
+    def order_fell_back(self) -> bool:
+        """True when factorise(order="fps") came back with the ARRIVAL order because the co-operative selection gave up (one of
+        its workgroups was never scheduled: bounded waits, csrc/subset.hip).  Exact either way - but candidate shards of one
+        step must hold the same factorisation, so PointSelector votes on this flag.  Reads one device word (synchronises)."""
+        if self.perm is None or getattr(self, "_order_flag", None) is None:
+            return False
+        return bool(int(self._order_flag.item()))
 
     def _perm_host(self):
         return None if self.perm is None else self.perm[: self.N].cpu().numpy()
@@ -668,7 +684,7 @@ class DeviceGP:
                 chunk64, J2, self._ptr(self._result), C.byref(stats), self._ptr(self._work_rescore), rbytes,
                 self._stream())
             _lib.check(st, "gpbo_bound_select_f64")
-            self.last_screen = dict(mode="bound", order=self.order, prefix=J, prefix2=J2, survivors=int(stats.survivors),
+            self.last_screen = dict(mode="bound", order="arrival (fps fell back)" if self.order_fell_back() else self.order, prefix=J, prefix2=J2, survivors=int(stats.survivors),
                                     rescored=int(stats.rescored), rounds=int(stats.rounds), fallback=bool(stats.fallback),
                                     threshold=float(stats.tau), candidates=M)
         self._keep = Xsd
@@ -759,24 +775,34 @@ class DeviceGP:
     ARD_LDS_MAX_N = 64   # above: the batched blocked Cholesky (faster from here on; see nlml_grid)
 
     def nlml_grid(self, X, y, ls_cells, jitter: float = JITTER_KERNEL, likelihood: str = "reference") -> np.ndarray:
-        """-log marginal likelihood of every row of ls_cells [G x d]  (point_selector.py:111-156).
+        """-log marginal likelihood of every row of ls_cells [G x d]  (point_selector.py:111-156), as a host array.
 
         likelihood="reference": the reference's value - float32, log det K taken as np.log(np.linalg.det(K)), which
         underflows to -inf beyond N ~ 100 (reproduced for parity).  likelihood="logdet": fp64, log det K = 2 sum log L_ii
         from the factor - finite at any N, NaN where a pivot is not positive (a documented departure)."""
+        res = self.nlml_grid_device(X, y, ls_cells, jitter, likelihood).cpu().numpy()   # synchronises: the workspace is idle
+        # the scratch slots can be GiBs (512 x (N + 16) x N x 8 bytes): kept between the calls of one search (a
+        # coordinate-wise ARD search calls this once per axis and sweep) only while they are small
+        if getattr(self, "_work_ard", None) is not None and self._work_ard.numel() * 8 > self.ARD_KEEP_WORKSPACE_BYTES:
+            self._work_ard = None
+        return res
+
+    def nlml_grid_device(self, X, y, ls_cells, jitter: float = JITTER_KERNEL, likelihood: str = "reference"):
+        """The same grid left on the device (float32 / float64 tensor [G]); enqueues on the current stream, no read-back."""
         if likelihood not in ("reference", "logdet"):
             raise ValueError(f"likelihood must be 'reference' or 'logdet', got {likelihood!r}")
         torch = self.torch
         Xd, yd = self._dev(X), self._dev(y).reshape(-1)
         N, d = int(Xd.shape[0]), int(Xd.shape[1])
-        cells = self._dev(np.asarray(ls_cells, dtype=np.float64).reshape(-1, d))
+        cells = ls_cells if isinstance(ls_cells, torch.Tensor) else np.asarray(ls_cells, dtype=np.float64).reshape(-1, d)
+        cells = self._dev(cells).reshape(-1, d)
         G = int(cells.shape[0])
         logdet = likelihood == "logdet"
-        if N > self.ARD_LDS_MAX_N or logdet:
-            # one persistent workgroup per cell, the whole factorisation in one launch (csrc/ard.hip, round 5); small N in
-            # reference mode stays on the in-LDS kernel, whose elimination order is the one pinned against the reference's
-            # float32 ties (golden g4_ard_n2).
-            with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device):
+            if N > self.ARD_LDS_MAX_N or logdet:
+                # one persistent workgroup per cell, the whole factorisation in one launch (csrc/ard.hip, round 5); small N
+                # in reference mode stays on the in-LDS kernel, whose elimination order is the one pinned against the
+                # reference's float32 ties (golden g4_ard_n2).
                 out = torch.empty(G, dtype=torch.float64 if logdet else torch.float32, device=self.device)
                 need = int(self.lib.gpbo_nlml_grid_batched_workspace_bytes(N, G))
                 if need < 0:
@@ -788,18 +814,13 @@ class DeviceGP:
                 st = fn(self._ptr(Xd), self._ptr(yd), N, d, self._ptr(cells), G, float(jitter), self._ptr(out),
                         self._ptr(self._work_ard), need, self._stream())
                 _lib.check(st, "gpbo_nlml_grid_batched_logdet_f64" if logdet else "gpbo_nlml_grid_batched_f64")
-                res = out.cpu().numpy()   # synchronises: the workspace is no longer in use
-                # the scratch slots can be GiBs (512 x (N + 16) x N x 8 bytes): kept between the calls of one search (a
-                # coordinate-wise ARD search calls this once per axis and sweep) only while they are small
-                if self._work_ard.numel() * 8 > self.ARD_KEEP_WORKSPACE_BYTES:
-                    self._work_ard = None
-                return res
-        with torch.cuda.device(self.device):
-            out = torch.empty(G, dtype=torch.float32, device=self.device)
-            st = self.lib.gpbo_nlml_grid_f64(self._ptr(Xd), self._ptr(yd), N, d, self._ptr(cells), G, float(jitter),
-                                             self._ptr(out), self._stream())
-            _lib.check(st, "gpbo_nlml_grid_f64")
-            return out.cpu().numpy()
+            else:
+                out = torch.empty(G, dtype=torch.float32, device=self.device)
+                st = self.lib.gpbo_nlml_grid_f64(self._ptr(Xd), self._ptr(yd), N, d, self._ptr(cells), G, float(jitter),
+                                                 self._ptr(out), self._stream())
+                _lib.check(st, "gpbo_nlml_grid_f64")
+            self._keep_ard = (Xd, yd, cells)   # alive until the stream has consumed them
+        return out
 
     # -- dense covariance blocks for inspection (small problems only) --------------------------------------
     def cov_meas_host(self) -> np.ndarray:

@@ -281,6 +281,11 @@ class PointSelector:
             # history; not with the N == M quirk, which is keyed on the arrival index (:173)
             fps = not self._dense and np.shape(self.predicted_pts) != np.shape(X)
             gp.factorise(X, y, ls, JITTER_KERNEL, JITTER_ASSEMBLY, check=True, order="fps" if fps else "arrival")
+            if fps and self._shard and self._world()[0] > 1:
+                # the order is part of the factorisation: if the selection fell back to the arrival order on ANY rank, every
+                # rank refactorises in arrival order (identical factors on all shards: the cross-shard tie rule needs them)
+                if not D.all_agree(not gp.order_fell_back()):
+                    gp.factorise(X, y, ls, JITTER_KERNEL, JITTER_ASSEMBLY, check=True, order="arrival")
         self.last_update = "append" if appended else "factorise"
         if self._incremental:
             self._inc = (X.copy(), y.copy(), ls.copy())

@@ -97,7 +97,7 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best, variance_dtype="f64", winner=None):
+def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best, variance_dtype="f64", winner=None, check=True):
     """The oracle's Cholesky route (NumPy/LAPACK, BLAS threads = host cores) on a bounded sample of the
     same workload; factorisation excluded (it is amortised over the 2^21 candidates of a real step).  The sample is
     sized from a 1024-candidate probe so that the leg takes about `target_s` seconds."""
@@ -137,6 +137,12 @@ def cpu_baseline(X, y, Xs, ls, acq, target_s, fixed_sample, f_best, variance_dty
     t0 = time.perf_counter()
     idx = run(Xs[:ns])
     dt = time.perf_counter() - t0
+    if not check:   # the timed leg only (the `also` entries: their arg-max is checked by tests/test_gpu_fullsize.py)
+        cpu_baseline.last_window = None
+        return dict(value=ns / dt, unit="candidate acquisitions/s", cores=int(threads), kind="port",
+                    sample=f"first {ns} of the candidates, N={N}, d={d}, posterior + {acq.upper()} + arg-max, {dt:.1f} s wall, "
+                           f"factorisation excluded (oracle/gp_oracle.py posterior_chol"
+                           f"{', variance product in fp32' if variance_dtype == 'f32' else ''})"), idx, ns
     if vdt is np.float32:   # what is TIMED is the fp32 restatement; what the GPU's decision is checked against is fp64
         vdt = np.float64
     # Untimed: the oracle's (index, value) on the sample and on a window around the arg-max the GPU reported, so that the
@@ -273,7 +279,41 @@ def kernel_rooflines(gp, N, d, dtype, qei=False, event_stride=1):
                                 avg_launch_ms=round(q_avg, 4), bytes_per_candidate=8.0 * N,
                                 note="algorithmic bytes = the rows of V the stage reads (8 N per candidate); 36 N / 8 flop "
                                      "per candidate + S x 44 / 8 beside them")
+    if kstar_roofline is not None:
+        # north_star's second number inside the dict the driver parses: the K(X*,X) build's share of its own roofline(s)
+        roofline["kstar"] = dict(kernel=kstar_roofline["kernel"], bound=kstar_roofline["bound"], frac=kstar_roofline["frac"],
+                                 valu_frac=(kstar_roofline.get("valu") or {}).get("frac"),
+                                 avg_launch_ms=kstar_roofline["avg_launch_ms"])
     return roofline, kstar_roofline, qei_roofline
+
+
+def host_threads():
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:  # noqa: BLE001
+        threads = os.cpu_count() or 1
+    try:
+        threads = min(threads, len(os.sched_getaffinity(0)))
+    except Exception:  # noqa: BLE001
+        pass
+    return int(threads)
+
+
+def _pmc_ard_entry(N, d):
+    """The committed counter pass of the likelihood grid at this shape (profiles/pmc_ard.json, profiles/collect_ard.sh) and
+    whether ard.hip has changed since."""
+    try:
+        e = json.load(open(os.path.join(REPO, "profiles", "pmc_ard.json"))).get(f"N={N},d={d},cells=2500")
+        if not e:
+            return None, None
+        sys.path.insert(0, os.path.join(REPO, "profiles"))
+        from source_hash import kernel_source_hash
+
+        return e, e.get("kernel_source_hash") != kernel_source_hash("ard")
+    except Exception:  # noqa: BLE001
+        return None, None
 
 
 def main():
@@ -470,11 +510,14 @@ def main():
         fz = fact_entry(g3, A3, b3, n3)
         del g3, A3, b3, P3
         torch.cuda.empty_cache()
+        # CPU: the fp32 restatement of this config on a fixed sample of 4,096 candidates (the 8192 x 8192
+        # factorisation on the host, untimed, is the long part of this leg)
+        cb3, _, _ = cpu_baseline(X3, y3, sobol_points(n3, 4096, d3), ls3, "lcb", 2.0, 4096, float(np.min(y3)), "f32", check=False)
         return dict(workload="configs[3] (per-GPU shard): d=16, N=8192, M=2^19, fp64 factorisation + fp32 variance screen + "
                              "fp64 re-score of the survivors, LCB(explore=4)", value=m3 / (ms * 1e-3), unit="candidates/s",
                     ms_per_step=ms, steps=3, dtype="f32", argmax_index=i, nan_count=n, screen=scr,
                     slice_argmax_matches_fp64=bool(r64.best_idx == rs.best_idx), roofline=rf, kstar_roofline=krf,
-                    factorisation=fz)
+                    factorisation=fz, cpu_baseline=cb3)
 
     def also_config4():
         """BASELINE configs[4], per-GPU shard: q=8 Monte-Carlo qEI (512 fixed base samples), d=8, N=2048, 2^20 candidates
@@ -496,12 +539,130 @@ def main():
         ms, (v, i, n, info) = timed_steps(one, 3, g4)
         rf, krf, qrf = kernel_rooflines(g4, n4, d, "f64", qei=True)
         fz = fact_entry(g4, A4, b4, n4)
+        # CPU: the oracle's qEI (oracle.qei_mc: joint posterior of a batch, 8 x 8 Cholesky, the same 512 base samples) on the
+        # first 256 batches; its own factorisation timed separately and subtracted (once per step, as on the GPU side)
+        from oracle import gp_oracle as O
+
+        Pq = sobol_points(n4, 2048, d)
+        Zq = np.random.default_rng(7).standard_normal((512, 8))
+        t = time.perf_counter()
+        O.factorise(X4, y4, ls)
+        tf_ = time.perf_counter() - t
+        t = time.perf_counter()
+        q_cpu = O.qei_mc(X4, y4, Pq, ls, Zq, f_best=fb4, xi=0.0)
+        tq = max(time.perf_counter() - t - tf_, 1e-9)
+        rq = g4.score_qei(P4[:2048], Z4, f_best=fb4, xi=0.0, dense=True)
+        q_gpu = rq.acq.cpu().numpy() if rq.acq is not None else None
+        cb4 = dict(value=2048 / tq, unit="candidate acquisitions/s", cores=host_threads(), kind="port",
+                   sample=f"first 256 batches (2,048 candidates), N={n4}, d={d}, oracle.qei_mc, {tq:.2f} s wall, factorisation "
+                          f"({tf_:.2f} s) excluded",
+                   max_abs_diff_gpu_vs_oracle_on_sample=(float(np.max(np.abs(q_gpu - q_cpu))) if q_gpu is not None else None))
         del g4, A4, b4, P4
         torch.cuda.empty_cache()
         return dict(workload="configs[4] (per-GPU shard): q=8 Monte-Carlo qEI, 512 fixed base samples, d=8, N=2048, M=2^20 "
                              "(2^17 batches), fp64", value=m4 / (ms * 1e-3), unit="candidates/s", ms_per_step=ms, steps=3,
                     dtype="f64", argmax_batch=i, nan_count=n, qei_value=v, roofline=rf, kstar_roofline=krf, qei_roofline=qrf,
-                    factorisation=fz)
+                    factorisation=fz, cpu_baseline=cb4)
+
+    def also_ard_grid():
+        """SURVEY 8(f) rank 1, the step in front of the hot path inside update_surrogate (point_selector.py:104-163): 2,500
+        likelihood cells by themselves - the reference's own case (d=2, N=32, 50 x 50 cells) and the sizes of the BASELINE
+        surrogates - on the fp64 matrix-core roofline (N^3 / 3 flop per cell: one Cholesky), HIP events on the launch stream,
+        with the oracle's restatement of the reference's formula (inv + det per cell) on a sample of cells beside it."""
+        from oracle import gp_oracle as O
+
+        a = np.linspace(0.05, 3.0, 50)
+        grid2 = np.stack(np.meshgrid(a, a, indexing="ij"), -1).reshape(-1, 2)
+        out = []
+        ga = DeviceGP(dev)
+        for (n_, d_) in ((32, 2), (176, 2), (512, 8), (1024, 8)):
+            if d_ == 2:
+                cells = grid2
+            else:   # a d-feature search's cells: two coordinates over the 50 x 50 grid, the others at geomspace(0.2, 2)
+                cells = np.tile(np.geomspace(0.2, 2.0, d_), (2500, 1))
+                cells[:, :2] = grid2
+            Xa = sobol_points(0, n_, d_)
+            ya = rff_objective(Xa, ard_length_scales(d_))
+            Ad, bd, cd = ga._dev(Xa), ga._dev(ya), ga._dev(cells)
+            res_ref = ga.nlml_grid(Ad, bd, cd)                      # warm-up (allocates the workspace) + the values
+            res_ld = ga.nlml_grid(Ad, bd, cd, likelihood="logdet")
+            reps = 10
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ga.nlml_grid_device(Ad, bd, cd)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(reps):
+                o_dev = ga.nlml_grid_device(Ad, bd, cd)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / reps
+            flop = 2500.0 * float(n_) ** 3 / 3.0
+            tf = flop / (ms * 1e-3) / 1e12
+            fused = n_ > ga.ARD_LDS_MAX_N
+            ent, stale = _pmc_ard_entry(n_, d_)
+            rf = dict(bound="mfma" if fused else "latency", achieved=round(tf, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                      frac=round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                      kernel="nlml_fused_kernel (+ nlml_prep_kernel)" if fused else "nlml_grid_kernel",
+                      avg_launch_ms=round(ms, 4), flop_per_cell=float(n_) ** 3 / 3.0, cells_per_launch=2500,
+                      traffic=(ent or {}).get("fabric_bytes_per_call"), traffic_stale=stale,
+                      algorithmic_bytes=(ent or {}).get("algorithmic_bytes_per_call"),
+                      traffic_source=(f"committed PMC pass {ent['source']} (FETCH_SIZE x2 + WRITE_SIZE), not this run" if ent else None))
+            if not fused:
+                rf["note"] = ("one workgroup per cell, the bordered matrix in LDS, one workgroup barrier + LDS round trip per "
+                              "column: bound by that latency chain (33 dependent steps), not by the matrix cores or HBM")
+            # CPU: the oracle's restatement of eval_log_marginal (inv + det per cell), all host cores, a sample of cells
+            nc = 64 if n_ <= 176 else (16 if n_ <= 512 else 6)
+            sel = np.linspace(0, 2499, nc).astype(int)
+            t = time.perf_counter()
+            cpu = O.nlml_cells(Xa, ya, cells[sel])
+            cdt = time.perf_counter() - t
+            cpu_ld = O.nlml_cells_logdet(Xa, ya, cells[sel])
+            fin = np.isfinite(cpu)
+            ok_ref = bool(np.allclose(res_ref[sel][fin], cpu[fin], rtol=1e-5, atol=1e-2)) if fin.any() else None
+            out.append(dict(
+                workload=f"d={d_}, N={n_}, 2,500 likelihood cells (50 x 50 over two length scales), likelihood='reference'",
+                ms_per_call=ms, cells_per_s=2500.0 / (ms * 1e-3), steps=reps, roofline=rf,
+                finite_cells_reference_mode=int(np.isfinite(res_ref).sum()), finite_cells_logdet_mode=int(np.isfinite(res_ld).sum()),
+                logdet_mode_max_rel_err_vs_oracle_on_sample=float(np.max(np.abs(res_ld[sel] - cpu_ld) / np.abs(cpu_ld))),
+                reference_mode_matches_oracle_where_finite=ok_ref,
+                cpu_baseline=dict(value=nc / cdt, unit="cells/s", cores=host_threads(), kind="port",
+                                  sample=f"{nc} of the 2,500 cells (evenly spaced), oracle.nlml_cells (np.linalg.inv + det per cell, "
+                                         f"point_selector.py:116-120), {cdt:.2f} s wall")))
+        del ga
+        torch.cuda.empty_cache()
+        return out
+
+    def also_append():
+        """one more observation in O(N^2) (gpbo_append_f64) against factorising the N + 1 observations."""
+        na = 4096
+        Xa = sobol_points(0, na + 1, d)
+        ya = rff_objective(Xa, ls)
+        g5 = DeviceGP(dev)
+        A5, b5 = g5._dev(Xa), g5._dev(ya)
+        g5.factorise(A5[:na], b5[:na], ls, check=False)
+        g5.append(A5[na], float(ya[na]), check=False)
+        ts = []
+        for _ in range(5):
+            g5.factorise(A5[:na], b5[:na], ls, check=False)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            g5.append(A5[na], float(ya[na]), check=False)
+            torch.cuda.synchronize(dev)
+            ts.append((time.perf_counter() - t) * 1e3)
+        t = time.perf_counter()
+        for _ in range(5):
+            g5.factorise(A5, b5, ls, check=False)
+        torch.cuda.synchronize(dev)
+        fms = (time.perf_counter() - t) / 5 * 1e3
+        ref = DeviceGP(dev).factorise(A5, b5, ls, check=False)
+        g5.factorise(A5[:na], b5[:na], ls, check=False)
+        g5.append(A5[na], float(ya[na]), check=False)
+        da = float((g5.alpha[: na + 1] - ref.alpha[: na + 1]).abs().max() / ref.alpha[: na + 1].abs().max())
+        del g5, ref
+        torch.cuda.empty_cache()
+        return dict(workload=f"d={d}, N=4096 -> 4097: gpbo_append_f64 (column N of U, alpha recomputed) vs gpbo_factorise_f64 of all 4097",
+                    append_ms=float(np.median(ts)), refactorise_ms=fms, steps=5, alpha_max_rel_diff_vs_refactorisation=da,
+                    note="host wall clock around one call each (append ends with the status read-back)")
 
     def also_full_m():
         """All 2^24 candidates of configs[2] in ONE call on one GPU (what 8 ranks share out): per-candidate rate, index
@@ -688,11 +849,14 @@ def main():
             for _ in range(20):
                 v, i, n = step(False, g2, A2, b2, P2, 0)
             ms = (time.perf_counter() - t) / 20 * 1e3
+            cb1, _, _ = cpu_baseline(X2, y2, sobol_points(n2, 1 << 16, d), ls, "lcb", 2.0, 0, float(np.min(y2)), check=False)
             res["configs[1]"] = dict(workload="d=8, N=512, M=2^20, fp64, LCB(explore=4)", value=m2 / (ms * 1e-3),
-                                     unit="candidates/s", ms_per_step=ms, argmax_index=i, steps=20)
+                                     unit="candidates/s", ms_per_step=ms, argmax_index=i, steps=20, cpu_baseline=cb1)
         if (N, d, args.dtype, args.acq) == (4096, 8, "f64", "lcb"):
             res["configs[3]"] = also_config3()
             res["configs[4]"] = also_config4()
+            res["ard_grid"] = also_ard_grid()
+            res["append"] = also_append()
             res["configs[2]_all_2^24_candidates_on_one_gpu"] = also_full_m()
         if not qei:
             # the once-per-step part by itself: K(X,X) + fused Cholesky / inverse factor + alpha (gpbo_factorise_f64), on the

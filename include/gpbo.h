@@ -29,6 +29,18 @@ extern "C" {
 
 #define GPBO_VERSION 150 /* 0.5.0: the likelihood grid of any N in one launch (one workgroup per cell), a second likelihood mode (log det from the factor: gpbo_nlml_grid_*logdet*) */
 
+/* Environment switches the SHIPPED library reads (each once per process; none changes a result beyond the rounding of a
+ * different summation order, none is needed for normal use - they select between measured alternatives for A/B runs):
+ *   GPBO_F64_GROUPS=g     column groups of the fp64 variance kernel for large calls (default 8: one per XCD)
+ *   GPBO_OVERLAP=1        K(X*,X) of chunk c + 1 on a second stream beside the variance launch of chunk c (measured: no gain)
+ *   GPBO_PREFIX_VALU=1    the prefix bound's first-level mean from the difference-form kernel instead of the MFMA one
+ *   GPBO_FACTOR_OLD=1     the round-2 factorisation chain (Cholesky + triangular inverse) instead of the fused sweep
+ *   GPBO_NO_LOOKAHEAD=1   that chain without its helper stream
+ *   GPBO_CI_OPTS=a,b,c,d  launch-plan options of the fused sweep (csrc/cholinv_plan.h)
+ * Read only by DIAGNOSTICS builds (-DGPBO_DIAGNOSTICS: tools/build_variant.sh, never the shipped library; some produce
+ * wrong results on purpose to time a phase): GPBO_KSTAR_VARIANT, GPBO_SIGMA_VARIANT, GPBO_CI_STAMPS, GPBO_FPS_MUTE (fault
+ * injection), GPBO_FPS_SHAPE, and the compile-time GPBO_ARD_SKIP / GPBO_ARD_STAMPS of csrc/ard.hip. */
+
 #define GPBO_OK 0
 #define GPBO_ERR_ARG (-1)      /* null pointer, bad size/alignment, unsupported d */
 #define GPBO_ERR_LAUNCH (-2)   /* HIP reported a launch/runtime error */
@@ -269,6 +281,11 @@ int gpbo_bound_select_f64(const double *Xs, int64_t M, const double *acq_ub, con
 int64_t gpbo_fps_order_workspace_bytes(int64_t N);
 int gpbo_fps_order_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_host, int64_t J,
                        int64_t *perm_out, double *Xp_out, double *yp_out, void *work, int64_t work_bytes, void *stream);
+/* The selection runs on up to 16 co-operating workgroups that wait for each other with BOUNDED polls; should one of them
+ * never be scheduled the others give up after about a second and the ARRIVAL order is installed (exact as well, it only
+ * prunes less).  gpbo_fps_order_status writes 1 into *fell_back (device int32) when the last gpbo_fps_order_f64 on this
+ * workspace ended that way, else 0 - a caller whose peers must hold the same factorisation (candidate shards) checks it. */
+int gpbo_fps_order_status(const void *work, int64_t N, int32_t *fell_back, void *stream);
 
 /* int8-sliced variance screen (Ozaki-style splitting on the integer matrix cores, csrc/ozaki.hip): same role and
  * outputs as gpbo_posterior_acq_f32 - mean exactly the fp64 path's, variance from 20 exact int8 slice products

@@ -352,12 +352,15 @@ def test_farthest_point_order_and_the_factorisation_of_the_permuted_problem(N, d
     assert np.array_equal(pr.cpu().numpy(), perm)
 
 
-@pytest.mark.parametrize("N,d,J", [(12000, 5, 96), (20000, 16, 64), (40000, 3, 48), (1024, 1, 1024), (1025, 2, 7)])
+@pytest.mark.parametrize("N,d,J", [(12000, 5, 96), (20000, 16, 64), (40000, 3, 48), (40000, 9, 48), (70000, 2, 24),
+                                   (1024, 1, 1024), (1025, 2, 7)])
 def test_every_form_of_the_selection_gives_the_numpy_sequence(N, d, J):
-    """gpbo_fps_order_f64 alone (no factorisation at these sizes): several workgroups with one point (12,000 x 5) or two
-    points per thread (20,000 x 16) exchanging one record per member, one launch per member beyond 32,768 observations
-    (40,000 x 3), every observation a member (J = N), a ragged second point per thread (1,025) - the same sequence as NumPy,
-    the same every time, a permutation of 0 .. N-1, rows gathered in that order."""
+    """gpbo_fps_order_f64 alone (no factorisation at these sizes): co-operating workgroups of 512 threads with up to eight
+    points per thread (12,000 x 5: 8 workgroups; 20,000 x 16 and 40,000 x 3: 10) exchanging one record per member; ONE
+    LAUNCH PER MEMBER (fps_step_kernel, with its release / acquire ticket and its NaN rule) where 16 workgroups cannot hold
+    the points - beyond 32,768 observations at d > 8 (40,000 x 9: four points per thread, 20 workgroups) and beyond 65,536 at
+    d <= 8 (70,000 x 2); every observation a member (J = N); a ragged second point per thread (1,025) - the same sequence as
+    NumPy, the same every time, a permutation of 0 .. N-1, rows gathered in that order."""
     import torch
 
     rng = np.random.default_rng(N + d)
@@ -420,6 +423,26 @@ def test_nan_observations_never_break_the_order(N, d):
             DeviceGP().factorise(Xn, y, ls, order="fps")
         with pytest.raises(np.linalg.LinAlgError):
             DeviceGP().factorise(Xn, y, ls)
+
+
+def test_failed_pivot_is_reported_as_the_callers_row_in_both_orders():
+    """Two identical observations and no jitter: the factorisation fails at the second of them IN FACTORISATION ORDER; the
+    LinAlgError names that observation as a row of the CALLER's arrays whatever the order (as the host-pointer entry point
+    does through `info`)."""
+    import re
+
+    N, d = 3000, 4
+    X, y, Xs, ls = make_problem(N, 40000, d)
+    a, b = 700, 2100
+    X = X.copy()
+    X[b] = X[a]
+    rows = {}
+    for order in ("arrival", "fps"):
+        with pytest.raises(np.linalg.LinAlgError) as e:
+            DeviceGP().factorise(X, y, ls, 0.0, 0.0, order=order)
+        rows[order] = int(re.search(r"pivot (\d+) of", str(e.value)).group(1))
+        assert rows[order] - 1 in (a, b), (order, rows[order])
+    assert rows["arrival"] - 1 == b
 
 
 @pytest.mark.parametrize("order", ["sobol", "sorted", "reversed", "clustered_first"])
@@ -629,15 +652,21 @@ def test_routes_the_bound_must_not_take_with_a_permuted_factorisation():
 
 
 def test_a_workgroup_that_never_answers_ends_in_the_identity_order_not_in_a_hang():
-    """The co-operating workgroups of the selection wait for each other's records with BOUNDED polls.  GPBO_FPS_MUTE makes one
-    of them stay silent (as if it had never been scheduled): the others give up after ~2 s, every workgroup leaves, and the order
-    that comes back is the identity - the arrival order, with which the route is still exact.  (A child process: the switch is
-    read once per process.)"""
+    """The co-operating workgroups of the selection wait for each other's records with BOUNDED polls.  In a DIAGNOSTICS build
+    of the library (ab_libs/diag_fps.so: subset.hip with -DGPBO_DIAGNOSTICS, made by __graft_entry__.build(); the shipped
+    library does not read the switch) GPBO_FPS_MUTE makes one of them stay silent, as if it had never been scheduled: the
+    others give up after ~1 s, every workgroup leaves, the order that comes back is the identity - the arrival order, with
+    which the route is still exact - and the fall-back is REPORTED (gpbo_fps_order_status -> DeviceGP.order_fell_back,
+    last_screen["order"] == "arrival (fps fell back)").  (A child process: the switch is read once per process.)"""
     import os
     import subprocess
     import sys
 
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(repo, "ab_libs", "diag_fps.so")
+    if not os.path.exists(diag):
+        subprocess.run(["bash", os.path.join(repo, "tools", "build_variant.sh"), "diag_fps", "subset", "-DGPBO_DIAGNOSTICS"],
+                       check=True, capture_output=True, timeout=600)
     code = (
         "import sys, time; sys.path.insert(0, %r)\n"
         "import numpy as np, torch\n"
@@ -647,16 +676,20 @@ def test_a_workgroup_that_never_answers_ends_in_the_identity_order_not_in_a_hang
         "t = time.time(); gp = DeviceGP(chunk=8192).factorise(X, y, ls, order='fps'); torch.cuda.synchronize(); dt = time.time() - t\n"
         "perm = gp.perm.cpu().numpy()\n"
         "rb, r64 = gp.score_bound(Xs), gp.score(Xs)\n"
-        "print('RESULT', bool(np.array_equal(perm, np.arange(9000))), rb.best_idx == r64.best_idx, round(dt, 2))\n" % repo)
-    env = dict(os.environ, GPBO_FPS_MUTE="3")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        "print('RESULT', bool(np.array_equal(perm, np.arange(9000))), rb.best_idx == r64.best_idx, round(dt, 2), "
+        "gp.order_fell_back(), gp.last_screen['order'].replace(' ', '_'))\n" % repo)
+    base = {k: v for k, v in os.environ.items() if k not in ("GPBO_FPS_MUTE", "GPBO_LIB")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env=dict(base, GPBO_FPS_MUTE="3", GPBO_LIB=diag))
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
     assert line[1] == "True" and line[2] == "True", out.stdout
     assert float(line[3]) < 60.0
-    # and without the switch the same call gives the farthest-point order
+    assert line[4] == "True" and line[5] == "arrival_(fps_fell_back)", out.stdout
+    # the SHIPPED library does not read the switch: the same call with it set gives the farthest-point order
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
-                         env={k: v for k, v in os.environ.items() if k != "GPBO_FPS_MUTE"})
+                         env=dict(base, GPBO_FPS_MUTE="3"))
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
     assert line[1] == "False" and line[2] == "True" and float(line[3]) < 20.0, out.stdout
+    assert line[4] == "False" and line[5] == "fps", out.stdout
