@@ -161,8 +161,12 @@ __device__ int g_nstamps[4];
 #define ARD_STAMP(TAG) do { } while (0)
 #endif
 
+#ifndef GPBO_ARD_SYNC
+#define GPBO_ARD_SYNC 0                 /* the waves of a workgroup meet every SYNC double steps of the first product (power of two; 0: never) */
+#endif
+constexpr int SYNC = GPBO_ARD_SYNC;
 #ifndef GPBO_ARD_OCC
-#define GPBO_ARD_OCC 3                  /* workgroups (= waves per SIMD) the register budget of the kernel allows per CU */
+#define GPBO_ARD_OCC 2                  /* workgroups (= waves per SIMD) per CU: LDS (the elimination's image) allows two */
 #endif
 constexpr int TH = 256;                 // 4 waves, one per SIMD; several workgroups per CU fill each other's serial phases
 constexpr int WAVES = TH / 64;
@@ -182,12 +186,12 @@ __device__ __forceinline__ int opaque(int v) {
 // costs one save of the accumulators per panel.
 __device__ __attribute__((noinline)) int potrf_panel_call() {
     extern __shared__ double smem_[];
-    return gpbo_pd::potrf_diag64_packed(smem_, threadIdx.x);
+    return gpbo_pd::potrf_diag64_lds(smem_, threadIdx.x);
 }
 
 template <int D>
 struct Lds {
-    double M[64 * LDM];       // packed (potrf_diag64_packed): (r, c <= r) D_jj -> L_jj; (r, c + 1 >= r + 1) I -> L_jj^-T
+    double M[2 * 64 * LDM];   // [D_jj ; I] -> [L_jj ; L_jj^-T]
     double Xc[64 * D];        // coordinates of the panel's 64 columns
     double yc[64];            // y of the panel's columns
     double tab[GPBO_EXP_E];   // exp_neg's table
@@ -257,29 +261,29 @@ __global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const doub
             for (int e = tid; e < 64 * D; e += TH) S.Xc[e] = Xp[(int64_t)J0 * D + e];
             if (tid < 64) S.yc[tid] = yp[J0 + tid];
             ARD_STAMP(1);
-            for (int e = tid; e < 64 * 64; e += TH)
-                if ((e & 63) >= (e >> 6)) S.M[(e >> 6) * LDM + (e & 63) + 1] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+            for (int e = tid; e < 64 * 64; e += TH) S.M[(64 + (e >> 6)) * LDM + (e & 63)] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
             __syncthreads();
             ARD_STAMP(2);
 
             // rows of the panel in blocks of 32 (two row tiles): blocks 0, 1 = the diagonal block, block nblk = y's tile.
             // Wave w takes blocks w, w + 4, ...; the elimination of the diagonal block sits between the two products of
-            // every wave's FIRST block (all waves pass through iteration 0, with or without a block).
+            // every wave's FIRST block.  All four waves pass through every iteration, with or without a block: they meet at
+            // a barrier every SYNC steps of the first product (see there).
             const int nblk = (Nf - J0) >> 5;
             const int jt0 = J0 >> 4;
             const int nkp = J0 >> 3;
-            for (int it = 0;; ++it) {
+            const int nit = (nblk + WAVES) / WAVES;     // ceil((nblk + 1) / WAVES)
+            for (int it = 0; it < nit; ++it) {
                 const int b = w + WAVES * it;
                 const bool has = (b <= nblk);
-                if (it > 0 && !has) break;
                 const bool yblk = (b == nblk);
-                const int rt0 = jt0 + 2 * b;
-                const int rt1 = yblk ? rt0 : rt0 + 1;       // y's block has one tile (computed twice, stored once)
+                const int rt0 = jt0 + 2 * (has ? b : 0);
+                const int rt1 = (yblk || !has) ? rt0 : rt0 + 1;       // y's block has one tile (computed twice, stored once)
                 d4_t acc[4][2];
-                if (has) {
-                    // ---- C' = K^T - L_j L_b^T: operands straight from memory, the next k-group pair in flight ----
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) { acc[ct][0] = d4_t{0.0, 0.0, 0.0, 0.0}; acc[ct][1] = d4_t{0.0, 0.0, 0.0, 0.0}; }
+                for (int ct = 0; ct < 4; ++ct) { acc[ct][0] = d4_t{0.0, 0.0, 0.0, 0.0}; acc[ct][1] = d4_t{0.0, 0.0, 0.0, 0.0}; }
+                {
+                    // ---- C' = K^T - L_j L_b^T: operands straight from memory, the next k-group pair in flight ----
                     if (nkp > 0 && !(SKIP & 8)) {
                         const d2_t *pa = Lf + ((int64_t)jt0 * KP) * 64 + lane;    // + ct * KP * 64
                         const d2_t *pb0 = Lf + ((int64_t)rt0 * KP) * 64 + lane;
@@ -302,23 +306,41 @@ __global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const doub
                             acc[2][0] = mfma_f64_16x16x4(F.f2.y, F.g0.y, acc[2][0]); acc[2][1] = mfma_f64_16x16x4(F.f2.y, F.g1.y, acc[2][1]);
                             acc[3][0] = mfma_f64_16x16x4(F.f3.y, F.g0.y, acc[3][0]); acc[3][1] = mfma_f64_16x16x4(F.f3.y, F.g1.y, acc[3][1]);
                         };
-                        load(A, 0);
+                        // The four waves read the SAME panel rows (pa) beside their own: kept within SYNC steps of each other
+                        // (a bare barrier - no memory is exchanged through it), the second to fourth reader find those lines
+                        // in L2 / L1 instead of fetching them again; left to drift, every wave fetched them from HBM and the
+                        // first product ran at the memory system's rate (102 GB per 2,500 cells at N = 1024: 4.8x the factor).
+                        if (has) load(A, 0);
                         for (int kp = 0; kp < nkp; kp += 2) {
-                            load(B, kp + 1);
-                            __builtin_amdgcn_sched_barrier(0);
-                            mult(A);
-                            __builtin_amdgcn_sched_barrier(0);
-                            load(A, (kp + 2 < nkp) ? kp + 2 : kp + 1);   // (the last step re-loads a pair it has)
-                            __builtin_amdgcn_sched_barrier(0);
-                            mult(B);
-                            __builtin_amdgcn_sched_barrier(0);
+                            if (SYNC > 0 && (kp & (2 * SYNC - 1)) == 0) __builtin_amdgcn_s_barrier();
+                            if (has) {
+                                load(B, kp + 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                                mult(A);
+                                __builtin_amdgcn_sched_barrier(0);
+                                load(A, (kp + 2 < nkp) ? kp + 2 : kp + 1);   // (the last step re-loads a pair it has)
+                                __builtin_amdgcn_sched_barrier(0);
+                                mult(B);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
+                }
+                if (has) {
                     ARD_STAMP(3);
                     // K's entries: register r of tile (ct, t) of lane l is column J0 + 16 ct + l4 + 4 r, row 16 rt_t + l15
                     const int l15 = opaque(l15_), l4 = opaque(l4_);
                     const bool interior = b >= 2 && !yblk && (rt1 << 4) + 15 < N && J0 + 63 < N;
                     if (SKIP & 2) {
+                    } else if (yblk) {       // y's tile: row 0 carries y, no kernel entry at all
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const double v = (l15 == 0) ? S.yc[16 * ct + l4 + 4 * r] : 0.0;
+                                acc[ct][0][r] = v - acc[ct][0][r];
+                                acc[ct][1][r] = acc[ct][0][r];
+                            }
                     } else if (interior) {   // every row and column is an observation, no diagonal entry
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
@@ -342,7 +364,7 @@ __global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const doub
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
-                    } else {          // the diagonal block, rows / columns of the padding, y's tile
+                    } else {          // the diagonal block, rows / columns of the padding
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             const int rt = t ? rt1 : rt0;
@@ -365,7 +387,6 @@ __global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const doub
                                     double v = exp_neg(0.5 * a, S.tab);
                                     if (row == col) v += jitter;
                                     if (row >= N || col >= N) v = (row == col) ? 1.0 : 0.0;
-                                    if (rt == RTY) v = (l15 == 0) ? S.yc[jc] : 0.0;
                                     acc[ct][t][r] = v - acc[ct][t][r];
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const doub
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int lrow = 32 * b + 16 * t + l15, jc = 16 * ct + l4 + 4 * r;
-                                    if (jc <= lrow) S.M[lrow * LDM + jc] = acc[ct][t][r];
+                                    S.M[lrow * LDM + jc] = (jc <= lrow) ? acc[ct][t][r] : 0.0;
                                 }
                     }
                     __syncthreads();
@@ -405,9 +426,7 @@ __global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const doub
                         for (int ct = 0; ct <= cq; ++ct)    // W is lower triangular
 #pragma unroll
                             for (int kg = 0; kg < 4; ++kg) {
-                                // W[16cq + l15][16ct + 4kg + l4] = (L_jj^-T)[16ct + 4kg + l4][16cq + l15]: the packed image's upper half
-                                const double wv = S.M[(16 * ct + 4 * kg + l4) * LDM + 16 * cq + l15 + 1];
-                                const double a = (ct < cq || 4 * kg + l4 <= l15) ? wv : 0.0;
+                                const double a = S.M[(64 + 16 * ct + 4 * kg + l4) * LDM + 16 * cq + l15];   // W[16cq + l15][16ct + 4kg + l4]
                                 o0 = mfma_f64_16x16x4(a, acc[ct][0][kg], o0);
                                 o1 = mfma_f64_16x16x4(a, acc[ct][1][kg], o1);
                             }

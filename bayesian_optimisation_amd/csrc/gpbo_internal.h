@@ -44,6 +44,26 @@ __device__ __forceinline__ double gpbo_acquisition(int kind, double mu, double s
     return imp * cdf + sigma * pdf;
 }
 
+// The same acquisition as an UPPER BOUND (the exact prefix bound: mu reported from below, sigma from above): a value that is
+// >= what gpbo_acquisition COMPUTES for any (mu' >= mu, sigma' <= sigma), roundings included.
+//   LCB (explore >= 0 on this route): p0 * sigma - mu is monotone operation by operation - the plain form is the bound.
+//   EI: imp Phi(z) + sigma phi(z) cancels for z << 0 (the two terms agree to 1 / z^2) and erfc / exp amplify the rounding of
+//   their arguments by ~ 2 z^2: the computed value carries an absolute error of up to ~ (c + 4 z^2) eps (|t1| + t2).  That
+//   bound is evaluated HERE, at the bound's own point - g(z) = (64 + 4 z^2) phi(z) decreases in |z| and sigma phi(z) grows
+//   with sigma and with imp, so it dominates the error of the plain pass's evaluation at (mu', sigma') as well - and added
+//   twice (once for each of the two evaluations being compared), plus a floor for results that underflow.
+__device__ __forceinline__ double gpbo_acquisition_ub(int kind, double mu, double sigma, double p0, double p1) {
+    if (kind == GPBO_ACQ_LCB) return p0 * sigma - mu;
+    const double imp = p0 - mu - p1;
+    if (!(sigma > 0.0)) return (sigma == 0.0) ? fmax(imp, 0.0) : sigma;  // sigma NaN propagates
+    const double z = imp / sigma;
+    const double cdf = 0.5 * erfc(-z * 0.70710678118654752440);
+    const double pdf = exp(-0.5 * z * z) * 0.39894228040143267794;
+    const double t1 = imp * cdf, t2 = sigma * pdf;
+    const double pad = 2.0 * (64.0 + 4.0 * z * z) * 1.1102230246251565e-16 * (fabs(t1) + t2);
+    return (t1 + t2) + pad + 1e-300;
+}
+
 // launchers implemented in the individual .hip files (host side, enqueue only)
 // prefix bound: variance floor / pad (see sigma_acq_kernel's epilogue)
 #define GPBO_BOUND_VAR_PAD 1e-8

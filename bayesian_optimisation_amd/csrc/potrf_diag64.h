@@ -135,114 +135,5 @@ __device__ __forceinline__ int potrf_diag64_lds(double *M, int tid) {
     return first_bad;
 }
 
-// The same elimination on a PACKED image (half the LDS): one [64 x LDM] array P holds both triangular halves,
-//     entry (r, c),     c <= r:   the block's lower triangle  ->  L
-//     entry (r, c + 1), c >= r:   the identity                ->  L^-T (upper triangular, shifted one column to the right)
-// The operations, their order and their operands are those of potrf_diag64_lds (same values bit for bit); what changes is
-// the addressing, and that the zero halves of the triangular 16 x 16 blocks are masks instead of stored zeros.
-// The caller fills the lower triangle with the block and the shifted upper one with the identity; nothing else is read.
-__device__ __forceinline__ int potrf_diag64_packed(double *P, int tid) {
-    asm volatile("" : "+v"(tid));   // inside a caller's loop: the lane masks below are recomputed per call, not hoisted
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, l4 = lane >> 4;
-    int first_bad = 0;  // 1-based column of the first non-positive / non-finite pivot (wave 0)
-    // (1): lanes 0..15 hold rows 16s.. of the block, lanes 16..31 the identity rows (lanes 32..63 mirror 0..31 and write
-    // nothing), columns 16s..16s+15
-    auto eliminate = [&](int s) {
-        const int l31 = lane & 31;
-        const bool ip = l31 >= PB;
-        const int rl = ip ? l31 - PB : l31;
-        double *row = P + (PB * s + rl) * LDM + PB * s + (ip ? 1 : 0);
-        double x[PB];
-#pragma unroll
-        for (int k = 0; k < PB; ++k) {
-            const double v = row[k];
-            x[k] = (ip && k < rl) ? 0.0 : v;     // (block rows: what lies right of the diagonal is never used)
-        }
-#pragma unroll
-        for (int c = 0; c < PB; ++c) {
-            const double piv = readlane_f64(x[c], c);
-            const bool ok = (piv > 0.0) && (piv < 1.0e300);
-            first_bad = (!ok && first_bad == 0) ? PB * s + c + 1 : first_bad;
-            x[c] *= rsqrt_refined(piv);
-#pragma unroll
-            for (int k = c + 1; k < PB; ++k) x[k] = fma(-x[c], readlane_f64(x[c], k), x[k]);
-        }
-        if (lane < 2 * PB) {
-#pragma unroll
-            for (int k = 0; k < PB; ++k)
-                if (ip ? (k >= rl) : (k <= rl)) row[k] = x[k];
-        }
-    };
-    // (2): X <- X * T, X = the 16 rows of row block rb (of the block, or ip: of the identity part) in column block s,
-    // T = L_ss^-T (identity part, diagonal block s: upper triangular)
-    auto panel = [&](bool ip, int rb, int s) {
-        const int sh = ip ? 1 : 0;
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < PB; kk += 4) {
-            const double a = P[(PB * rb + l15) * LDM + PB * s + kk + l4 + sh];
-            const double t = P[(PB * s + kk + l4) * LDM + PB * s + l15 + 1];
-            const double b = (kk + l4 <= l15) ? t : 0.0;
-            acc = mfma_f64_16x16x4(a, b, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) P[(PB * rb + l4 + 4 * r) * LDM + PB * s + l15 + sh] = acc[r];
-    };
-    // (3): [row block rb, column block c] -= [row block rb, column block s] * L[block c, block s]^T
-    auto trail = [&](bool ip, int rb, int c, int s) {
-        const int sh = ip ? 1 : 0;
-        const bool adiag = ip && rb == s;       // operand = the identity part's own diagonal block: upper triangular
-        const bool cdiag = !ip && rb == c;      // result = a diagonal block of the block itself: lower triangle only
-        d4_t acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = P[(PB * rb + l4 + 4 * r) * LDM + PB * c + l15 + sh];
-#pragma unroll
-        for (int kk = 0; kk < PB; kk += 4) {
-            const double av = P[(PB * rb + l15) * LDM + PB * s + kk + l4 + sh];
-            const double a = (adiag && kk + l4 < l15) ? 0.0 : -av;
-            const double b = P[(PB * c + l15) * LDM + PB * s + kk + l4];
-            acc = mfma_f64_16x16x4(a, b, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (!cdiag || l15 <= l4 + 4 * r) P[(PB * rb + l4 + 4 * r) * LDM + PB * c + l15 + sh] = acc[r];
-    };
-
-    constexpr int NS = NB / PB;  // 4
-    if (w == 0) eliminate(0);
-    __syncthreads();
-    for (int s = 0; s < NS; ++s) {
-        // (2) the non-zero panel blocks: row blocks s+1..3 of the block and 0..s-1 of the identity part - always three
-        if (w < NS - 1) {
-            const int t = w;  // 0..2
-            const int nA = NS - 1 - s;
-            if (t < nA) panel(false, s + 1 + t, s); else panel(true, t - nA, s);
-        }
-        __syncthreads();
-        if (s == NS - 1) break;
-        // (3) trailing blocks; wave 0: the next diagonal sub-block, then its elimination
-        if (w == 0) {
-            trail(false, s + 1, s + 1, s);
-            eliminate(s + 1);
-        } else if (w < NS) {
-            int q = 0;
-            for (int c = s + 1; c < NS; ++c) {
-                for (int R = c; R < NS; ++R) {  // the block, lower block triangle
-                    if (R == s + 1 && c == s + 1) continue;
-                    if (q % 3 == w - 1) trail(false, R, c, s);
-                    ++q;
-                }
-                for (int m = 0; m <= s; ++m) {  // identity part: its rows 0..16(s+1)-1 are non-zero in block s
-                    if (q % 3 == w - 1) trail(true, m, c, s);
-                    ++q;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    return first_bad;
-}
 
 }  // namespace gpbo_pd

@@ -312,7 +312,8 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
         // the bound holds whenever the plain variance is above -1e-9 (observed: 1e-13)
         if (ncb > 0) var = fmax(var, 0.0) + GPBO_BOUND_VAR_PAD;
         const double sigma = sqrt(fabs(var));  // abs, then sqrt: point_selector.py:98
-        const double acq = acquisition(acq_kind, mu, sigma, p0, p1);
+        // (prefix bound: the acquisition rounded outward, so that it bounds what the plain pass computes - gpbo_internal.h)
+        const double acq = (ncb > 0) ? gpbo_acquisition_ub(acq_kind, mu, sigma, p0, p1) : acquisition(acq_kind, mu, sigma, p0, p1);
         if (valid) {
             if (mu_out) mu_out[c] = mu;
             if (sigma_out) sigma_out[c] = sigma;
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void split_finish_kernel(const double *__restr
     double var = prior_var - ssq;
     if (var_pad > 0.0) var = fmax(var, 0.0) + var_pad;
     const double sigma = sqrt(fabs(var));
-    const double acq = acquisition(acq_kind, mu, sigma, p0, p1);
+    const double acq = (var_pad > 0.0) ? gpbo_acquisition_ub(acq_kind, mu, sigma, p0, p1) : acquisition(acq_kind, mu, sigma, p0, p1);
     if (valid) {
         if (mu_out) mu_out[c] = mu;
         if (sigma_out) sigma_out[c] = sigma;

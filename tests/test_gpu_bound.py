@@ -426,23 +426,21 @@ def test_nan_observations_never_break_the_order(N, d):
 
 
 def test_failed_pivot_is_reported_as_the_callers_row_in_both_orders():
-    """Two identical observations and no jitter: the factorisation fails at the second of them IN FACTORISATION ORDER; the
-    LinAlgError names that observation as a row of the CALLER's arrays whatever the order (as the host-pointer entry point
-    does through `info`)."""
+    """An observation with a NaN coordinate makes its own pivot the first one that fails, wherever the factorisation's order
+    puts it: the LinAlgError names that observation as a row of the CALLER's arrays in both orders (as the host-pointer entry
+    point does through `info`) - round 4 reported the position in factorisation order for order="fps"."""
     import re
 
     N, d = 3000, 4
-    X, y, Xs, ls = make_problem(N, 40000, d)
-    a, b = 700, 2100
+    X, y, _, ls = make_problem(N, 8, d)
+    bad = 2100
     X = X.copy()
-    X[b] = X[a]
-    rows = {}
+    X[bad, 1] = np.nan
     for order in ("arrival", "fps"):
         with pytest.raises(np.linalg.LinAlgError) as e:
-            DeviceGP().factorise(X, y, ls, 0.0, 0.0, order=order)
-        rows[order] = int(re.search(r"pivot (\d+) of", str(e.value)).group(1))
-        assert rows[order] - 1 in (a, b), (order, rows[order])
-    assert rows["arrival"] - 1 == b
+            DeviceGP().factorise(X, y, ls, order=order)
+        row = int(re.search(r"pivot (\d+) of", str(e.value)).group(1))
+        assert row - 1 == bad, (order, row)
 
 
 @pytest.mark.parametrize("order", ["sobol", "sorted", "reversed", "clustered_first"])
@@ -567,9 +565,9 @@ def test_shipping_bound_holds_for_every_candidate_at_both_levels(problem):
         assert np.all(m <= mu)           # the mean is reported from below (kstar_mfma.hip), never above the plain pass's
         assert np.all(s >= sig) and np.all(a >= acq), (problem, J, float((sig - s).max()))
         _, _, ae = _prefix_pass(gp, Xs, J, kind=_lib.ACQ_EI, p0=fb, p1=0.0)
-        # (EI = imp Phi(z) + sigma phi(z) cancels for z << 0: values of 1e-100 carry rounding noise of their own size; the
-        #  selection's slack, 1e-10 max(1, |t|), is what covers it - rescore.hip)
-        assert np.all(ae >= ei - 1e-13 * max(1.0, float(ei.max()))), (problem, J, float((ei - ae).max()))
+        # (EI = imp Phi(z) + sigma phi(z) cancels for z << 0: values of 1e-100 carry rounding noise of their own size - the
+        #  bound form rounds outward by that noise, gpbo_acquisition_ub: no tolerance here)
+        assert np.all(ae >= ei), (problem, J, float((ei - ae).max()), int(np.argmax(ei - ae)))
         if prev is not None:
             assert np.all(s <= prev + 1e-13)
         prev = s

@@ -924,3 +924,34 @@ def test_ard_coordinate_search_d8_n512_logdet_mode_picks_finite_cells():
     ref.length_scales = axes
     ref.update_surrogate()
     assert any(np.isneginf(g).any() for g in ref.nlogml)
+
+
+def test_dense_and_next_point_only_selectors_agree_beyond_the_rounding_of_the_order():
+    """dense_outputs=False factorises the observations in farthest-point order (N > 128 here, so the order really differs from
+    the arrival order), dense_outputs=True in arrival order: the same GP, roundings of a different order.  Both selectors
+    return the same multi-index whenever the top-2 gap of the acquisition exceeds that rounding (1e-8), on a grid WITH exact
+    ties (duplicated candidate rows: lowest index wins in both) and near-maxima; and the index is the oracle's."""
+    N, d = 700, 3
+    X, y, Xs, ls = make_problem(N, 40000, d)
+    Xs = Xs.copy()
+    Xs[20000:20050] = Xs[100:150]            # exact duplicates: exact ties wherever one of them is the maximum
+    out = {}
+    for dense in (True, False):
+        ps = PointSelector(dense_outputs=dense)
+        ps.name, ps.iteration = "t", 0
+        ps.measured_pts, ps.measured_vals = X, y
+        ps.feature_domain, ps.predicted_pts = [len(Xs)], Xs
+        ps.set_kernel_params(ls)
+        ps.update_surrogate()
+        out[dense] = {e: ps.lower_confidence_bound(e) for e in (0.5, 1.0, 4.0, 10.0)}
+    mu_o, sig_o = O.posterior_chol(X, y, Xs, ls)
+    for e in (0.5, 1.0, 4.0, 10.0):
+        acq = O.lcb(mu_o, sig_o, e)
+        top = np.sort(acq)[::-1]
+        first = _first_argmax(acq)
+        gap = top[0] - top[top < top[0]][0] if (top < top[0]).any() else np.inf
+        if gap > 1e-8:
+            assert out[True][e][0] == first == out[False][e][0], (e, gap)
+        else:   # a near-tie: each mode may pick either of the near-maxima, nothing else
+            near = set(np.flatnonzero(acq >= top[0] - 1e-8).tolist())
+            assert int(out[True][e][0]) in near and int(out[False][e][0]) in near
