@@ -132,9 +132,12 @@ __global__ __launch_bounds__(256) void nlml_cell_kernel(const double *__restrict
 // accumulators ARE the fragments later panels load as operands.  Nothing is transposed through LDS, and L lives in memory
 // in FRAGMENT ORDER:   frag(rt, kg)[lane] = L[16 rt + (lane & 15)][4 kg + (lane >> 4)], two k-groups interleaved per lane
 // (one 16-byte load / store per lane, 1 KiB contiguous per wave instruction).
-// The workgroup is persistent (cells g = blockIdx.x, + gridDim.x, ...) and owns one scratch slot of (Nf + 16) x Nf
-// doubles, written once and read (N / 64) / 3 times on average per cell - the matrices of the launch-chain version of
-// rounds 2-4 (up to 8 GiB per sub-batch, swept once per panel by three launches) are gone.
+// The workgroup is persistent (cells g = blockIdx.x, + gridDim.x, ...; as many workgroups as are resident at once: two per
+// CU) and owns one scratch slot of (Nf + 16) x Nf doubles, written once and read (N / 64) / 3 times on average per cell -
+// the matrices of the launch-chain version of rounds 2-4 (up to 8 GiB per sub-batch, swept once per panel by three
+// launches: 11.4 / 61 ms for 2,500 cells at N = 512 / 1024) are gone.  Measured (one MI355X, 2,500 cells, d = 8):
+// N = 176 / 512 / 1024: 0.65 / 4.2 / 23.8 ms = 0.09 / 0.34 / 0.48 of the fp64 matrix peak; where the rest goes
+// (tools/ard_stamps.py, knock-out builds): DESIGN.md section 4a.
 namespace fused {
 
 // Timing-only variants (wrong results; tools/build_variant.sh ... "-DGPBO_DIAGNOSTICS -DGPBO_ARD_SKIP=bits"): what each phase
@@ -161,17 +164,11 @@ __device__ int g_nstamps[4];
 #define ARD_STAMP(TAG) do { } while (0)
 #endif
 
-#ifndef GPBO_ARD_SYNC
-#define GPBO_ARD_SYNC 0                 /* the waves of a workgroup meet every SYNC double steps of the first product (power of two; 0: never) */
-#endif
-constexpr int SYNC = GPBO_ARD_SYNC;
-#ifndef GPBO_ARD_OCC
-#define GPBO_ARD_OCC 2                  /* workgroups (= waves per SIMD) per CU: LDS (the elimination's image) allows two */
-#endif
+constexpr int OCC = 2;                  // workgroups (= waves per SIMD) per CU: LDS (the elimination's image) allows two
 constexpr int TH = 256;                 // 4 waves, one per SIMD; several workgroups per CU fill each other's serial phases
 constexpr int WAVES = TH / 64;
 constexpr int LDM = gpbo_pd::LDM;       // 66
-constexpr int SLOTS = 1024;             // most workgroups of one launch = scratch slots (4 per CU on 256 CUs)
+constexpr int SLOTS = 512;              // most workgroups of one launch = scratch slots (2 per CU on 256 CUs)
 constexpr int DMAX = 16;                // widest feature bucket (GPBO_MAX_D)
 constexpr int64_t WORK_CAP = 16ll << 30;
 
@@ -230,7 +227,7 @@ __global__ __launch_bounds__(256) void nlml_prep_kernel(const double *__restrict
 // MODE 0: the reference's likelihood, float32, log(exp(logdet)) (point_selector.py:117-119: np.log(np.linalg.det(K)));
 // MODE 1: fp64, log det straight from the factor (no underflow), NaN when a pivot fails.
 template <int D, int MODE>
-__global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const double *__restrict__ Xp, const double *__restrict__ yp, int N,
+__global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__restrict__ Xp, const double *__restrict__ yp, int N,
                                                          int Nf, const double *__restrict__ il2p, int G, double jitter,
                                                          void *__restrict__ out_, double *scratch) {
     extern __shared__ double smem_[];
@@ -267,8 +264,7 @@ __global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const doub
 
             // rows of the panel in blocks of 32 (two row tiles): blocks 0, 1 = the diagonal block, block nblk = y's tile.
             // Wave w takes blocks w, w + 4, ...; the elimination of the diagonal block sits between the two products of
-            // every wave's FIRST block.  All four waves pass through every iteration, with or without a block: they meet at
-            // a barrier every SYNC steps of the first product (see there).
+            // every wave's FIRST block (all four waves pass through every iteration, with or without a block).
             const int nblk = (Nf - J0) >> 5;
             const int jt0 = J0 >> 4;
             const int nkp = J0 >> 3;
@@ -282,9 +278,7 @@ __global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const doub
                 d4_t acc[4][2];
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) { acc[ct][0] = d4_t{0.0, 0.0, 0.0, 0.0}; acc[ct][1] = d4_t{0.0, 0.0, 0.0, 0.0}; }
-                {
-                    // ---- C' = K^T - L_j L_b^T: operands straight from memory, the next k-group pair in flight ----
-                    if (nkp > 0 && !(SKIP & 8)) {
+                if (nkp > 0 && !(SKIP & 8)) {
                         const d2_t *pa = Lf + ((int64_t)jt0 * KP) * 64 + lane;    // + ct * KP * 64
                         const d2_t *pb0 = Lf + ((int64_t)rt0 * KP) * 64 + lane;
                         const d2_t *pb1 = Lf + ((int64_t)rt1 * KP) * 64 + lane;
@@ -306,13 +300,15 @@ __global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const doub
                             acc[2][0] = mfma_f64_16x16x4(F.f2.y, F.g0.y, acc[2][0]); acc[2][1] = mfma_f64_16x16x4(F.f2.y, F.g1.y, acc[2][1]);
                             acc[3][0] = mfma_f64_16x16x4(F.f3.y, F.g0.y, acc[3][0]); acc[3][1] = mfma_f64_16x16x4(F.f3.y, F.g1.y, acc[3][1]);
                         };
-                        // The four waves read the SAME panel rows (pa) beside their own: kept within SYNC steps of each other
-                        // (a bare barrier - no memory is exchanged through it), the second to fourth reader find those lines
-                        // in L2 / L1 instead of fetching them again; left to drift, every wave fetched them from HBM and the
-                        // first product ran at the memory system's rate (102 GB per 2,500 cells at N = 1024: 4.8x the factor).
+                        // (Every wave fetches the panel rows - pa, the operand the four share - for itself: 104 GB per 2,500 cells
+                        //  at N = 1024, d = 8 = 1.5x what the 64-column algorithm itself must move.  Sharing them was built three
+                        //  ways and measured slower each time, same box: slabs staged through LDS with one barrier per 64
+                        //  products 23.5 against 22.7 ms, three 8-KB stages three slabs ahead with one barrier per 32 products
+                        //  25.6 against 22.6, a bare barrier every 16 / 32 / 64 / 128 products so that the second to fourth
+                        //  reader hit L2 23.3 / 23.1 / 23.0 / 22.9 against 22.7: a wave's pace depends on what the OTHER
+                        //  workgroup's wave on its SIMD is doing, and every meeting point makes the four wait for the slowest.)
                         if (has) load(A, 0);
                         for (int kp = 0; kp < nkp; kp += 2) {
-                            if (SYNC > 0 && (kp & (2 * SYNC - 1)) == 0) __builtin_amdgcn_s_barrier();
                             if (has) {
                                 load(B, kp + 1);
                                 __builtin_amdgcn_sched_barrier(0);
@@ -324,7 +320,6 @@ __global__ __launch_bounds__(TH, GPBO_ARD_OCC) void nlml_fused_kernel(const doub
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
-                    }
                 }
                 if (has) {
                     ARD_STAMP(3);

@@ -234,28 +234,6 @@ static int potrf_run(double *Kp, int64_t Np, double *dinv, int32_t *info, bool i
     return GPBO_OK;
 }
 
-// Batched right-looking Cholesky of `batch` matrices [Ne x Ne] (row stride Ne, matrix stride Ne*Ne), the first `nbf`
-// block columns only: what is left in rows >= 64 nbf is the Schur complement (the ARD grid borders K with y there).
-// dinv: [batch][nbf][64 x 64]; info: [batch] int32, cleared by the caller.
-int gpbo_potrf_batched(double *Ab, int64_t Ne, int nbf, int batch, double *dinv, int32_t *info, hipStream_t st) {
-    if (!Ab || !dinv || !info || Ne % NB || nbf < 1 || (int64_t)nbf * NB > Ne || batch < 1) return GPBO_ERR_ARG;
-    const int64_t sK = Ne * Ne, sD = (int64_t)nbf * NB * NB;
-    for (int j = 0; j < nbf; ++j) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3((unsigned)batch), dim3(256), 0, st, Ab, Ne, j, dinv, info, sK, sD);
-        GPBO_CHECK_LAUNCH();
-        const int64_t rest = Ne - (int64_t)(j + 1) * NB;
-        if (rest <= 0) break;
-        double *panel = Ab + (int64_t)(j + 1) * NB * Ne + (int64_t)j * NB;
-        int rc = gpbo_gemm_launch(1, rest, NB, NB, 1.0, panel, Ne, sK, dinv + (int64_t)j * NB * NB, NB, sD, 0.0, panel, Ne, sK,
-                                  batch, 0, st);
-        if (rc != GPBO_OK) return rc;
-        double *trail = Ab + (int64_t)(j + 1) * NB * Ne + (int64_t)(j + 1) * NB;
-        rc = gpbo_gemm_launch(1, rest, rest, NB, -1.0, panel, Ne, sK, panel, Ne, sK, 1.0, trail, Ne, sK, batch, 1, st);
-        if (rc != GPBO_OK) return rc;
-    }
-    return GPBO_OK;
-}
-
 extern "C" int gpbo_potrf_f64(double *Kp, int64_t Np, double *dinv, int32_t *info, void *stream) {
     return potrf_run(Kp, Np, dinv, info, false, stream);
 }

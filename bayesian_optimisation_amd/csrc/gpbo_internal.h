@@ -102,7 +102,6 @@ int gpbo_posterior_acq_f64_split(const double *Xs, int64_t M, const double *X, i
                                  void *work, int64_t work_bytes, gpbo_profile *prof, int split_max, int64_t n_prefix,
                                  void *stream);
 #define GPBO_RESCORE_SPLIT_MAX 64
-int gpbo_potrf_batched(double *Ab, int64_t Ne, int nbf, int batch, double *dinv, int32_t *info, hipStream_t st);
 int gpbo_gemm_launch_tri(int transB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
                          int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double beta, double *C,
                          int64_t ldc, int64_t strideC, int batch, int lower_only, int tri, hipStream_t st);

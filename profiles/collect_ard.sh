@@ -17,4 +17,4 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES
   echo "pmc $name rc=$?"
 done
 fi
-cd $REPO && python3 profiles/summarise_ard.py $OUT $N | tee $OUT/summary.txt
+cd $REPO && python3 profiles/summarise_ard.py $OUT $N "" $D | tee $OUT/summary.txt
