@@ -67,13 +67,20 @@ __device__ __forceinline__ double acquisition(int kind, double mu, double sigma,
     return gpbo_acquisition(kind, mu, sigma, p0, p1);
 }
 
-template <int VARIANT>  // 0 = product; 1, 2 = timing-only diagnostics (GPBO_SIGMA_VARIANT), wrong results
+// GRAM (config 5, q = 8 Monte-Carlo qEI): the tiles of V are computed TRANSPOSED (the two operands of every product swapped:
+// register r of lane l then holds V[candidate l & 15][column (l >> 4) + 4r] of its tile), which makes one accumulator
+// register at once the A operand (row = candidate, k = column) and the B operand (k = column, column = candidate) of
+// v_mfma_f64_16x16x4_f64: four products per finished tile add V V^T of its 16 candidates - the joint posterior's Gram
+// blocks of two 8-candidate batches - to 8 more accumulators, and V itself never leaves the registers (round 4 wrote the
+// 2.1 GB of V per launch for qei_kernel to read back).  `vbuf` then receives the partial Gram blocks:
+// [S * WQ partials][ldk / 8 batches][8 x 8].
+template <int VARIANT, bool GRAM = false>  // VARIANT 0 = product; 1, 2 = timing-only diagnostics (GPBO_SIGMA_VARIANT), wrong results
 __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
     const double *__restrict__ KsT, int64_t ldk, const double *__restrict__ U, int Np,
     const double *__restrict__ mu_part, int nsl, int64_t Mc, double prior_var, int acq_kind, double p0, double p1,
     int64_t idx_base, double *__restrict__ mu_out, double *__restrict__ sigma_out, double *__restrict__ acq_out,
     double *__restrict__ part_val, int64_t *__restrict__ part_idx, unsigned long long *__restrict__ nan_count,
-    double *__restrict__ vbuf /* optional [chunk x Np]: V = K* U itself, for the joint (qEI) posterior */,
+    double *__restrict__ vbuf /* GRAM: the partial Gram blocks of the 8-candidate batches (see above); else unused */,
     double *__restrict__ ss_part /* column-split launches (gridDim.y = S > 1): [S x ldk] partial |v|^2, no epilogue */,
     int xg /* > 1: one-dimensional launch, the xg column groups of a candidate tile 8 linear ids apart (same XCD) */,
     int ntile, int ncb /* > 0: only the first ncb column blocks of V (the prefix-bound screen: |v|^2 over the first
@@ -127,6 +134,9 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
         ldsB[r] = A_TILE + row * LDB + piece * 128;
     }
     d4_t acc[MI][NI];
+    d4_t gram[GRAM ? MI : 1];
+#pragma unroll
+    for (int i = 0; i < (GRAM ? MI : 1); ++i) gram[i] = d4_t{0.0, 0.0, 0.0, 0.0};
     double ss[MI][4];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -206,7 +216,8 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
             for (int ni = nlo; ni < nlo + NI / 2; ++ni) {
                 if (FULL || ni >= ni_min) {
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma_f64_16x16x4(af[mi], bf[ni], acc[mi][ni]);
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[mi][ni] = GRAM ? mfma_f64_16x16x4(bf[ni], af[mi], acc[mi][ni]) : mfma_f64_16x16x4(af[mi], bf[ni], acc[mi][ni]);
                 }
             }
         };
@@ -248,16 +259,17 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
         const int heavy = jb * (BN / BK);
         for (int kt = 0; kt < heavy; ++kt) tile_body(std::true_type{}, jb, kt);
         for (int kt = heavy; kt < heavy + BN / BK; ++kt) tile_body(std::false_type{}, jb, kt);
-        // column block finished: fold |V|^2 into the row sums
-        if (vbuf && VARIANT != 6) {  // (wave-uniform) keep the block of V: row = candidate, 16 consecutive columns per lane group
+        // column block finished: fold |V|^2 into the row sums (GRAM: V V^T of each tile's 16 candidates into the Gram blocks)
+        if (GRAM) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
+                for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        vbuf[(cand0 + wr * (BM / WR) + mi * 16 + l4 + 4 * r) * (int64_t)Np + jb * BN + (WQ * ni + wq) * 16 + l15] =
-                            acc[mi][ni][r];
+                    for (int r = 0; r < 4; ++r) gram[mi] = mfma_f64_16x16x4(acc[mi][ni][r], acc[mi][ni][r], gram[mi]);
+                    acc[mi][ni] = d4_t{0.0, 0.0, 0.0, 0.0};
+                }
+            continue;
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -267,6 +279,23 @@ __global__ __launch_bounds__(NW * 64) void sigma_acq_kernel(
                 for (int r = 0; r < 4; ++r) ss[mi][r] = fma(acc[mi][ni][r], acc[mi][ni][r], ss[mi][r]);
                 acc[mi][ni] = d4_t{0.0, 0.0, 0.0, 0.0};
             }
+    }
+    if (GRAM) {
+        // this wave's partial Gram of its 64 candidates over its columns: register r of lane l of tile mi is
+        // G[(l >> 4) + 4r][l & 15]; the two diagonal 8 x 8 blocks are the batches 2 t and 2 t + 1 of 16-candidate tile t
+        const int p = sp * WQ + wq;
+        const int64_t nb8 = ldk / 8;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int64_t t16 = (cand0 + wr * (BM / WR) + mi * 16) / 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = l4 + 4 * r;
+                const bool lo = (r < 2) && (l15 < 8), hi = (r >= 2) && (l15 >= 8);
+                if (lo) vbuf[((int64_t)p * nb8 + 2 * t16) * 64 + i * 8 + l15] = gram[mi][r];
+                if (hi) vbuf[((int64_t)p * nb8 + 2 * t16 + 1) * 64 + (i - 8) * 8 + (l15 - 8)] = gram[mi][r];
+            }
+        }
     }
 
     // ---- row sums: across the 16 lanes that share a candidate row, then across the two column halves
@@ -552,7 +581,7 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void qei_kernel(const double *__restrict__ V, int Np, const double *__restrict__ mu,
+__global__ __launch_bounds__(256) void qei_kernel(const double *__restrict__ G, int P, int64_t nb8, const double *__restrict__ mu,
                                                   const double *__restrict__ Xs, int d, QeiLs ls, int64_t nbatch,
                                                   double prior_var, double f_best, double xi,
                                                   const double *__restrict__ Z, int S, int64_t batch_base,
@@ -565,22 +594,15 @@ __global__ __launch_bounds__(256) void qei_kernel(const double *__restrict__ V, 
     const int64_t b = (int64_t)blockIdx.x * 4 + wid;
     const bool valid = b < nbatch;
     const int64_t bb = valid ? b : 0;  // idle waves recompute batch 0 (keeps every shuffle full-wave)
-    const double *vrow = V + bb * QQ * (int64_t)Np;
-
+    // V_b V_b^T of the batch: the P partial 8 x 8 blocks the variance launch left (one per column group of its waves and
+    // workgroups), summed in partial order - lane e holds entry (e >> 3, e & 7) - then every lane gathers the lower triangle
+    double gsum = 0.0;
+    for (int q = 0; q < P; ++q) gsum += G[((int64_t)q * nb8 + bb) * 64 + lane];
     double g[QT];
 #pragma unroll
-    for (int t = 0; t < QT; ++t) g[t] = 0.0;
-    for (int col = lane; col < Np; col += 64) {
-        double v[QQ];
+    for (int i = 0; i < QQ; ++i)
 #pragma unroll
-        for (int j = 0; j < QQ; ++j) v[j] = vrow[(int64_t)j * Np + col];
-#pragma unroll
-        for (int i = 0; i < QQ; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) g[i * (i + 1) / 2 + j] = fma(v[i], v[j], g[i * (i + 1) / 2 + j]);
-    }
-#pragma unroll
-    for (int t = 0; t < QT; ++t) g[t] = wave_sum(g[t]);
+        for (int j = 0; j <= i; ++j) g[i * (i + 1) / 2 + j] = __shfl(gsum, i * 8 + j);
 
     // prior covariance of the batch, entry (i, j) by lane t = i(i+1)/2 + j, then gathered by every lane
     double kmine = 0.0;
@@ -674,7 +696,7 @@ QeiLayout qei_layout(int64_t Np, int64_t chunk, int64_t M) {
     L.kst_off = off; off += align_up((int64_t)sizeof(double) * Np * chunk, 256);
     L.mup_off = off; off += align_up((int64_t)sizeof(double) * (Np / GPBO_KS_SLICE) * chunk, 256);
     L.xsc_off = off; off += align_up((int64_t)sizeof(double) * Np * GPBO_MAX_D, 256);
-    L.v_off = off; off += align_up((int64_t)sizeof(double) * Np * chunk, 256);
+    L.v_off = off; off += align_up((int64_t)sizeof(double) * 64 * (chunk / 8) * 16 * WQ, 256);   // Gram blocks: <= 16 x WQ partials
     L.mu_off = off; off += align_up((int64_t)sizeof(double) * chunk, 256);
     L.spv_off = off; off += align_up((int64_t)sizeof(double) * (chunk / BM), 256);
     L.spi_off = off; off += align_up((int64_t)sizeof(int64_t) * (chunk / BM), 256);
@@ -1019,14 +1041,16 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
         if (rc != GPBO_OK) return rc;
         if (rec && !mark(prof->begin[prof->count])) return GPBO_ERR_LAUNCH;
         const int64_t nblk = (Mc + BM - 1) / BM;
-        // the variance kernel also leaves V (vbuf) and mu; its own single-point acquisition result is ignored.
-        // Large calls: column groups on one XCD as in gpbo_posterior_acq_f64 (each group writes its column blocks of V;
-        // the mean then comes from split_finish_kernel).
+        // the variance kernel in its GRAM form leaves the batches' partial V V^T blocks (vbuf) and mu; its own single-point
+        // acquisition result is ignored.  Large calls: column groups on one XCD as in gpbo_posterior_acq_f64 (each group
+        // leaves the Gram partials of its column blocks; the mean then comes from split_finish_kernel).
         static const int xg_env = getenv("GPBO_F64_GROUPS") ? atoi(getenv("GPBO_F64_GROUPS")) : 8;
+        int gram_parts = WQ;   // partial Gram blocks per batch: one per column group of waves and of workgroups
         if (xg_env > 1 && xg_env <= 16 && M >= 32768 && Np / BN >= 2 * xg_env) {
+            gram_parts = xg_env * WQ;
             double *ss_part = reinterpret_cast<double *>(w + L.ssp_off);
             const int64_t grid1 = (nblk + 7) / 8 * 8 * xg_env;
-            hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)grid1), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
+            hipLaunchKernelGGL((sigma_acq_kernel<0, true>), dim3((unsigned)grid1), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0,
                                (double *)nullptr, (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb, ss_part,
                                xg_env, (int)nblk, 0);
@@ -1034,7 +1058,7 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
                                (double *)nullptr, (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, 0.0);
         } else {
-            hipLaunchKernelGGL(sigma_acq_kernel<0>, dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
+            hipLaunchKernelGGL((sigma_acq_kernel<0, true>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, KsT, chunk, U, (int)Np, mu_part,
                                (int)(Np / GPBO_KS_SLICE), Mc, prior_var, (int)GPBO_ACQ_LCB, 0.0, 0.0, (int64_t)0, mu,
                                (double *)nullptr, (double *)nullptr, spv, spi, nan_scratch, Vb, (double *)nullptr, 1,
                                (int)nblk, 0);
@@ -1043,7 +1067,7 @@ extern "C" int gpbo_posterior_qei_f64(const double *Xs, int64_t M, const double 
         if (rec && !mark(prof->end[prof->count])) return GPBO_ERR_LAUNCH;
         const int64_t nbatch = Mc / QQ;
         const int64_t qblk = (nbatch + 3) / 4;
-        hipLaunchKernelGGL(qei_kernel, dim3((unsigned)qblk), dim3(256), 0, st, Vb, (int)Np, mu, Xs + s * d, (int)d, ls, nbatch,
+        hipLaunchKernelGGL(qei_kernel, dim3((unsigned)qblk), dim3(256), 0, st, Vb, gram_parts, chunk / 8, mu, Xs + s * d, (int)d, ls, nbatch,
                            prior_var, f_best, xi, Z, (int)S, batch_offset + s / QQ, qei_out ? qei_out + s / QQ : nullptr,
                            part_val + nparts, part_idx + nparts, nan_count);
         GPBO_CHECK_LAUNCH();

@@ -264,21 +264,22 @@ def kernel_rooflines(gp, N, d, dtype, qei=False, event_stride=1):
                          "streaming its stores: two nearly saturated resources that do not overlap perfectly")
     qei_roofline = None
     if qei:
-        # the qEI stage (qei_kernel: Gram of the 8 rows of V of a batch, 8 x 8 Cholesky, S samples): an HBM READ of V,
-        # 8 N bytes per candidate (the variance launch of this mode WRITES V: the same bytes, inside its own interval)
+        # the qEI stage (qei_kernel: the batch's 8 x 8 Gram block summed from the partials the variance launch left - round 5:
+        # V itself no longer leaves the variance kernel's registers - then the 8 x 8 Cholesky and S samples).  What it reads:
+        # 64 doubles per partial and batch, 2 partials per batch (16 when the variance launch runs in 8 column groups)
         q_ms, q_launches, q_cands = gp.read_profile_qei()
         if q_launches:
             q_avg = q_ms / q_launches
-            gbs = 8.0 * N * (q_cands / q_launches) / (q_avg * 1e-3) / 1e9
-            eq, stale_q = _pmc_entry(N, d, dtype, q_cands / q_launches)
+            parts = 16 if (q_cands / q_launches >= 32768 and gp.Np >= 2048) else 2
+            bpc = parts * 64.0 * 8.0 / 8.0
+            gbs = bpc * (q_cands / q_launches) / (q_avg * 1e-3) / 1e9
             qei_roofline = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=round(gbs / HBM_PEAK_GBS, 4), kernel="qei_kernel", launches=int(q_launches),
-                                traffic=(eq or {}).get("qei_hbm_bytes_per_launch"), traffic_stale=stale_q,
-                                traffic_source=(f"committed PMC pass {eq['source']} (FETCH_SIZE x2 + WRITE_SIZE), not this run"
-                                                if eq and "qei_hbm_bytes_per_launch" in eq else None),
-                                avg_launch_ms=round(q_avg, 4), bytes_per_candidate=8.0 * N,
-                                note="algorithmic bytes = the rows of V the stage reads (8 N per candidate); 36 N / 8 flop "
-                                     "per candidate + S x 44 / 8 beside them")
+                                avg_launch_ms=round(q_avg, 4), bytes_per_candidate=bpc,
+                                note="round 5: the joint posterior's Gram blocks are formed on the matrix cores inside the "
+                                     "variance launch (sigma_acq_kernel<0, true>); this stage reads 64 x partials doubles per "
+                                     "batch instead of the 8 N bytes per candidate of V it used to (2.15 GB per launch at N = 2048) "
+                                     "and is bound by its own arithmetic (36 + S x 44 flop per batch of 8), not by HBM")
     if kstar_roofline is not None:
         # north_star's second number inside the dict the driver parses: the K(X*,X) build's share of its own roofline(s)
         roofline["kstar"] = dict(kernel=kstar_roofline["kernel"], bound=kstar_roofline["bound"], frac=kstar_roofline["frac"],
