@@ -85,6 +85,26 @@ __device__ __forceinline__ double exp_neg_m(double t, const double *tab) {
     return __hiloint2double(__double2hiint(v) + ((ni >> 8) << 20), __double2loint(v));
 }
 
+// Round 5: the entries that are NOT stored (15/16 of them: they only feed the mean, which is reported from below anyway) take a
+// shorter exponential still: a 1,024-entry table 2^(j/1024) in LDS and ONE term of the series, exp(r) ~ 1 + r with
+// |r| <= ln2 / 2048: relative error r^2 / 2 <= 5.8e-8 (+ 1e-13 from the one-word reduction), carried in the slack as
+// EXP_FAST_REL_ERR S0 (4.7e-3 on the N = 4096 benchmark problem, S0 = 7.8e4: the first level keeps 14,659 instead of 14,206
+// of 2^21 candidates against the best exact value - tools/bound_fp32_probe.py - where an fp32 exponential, 1.5e-7 S0, keeps
+// 14,749 at more instructions: v_cvt_f32_f64 / v_exp_f32 / v_cvt_f64_f32 against the three fused operations saved here).
+// 10 instead of 19 VALU instructions per pair; the stored entries keep exp_neg_m (they feed |v[:J]|^2, whose pad is 1e-8).
+constexpr double EXP_FAST_REL_ERR = 6.0e-8;
+__device__ __forceinline__ double exp_neg_fast(double t, const double *tab1024) {
+    double u;
+    asm("v_min_f64 %0, %1, %2" : "=v"(u) : "v"(t), "v"(708.0));   // (padding rows: t = 1e300; NaN -> 708; t < 0 by a rounding: fine)
+    const double z = fma(-u, 1477.3197218702985, 6755399441055744.0);    // 1024 / ln 2
+    const int ni = __double2loint(z);
+    const double fn = z - 6755399441055744.0;
+    const double r = fma(fn, -6.7690154351557157e-4, -u);                 // ln 2 / 1024
+    const double T = tab1024[ni & 1023];
+    const double v = fma(T, r, T);                 // in [1, 2): scale by 2^(n >> 10) through the exponent field
+    return __hiloint2double(__double2hiint(v) + ((ni >> 10) << 20), __double2loint(v));
+}
+
 // clamp to [0, 708] without the canonicalising v_max the compiler puts in front of fmax / fmin on an MFMA result (a rounding
 // can leave a tiny negative distance; beyond 708 the result is below 1e-307 either way; NaN -> 0: the caller poisons the mean)
 __device__ __forceinline__ double clamp_t(double t) {
@@ -169,9 +189,17 @@ __global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__rest
     constexpr int NC = 4;   // candidate tiles per wave
     const int LDB = KP + 1;   // LDS row stride of the observation rows (odd: the 16 rows of a tile land on different banks)
     __shared__ double tab[256];
+    __shared__ double tabf[1024];                  // 2^(j/1024) = 2^((j >> 2)/256) x 2^((j & 3)/1024): exp_neg_fast
     __shared__ double Bs[OB_MAX * (4 * KQ + 5)];   // KP <= 4 KQ + 4
     __shared__ double As[OB_MAX];   // alpha of the workgroup's observations (0 beyond N: those rows give k = 0 anyway)
     tab[threadIdx.x] = kExp2Tab256[threadIdx.x];   // (256 threads)
+    {
+        const double t0 = kExp2Tab256[threadIdx.x];
+        tabf[4 * threadIdx.x + 0] = t0;
+        tabf[4 * threadIdx.x + 1] = t0 * 1.0006771306930664;    // 2^(1/1024)
+        tabf[4 * threadIdx.x + 2] = t0 * 1.0013547198921082;    // 2^(2/1024)
+        tabf[4 * threadIdx.x + 3] = t0 * 1.002032767907594;    // 2^(3/1024)
+    }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t cbase = (int64_t)blockIdx.x * 256 + wid * 64;
@@ -211,7 +239,7 @@ __global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__rest
         // such a candidate is reported like a NaN one here - its bound is NaN, so it always survives to the fp64 kernels
         bad = bad || !(na < __builtin_inf());
         nac[tc] = na;
-        slack[tc] = gamma * fma(na, prep->S0, prep->S1) + (EXP_REL_ERR + EXP_ABS_ERR + eps_acc) * prep->S0;
+        slack[tc] = gamma * fma(na, prep->S0, prep->S1) + (EXP_FAST_REL_ERR + EXP_REL_ERR + EXP_ABS_ERR + eps_acc) * prep->S0;
         isnan_c[tc] = bad;
     }
     __syncthreads();
@@ -242,7 +270,7 @@ __global__ __launch_bounds__(256) void kstar_mu_mfma_kernel(const double *__rest
             for (int q = 0; q < KQ; ++q) acc = mfma_f64_16x16x4(aop[q], bop[tc][q], acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double k = exp_neg_m(clamp_t(acc[r]), tab);
+                const double k = STORE ? exp_neg_m(clamp_t(acc[r]), tab) : exp_neg_fast(acc[r], tabf);
                 mu[tc] = fma(k, al[r], mu[tc]);
                 if (STORE) KsT[(int64_t)(r0 + l4 + 4 * r) * ldk + cbase + 16 * tc + l15] = k;
             }

@@ -226,13 +226,13 @@ def kernel_rooflines(gp, N, d, dtype, qei=False, event_stride=1):
         ks_avg = ks_ms / ks_launches
         bytes_per_cand = {"f32": 4.0, "i8": 5.0, "i8c": 3.0}.get(dtype, 8.0) * N + 8.0 * d
         if bnd:
-            # The prefix-bound route's K(X*,X) interval = kstar_mu_mfma_kernel (the mean of all N observations: 19 fp64
+            # The prefix-bound route's K(X*,X) interval = kstar_mu_mfma_kernel (the mean of all N observations: 10 fp64
             # VALU instructions per (candidate, observation) pair beside 2 fp64 MFMAs per 256 pairs) +
             # kstar_mu_kernel on the J stored rows (41 per pair).  It writes J rows, not N: the bound is the vector
             # fp64 issue rate (33 T lane-instructions/s measured by tools/valu_f64_peak.hip), not HBM.  The MFMAs do not
-            # run beside fp64 VALU on gfx950 (32 of the ~108 cycles per pair and lane), so frac cannot reach 1.
+            # run beside fp64 VALU on gfx950 (32 of the ~72 cycles per pair and lane), so frac cannot reach 1.
             Jp = float((gp.last_screen or {}).get("prefix", N))
-            lane_instr_per_cand = 19.0 * N + 41.0 * Jp
+            lane_instr_per_cand = 10.0 * N + 41.0 * Jp   # (round 5: 10 per pair with the one-term exponential, 19 before)
             tli = lane_instr_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e12
             kstar_roofline = dict(bound="valu", achieved=round(tli, 2), peak=VALU_F64_PEAK_TLANE,
                                   unit="T lane-instructions/s (fp64 VALU)", frac=round(tli / VALU_F64_PEAK_TLANE, 4),
@@ -240,7 +240,7 @@ def kernel_rooflines(gp, N, d, dtype, qei=False, event_stride=1):
                                   launches=int(ks_launches), avg_launch_ms=round(ks_avg, 4),
                                   lane_instructions_per_candidate=lane_instr_per_cand,
                                   note="static instruction counts per pair (ISA of the two kernels); the 2 fp64 MFMAs per 256 "
-                                       "pairs of the first kernel occupy the SIMD for 32 of ~108 cycles per pair and lane and "
+                                       "pairs of the first kernel occupy the SIMD for 32 of ~72 cycles per pair and lane and "
                                        "do not overlap with fp64 VALU on gfx950")
         else:
             gbs = bytes_per_cand * (ks_cands / ks_launches) / (ks_avg * 1e-3) / 1e9

@@ -75,8 +75,10 @@ def test_bound_is_an_upper_bound_of_the_fp64_acquisition_for_every_candidate():
         assert st == 0
         m, s, a = (t.cpu().numpy() for t in o)
         # the first pass takes the pair distances from the matrix cores (kstar_mfma.hip) and reports the mean from BELOW by
-        # its error bound (~1e-9 here): never above the plain pass's mean, never far below
-        assert np.all(m <= mu) and np.max(mu - m) <= 1e-7
+        # its error bound: never above the plain pass's mean, never further below than that bound - round 5: the entries
+        # come from a one-term exponential (relative error <= 6e-8), so the bound is ~6e-8 sum|alpha| (7e-4 here)
+        S0 = float(gp.alpha[: gp.N].abs().sum())
+        assert np.all(m <= mu) and np.max(mu - m) <= 1.3e-7 * S0 + 1e-7
         assert np.all(s >= sig) and np.all(a >= acq)   # (the bound's variance is clamped at 0 and padded by 1e-8)
         if prev is not None:
             assert np.all(s <= prev + 1e-13)   # more observations, tighter bound
@@ -118,7 +120,8 @@ def test_first_pass_kernel_for_every_operand_length(d):
     ok = np.ones(M, bool)
     ok[17] = False
     assert np.isnan(m[17]) and np.isnan(mu[17])
-    assert np.all(m[ok] <= mu[ok]) and np.max(mu[ok] - m[ok]) <= 1e-7 * max(1.0, np.abs(y).max())
+    S0 = float(gp.alpha[: gp.N].abs().sum())
+    assert np.all(m[ok] <= mu[ok]) and np.max(mu[ok] - m[ok]) <= 1.3e-7 * S0 + 1e-7 * max(1.0, np.abs(y).max())
     assert np.all(s[ok] >= sig[ok]) and np.max(s[ok] ** 2 - sig[ok] ** 2) <= 2e-8
 
 
