@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void nlml_grid_kernel(const double *__restrict
 
     for (int e = tid; e < N * d; e += 256) xs[e] = X[e];
     if (tid < d) il2[tid] = 1.0 / (ls[tid] * ls[tid]);
-    __syncthreads();
+    gpbo_syncthreads();
     const int n1 = N + 1;
     for (int e = tid; e < n1 * n1; e += 256) {
         const int r = e / n1, q = e - r * n1;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void nlml_grid_kernel(const double *__restrict
         a[tri(r, q)] = v;
     }
     for (int c = 0; c < N; ++c) {
-        __syncthreads();
+        gpbo_syncthreads();
         const double piv = a[tri(c, c)];
         const double dd = sqrt(piv);   // NaN for a negative pivot: propagates to the cell's value
         const double inv = 1.0 / dd;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void nlml_grid_kernel(const double *__restrict
             }
         }
     }
-    __syncthreads();
+    gpbo_syncthreads();
     if (tid == 0) {
         double logdet = 0.0;
         for (int c = 0; c < N; ++c) logdet += log(diag[c]);
@@ -104,10 +104,10 @@ __global__ __launch_bounds__(256) void nlml_cell_kernel(const double *__restrict
     }
     s_ld[tid] = ld;
     s_q[tid] = q;
-    __syncthreads();
+    gpbo_syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if (tid < off) { s_ld[tid] += s_ld[tid + off]; s_q[tid] += s_q[tid + off]; }
-        __syncthreads();
+        gpbo_syncthreads();
     }
     if (tid == 0) {
         const double logdet = 2.0 * s_ld[0];
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
     if (tid0 < GPBO_EXP_E) S.tab[tid0] = kExp2Tab256[tid0 * (256 / GPBO_EXP_E)];
 
     for (int g = blockIdx.x; g < G; g += gridDim.x) {
-        __syncthreads();   // the previous cell's reductions have been read
+        gpbo_syncthreads();   // the previous cell's reductions have been read
         double il2[D];     // wave-uniform (scalar loads)
 #pragma unroll
         for (int k = 0; k < D; ++k) il2[k] = il2p[(int64_t)g * D + k];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
             if (tid < 64) S.yc[tid] = yp[J0 + tid];
             ARD_STAMP(1);
             for (int e = tid; e < 64 * 64; e += TH) S.M[(64 + (e >> 6)) * LDM + (e & 63)] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
-            __syncthreads();
+            gpbo_syncthreads();
             ARD_STAMP(2);
 
             // rows of the panel in blocks of 32 (two row tiles): blocks 0, 1 = the diagonal block, block nblk = y's tile.
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
                                     S.M[lrow * LDM + jc] = (jc <= lrow) ? acc[ct][t][r] : 0.0;
                                 }
                     }
-                    __syncthreads();
+                    gpbo_syncthreads();
                     ARD_STAMP(5);
                     const int fbad = (SKIP & 1) ? 0 : potrf_panel_call();
                     ARD_STAMP(6);
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
                 }
             }
             ARD_STAMP(8);
-            __syncthreads();   // the panel's fragments are visible to every wave; M and Xc are free
+            gpbo_syncthreads();   // the panel's fragments are visible to every wave; M and Xc are free
             ARD_STAMP(9);
         }
 
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
             quad_t += __shfl_xor(quad_t, off);
         }
         if ((tid0 & 63) == 0) { S.red[w] = logdet_t; S.red[WAVES + w] = quad_t; }
-        __syncthreads();
+        gpbo_syncthreads();
         if (tid0 == 0) {
             double quad = 0.0;
             for (int k = 0; k < WAVES; ++k) quad += S.red[WAVES + k];

@@ -27,6 +27,17 @@ __device__ __forceinline__ d4_t mfma_f64_16x16x4(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// __syncthreads() with the wave's own outstanding LDS and memory operations waited for EXPLICITLY.  hipcc (ROCm 7.2, gfx950)
+// was seen to emit the s_barrier of a __syncthreads() at a LOOP HEADER without the s_waitcnt lgkmcnt(0) in front of it
+// (nlml_grid_kernel's elimination loop: the last ds_write of step c still in flight when another wave, released by the
+// barrier, read that entry in step c + 1): 2 % of the cells of a 2,600-cell launch at d = 16 came out wrong, differently
+// every run, found by tools/fuzz_ard.py in round 5.  The wait is two scalar instructions; use this wherever a barrier
+// publishes LDS (or memory) writes of the loop body before it.
+__device__ __forceinline__ void gpbo_syncthreads() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // (value, index) order of every arg-max reduction: larger value first, ties to the LOWER index (point_selector.py:207)
 __device__ __forceinline__ bool gpbo_better(double v2, int64_t i2, double v, int64_t i) {
     return (v2 > v) || (v2 == v && i2 < i);

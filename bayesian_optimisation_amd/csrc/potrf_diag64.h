@@ -102,7 +102,7 @@ __device__ __forceinline__ int potrf_diag64_lds(double *M, int tid) {
 
     constexpr int NS = NB / PB;  // 4
     if (w == 0) eliminate(0);
-    __syncthreads();
+    gpbo_syncthreads();
     for (int s = 0; s < NS; ++s) {
         // (2) the non-zero panel blocks: A row blocks s+1..3 and identity-part row blocks 0..s-1 - always three
         if (w < NS - 1) {
@@ -110,7 +110,7 @@ __device__ __forceinline__ int potrf_diag64_lds(double *M, int tid) {
             const int nA = NS - 1 - s;
             panel(t < nA ? PB * (s + 1 + t) : NB + PB * (t - nA), s);
         }
-        __syncthreads();
+        gpbo_syncthreads();
         if (s == NS - 1) break;
         // (3) trailing blocks; wave 0: the next diagonal sub-block, then its elimination
         if (w == 0) {
@@ -130,7 +130,7 @@ __device__ __forceinline__ int potrf_diag64_lds(double *M, int tid) {
                 }
             }
         }
-        __syncthreads();
+        gpbo_syncthreads();
     }
     return first_bad;
 }

@@ -374,3 +374,28 @@ def test_nlml_logdet_host_entry_point_equals_the_device_one(env):
     assert b.dtype == np.float64 and np.array_equal(a, b)
     with pytest.raises(ValueError):
         H.nlml_grid(X, y, cells, likelihood="det")
+
+
+@pytest.mark.parametrize("N,d", [(63, 16), (32, 16), (64, 9), (150, 16)])
+def test_nlml_grid_is_deterministic_when_the_chip_is_full(env, N, d):
+    """2,600 cells that are 200 copies of 13: every copy must give the bits of the first, in both kernels and both modes, run
+    after run.  Round 5's randomised sweep (tools/fuzz_ard.py) found the in-LDS kernel returning a different value for ~2 %
+    of such cells at d = 16 - hipcc had emitted the barrier at the head of its elimination loop without waiting for the wave's
+    own LDS writes (gpbo_syncthreads in gpbo_internal.h); a few cells alone never showed it."""
+    from bayesian_optimisation_amd import DeviceGP
+
+    rng = np.random.default_rng(N + d)
+    X = 0.5 + 0.02 * rng.standard_normal((N, d))
+    y = 0.1 * rng.standard_normal(N)
+    base = np.exp(rng.uniform(np.log(0.02), np.log(20.0), size=(13, d)))
+    cells = np.tile(base, (200, 1))
+    gp = DeviceGP()
+    want = O.nlml_cells_logdet(X, y, base)
+    for rep in range(3):
+        for mode in ("reference", "logdet"):
+            out = gp.nlml_grid(X, y, cells, likelihood=mode).reshape(200, 13)
+            assert np.array_equal(out, np.tile(out[0], (200, 1)), equal_nan=True), (rep, mode, int((out != out[0]).sum()))
+        np.testing.assert_allclose(out[0], want, rtol=1e-9, atol=1e-9 * N)   # (the three terms cancel: values near 0 occur)
+        if N <= 176:
+            a = _nlml_direct(gp, X, y, cells, batched=False).reshape(200, 13)
+            assert np.array_equal(a, np.tile(a[0], (200, 1)), equal_nan=True), (rep, "in-LDS", int((a != a[0]).sum()))
