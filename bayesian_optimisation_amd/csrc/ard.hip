@@ -164,6 +164,10 @@ __device__ int g_nstamps[4];
 #define ARD_STAMP(TAG) do { } while (0)
 #endif
 
+#ifndef GPBO_ARD_RT4_FROM
+#define GPBO_ARD_RT4_FROM 1280
+#endif
+constexpr int RT4_FROM = GPBO_ARD_RT4_FROM;   // padded sizes from here on: 64 x 64 wave tiles (see the kernel)
 constexpr int OCC = 2;                  // workgroups (= waves per SIMD) per CU: LDS (the elimination's image) allows two
 constexpr int TH = 256;                 // 4 waves, one per SIMD; several workgroups per CU fill each other's serial phases
 constexpr int WAVES = TH / 64;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256) void nlml_prep_kernel(const double *__restrict
 
 // MODE 0: the reference's likelihood, float32, log(exp(logdet)) (point_selector.py:117-119: np.log(np.linalg.det(K)));
 // MODE 1: fp64, log det straight from the factor (no underflow), NaN when a pivot fails.
-template <int D, int MODE>
+template <int D, int MODE, int RT /* row tiles per block of a wave: 2 or 4 */>
 __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__restrict__ Xp, const double *__restrict__ yp, int N,
                                                          int Nf, const double *__restrict__ il2p, int G, double jitter,
                                                          void *__restrict__ out_, double *scratch) {
@@ -262,10 +266,16 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
             gpbo_syncthreads();
             ARD_STAMP(2);
 
-            // rows of the panel in blocks of 32 (two row tiles): blocks 0, 1 = the diagonal block, block nblk = y's tile.
-            // Wave w takes blocks w, w + 4, ...; the elimination of the diagonal block sits between the two products of
-            // every wave's FIRST block (all four waves pass through every iteration, with or without a block).
-            const int nblk = (Nf - J0) >> 5;
+            // rows of the panel in blocks of RT row tiles (32 or 64 rows): the first 64 / (16 RT) blocks = the diagonal block,
+            // block nblk = y's tile.  Wave w takes blocks w, w + 4, ...; the elimination of the diagonal block sits between the
+            // two products of every wave's FIRST block (all four waves pass through every iteration, with or without a block).
+            // RT = 4 (Nf >= 1280): a 64 x 64 wave tile fetches (64 + 64) 8 bytes per 8,192 flop where the 32 x 64 one fetches
+            // (32 + 64) 8 per 4,096 - a third less traffic for the product that runs at the memory system's rate - at the
+            // price of half as many blocks to share out among the four waves and of ~100 spilled registers.  Measured, same
+            // box, 2,500 cells, d = 2, ms with RT = 2 / RT = 4: N = 512: 4.01 / 4.62; 768: 11.3 / 12.0; 1024: 24.8 / 24.9 (d = 8:
+            // 26.2 / 27.2); 1536: 78.5 / 75.3; 2048: 180.7 / 167.7 - it pays from about 1,300 observations on.
+            constexpr int DB = 4 / RT;                    // blocks of the diagonal block
+            const int nblk = (Nf - J0) / (16 * RT);
             const int jt0 = J0 >> 4;
             const int nkp = J0 >> 3;
             const int nit = (nblk + WAVES) / WAVES;     // ceil((nblk + 1) / WAVES)
@@ -273,59 +283,72 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
                 const int b = w + WAVES * it;
                 const bool has = (b <= nblk);
                 const bool yblk = (b == nblk);
-                const int rt0 = jt0 + 2 * (has ? b : 0);
-                const int rt1 = (yblk || !has) ? rt0 : rt0 + 1;       // y's block has one tile (computed twice, stored once)
-                d4_t acc[4][2];
+                const int rt0 = jt0 + RT * (has ? b : 0);
+                int rtt[RT];                                // the block's row tiles (y's block: its one tile RT times, stored once)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) { acc[ct][0] = d4_t{0.0, 0.0, 0.0, 0.0}; acc[ct][1] = d4_t{0.0, 0.0, 0.0, 0.0}; }
+                for (int t = 0; t < RT; ++t) rtt[t] = (yblk || !has) ? rt0 : rt0 + t;
+                d4_t acc[4][RT];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) acc[ct][t] = d4_t{0.0, 0.0, 0.0, 0.0};
                 if (nkp > 0 && !(SKIP & 8)) {
-                        const d2_t *pa = Lf + ((int64_t)jt0 * KP) * 64 + lane;    // + ct * KP * 64
-                        const d2_t *pb0 = Lf + ((int64_t)rt0 * KP) * 64 + lane;
-                        const d2_t *pb1 = Lf + ((int64_t)rt1 * KP) * 64 + lane;
-                        const int64_t sa = (int64_t)KP * 64;
-                        // two register sets in turn (nkp is a multiple of 8): the loads of one pair are in flight while the
-                        // sixteen products of the other issue; the scheduling barriers keep that order
-                        struct Frag { d2_t f0, f1, f2, f3, g0, g1; } A, B;
-                        auto load = [&](Frag &F, int k) {
-                            F.f0 = pa[k * 64]; F.f1 = pa[sa + k * 64]; F.f2 = pa[2 * sa + k * 64]; F.f3 = pa[3 * sa + k * 64];
-                            F.g0 = pb0[k * 64]; F.g1 = pb1[k * 64];
-                        };
-                        auto mult = [&](const Frag &F) {
-                            acc[0][0] = mfma_f64_16x16x4(F.f0.x, F.g0.x, acc[0][0]); acc[0][1] = mfma_f64_16x16x4(F.f0.x, F.g1.x, acc[0][1]);
-                            acc[1][0] = mfma_f64_16x16x4(F.f1.x, F.g0.x, acc[1][0]); acc[1][1] = mfma_f64_16x16x4(F.f1.x, F.g1.x, acc[1][1]);
-                            acc[2][0] = mfma_f64_16x16x4(F.f2.x, F.g0.x, acc[2][0]); acc[2][1] = mfma_f64_16x16x4(F.f2.x, F.g1.x, acc[2][1]);
-                            acc[3][0] = mfma_f64_16x16x4(F.f3.x, F.g0.x, acc[3][0]); acc[3][1] = mfma_f64_16x16x4(F.f3.x, F.g1.x, acc[3][1]);
-                            acc[0][0] = mfma_f64_16x16x4(F.f0.y, F.g0.y, acc[0][0]); acc[0][1] = mfma_f64_16x16x4(F.f0.y, F.g1.y, acc[0][1]);
-                            acc[1][0] = mfma_f64_16x16x4(F.f1.y, F.g0.y, acc[1][0]); acc[1][1] = mfma_f64_16x16x4(F.f1.y, F.g1.y, acc[1][1]);
-                            acc[2][0] = mfma_f64_16x16x4(F.f2.y, F.g0.y, acc[2][0]); acc[2][1] = mfma_f64_16x16x4(F.f2.y, F.g1.y, acc[2][1]);
-                            acc[3][0] = mfma_f64_16x16x4(F.f3.y, F.g0.y, acc[3][0]); acc[3][1] = mfma_f64_16x16x4(F.f3.y, F.g1.y, acc[3][1]);
-                        };
-                        // (Every wave fetches the panel rows - pa, the operand the four share - for itself: 104 GB per 2,500 cells
-                        //  at N = 1024, d = 8 = 1.5x what the 64-column algorithm itself must move.  Sharing them was built three
-                        //  ways and measured slower each time, same box: slabs staged through LDS with one barrier per 64
-                        //  products 23.5 against 22.7 ms, three 8-KB stages three slabs ahead with one barrier per 32 products
-                        //  25.6 against 22.6, a bare barrier every 16 / 32 / 64 / 128 products so that the second to fourth
-                        //  reader hit L2 23.3 / 23.1 / 23.0 / 22.9 against 22.7: a wave's pace depends on what the OTHER
-                        //  workgroup's wave on its SIMD is doing, and every meeting point makes the four wait for the slowest.)
-                        if (has) load(A, 0);
-                        for (int kp = 0; kp < nkp; kp += 2) {
-                            if (has) {
-                                load(B, kp + 1);
-                                __builtin_amdgcn_sched_barrier(0);
-                                mult(A);
-                                __builtin_amdgcn_sched_barrier(0);
-                                load(A, (kp + 2 < nkp) ? kp + 2 : kp + 1);   // (the last step re-loads a pair it has)
-                                __builtin_amdgcn_sched_barrier(0);
-                                mult(B);
-                                __builtin_amdgcn_sched_barrier(0);
+                    // ---- C' = K^T - L_j L_b^T: operands straight from memory, the next k-group pair in flight ----
+                    const d2_t *pa = Lf + ((int64_t)jt0 * KP) * 64 + lane;    // + ct * KP * 64
+                    const d2_t *pb[RT];
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) pb[t] = Lf + ((int64_t)rtt[t] * KP) * 64 + lane;
+                    const int64_t sa = (int64_t)KP * 64;
+                    // two register sets in turn (nkp is a multiple of 8): the loads of one pair are in flight while the
+                    // products of the other issue; the scheduling barriers keep that order
+                    struct Frag { d2_t f[4], g[RT]; } A, B;
+                    auto load = [&](Frag &F, int k) {
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) F.f[ct] = pa[ct * sa + k * 64];
+#pragma unroll
+                        for (int t = 0; t < RT; ++t)
+                            if (t == 0 || !yblk) F.g[t] = pb[t][k * 64];
+                    };
+                    auto mult = [&](const Frag &F) {
+#pragma unroll
+                        for (int t = 0; t < RT; ++t)
+                            if (t == 0 || !yblk) {
+#pragma unroll
+                                for (int ct = 0; ct < 4; ++ct) acc[ct][t] = mfma_f64_16x16x4(F.f[ct].x, F.g[t].x, acc[ct][t]);
                             }
+#pragma unroll
+                        for (int t = 0; t < RT; ++t)
+                            if (t == 0 || !yblk) {
+#pragma unroll
+                                for (int ct = 0; ct < 4; ++ct) acc[ct][t] = mfma_f64_16x16x4(F.f[ct].y, F.g[t].y, acc[ct][t]);
+                            }
+                    };
+                    // (Every wave fetches the panel rows - pa, the operand the four share - for itself: 104 GB per 2,500 cells
+                    //  at N = 1024, d = 8 with RT = 2 = 1.5x what the 64-column algorithm itself must move.  Sharing them was built
+                    //  three ways and measured slower each time, same box: slabs staged through LDS with one barrier per 64
+                    //  products 23.5 against 22.7 ms, three 8-KB stages three slabs ahead with one barrier per 32 products
+                    //  25.6 against 22.6, a bare barrier every 16 / 32 / 64 / 128 products so that the second to fourth
+                    //  reader hit L2 23.3 / 23.1 / 23.0 / 22.9 against 22.7: a wave's pace depends on what the OTHER
+                    //  workgroup's wave on its SIMD is doing, and every meeting point makes the four wait for the slowest.)
+                    if (has) {
+                        load(A, 0);
+                        for (int kp = 0; kp < nkp; kp += 2) {
+                            load(B, kp + 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mult(A);
+                            __builtin_amdgcn_sched_barrier(0);
+                            load(A, (kp + 2 < nkp) ? kp + 2 : kp + 1);   // (the last step re-loads a pair it has)
+                            __builtin_amdgcn_sched_barrier(0);
+                            mult(B);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
+                    }
                 }
                 if (has) {
                     ARD_STAMP(3);
                     // K's entries: register r of tile (ct, t) of lane l is column J0 + 16 ct + l4 + 4 r, row 16 rt_t + l15
                     const int l15 = opaque(l15_), l4 = opaque(l4_);
-                    const bool interior = b >= 2 && !yblk && (rt1 << 4) + 15 < N && J0 + 63 < N;
+                    const bool interior = b >= DB && !yblk && (rtt[RT - 1] << 4) + 15 < N && J0 + 63 < N;
                     if (SKIP & 2) {
                     } else if (yblk) {       // y's tile: row 0 carries y, no kernel entry at all
 #pragma unroll
@@ -334,12 +357,11 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
                             for (int r = 0; r < 4; ++r) {
                                 const double v = (l15 == 0) ? S.yc[16 * ct + l4 + 4 * r] : 0.0;
                                 acc[ct][0][r] = v - acc[ct][0][r];
-                                acc[ct][1][r] = acc[ct][0][r];
                             }
                     } else if (interior) {   // every row and column is an observation, no diagonal entry
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const double *xp = Xp + (int64_t)(((t ? rt1 : rt0) << 4) + l15) * D;
+                        for (int t = 0; t < RT; ++t) {
+                            const double *xp = Xp + (int64_t)((rtt[t] << 4) + l15) * D;
                             double xr[D];
 #pragma unroll
                             for (int k = 0; k < D; ++k) xr[k] = xp[k];
@@ -361,9 +383,8 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
                         }
                     } else {          // the diagonal block, rows / columns of the padding
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const int rt = t ? rt1 : rt0;
-                            const int row = (rt << 4) + l15;
+                        for (int t = 0; t < RT; ++t) {
+                            const int row = (rtt[t] << 4) + l15;
                             const double *xp = Xp + (int64_t)row * D;
                             double xr[D];
 #pragma unroll
@@ -391,15 +412,15 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
                 }
                 ARD_STAMP(4);
                 if (it == 0) {
-                    if (has && b < 2) {   // the diagonal block's rows: lower triangle into LDS
+                    if (has && b < DB) {   // the diagonal block's rows: lower triangle into LDS
                         const int l15 = opaque(l15_), l4 = opaque(l4_);
 #pragma unroll
-                        for (int t = 0; t < 2; ++t)
+                        for (int t = 0; t < RT; ++t)
 #pragma unroll
                             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    const int lrow = 32 * b + 16 * t + l15, jc = 16 * ct + l4 + 4 * r;
+                                    const int lrow = 16 * RT * b + 16 * t + l15, jc = 16 * ct + l4 + 4 * r;
                                     S.M[lrow * LDM + jc] = (jc <= lrow) ? acc[ct][t][r] : 0.0;
                                 }
                     }
@@ -411,31 +432,34 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
                     if (tid < 64) logdet_t += log(S.M[tid * LDM + tid]);
                 }
                 ARD_STAMP(7);
-                if (has && b >= 2 && !(SKIP & 4)) {
+                if (has && b >= DB && !(SKIP & 4)) {
                     // ---- L^T = W C': stored in fragment order; y's row adds its squares to |z|^2 ----
                     const int l15 = opaque(l15_), l4 = opaque(l4_);
 #pragma unroll
                     for (int cq = 0; cq < 4; ++cq) {        // output column tile: panel columns 16 cq ..
-                        d4_t o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
+                        d4_t o[RT];
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) o[t] = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                         for (int ct = 0; ct <= cq; ++ct)    // W is lower triangular
 #pragma unroll
                             for (int kg = 0; kg < 4; ++kg) {
                                 const double a = S.M[(64 + 16 * ct + 4 * kg + l4) * LDM + 16 * cq + l15];   // W[16cq + l15][16ct + 4kg + l4]
-                                o0 = mfma_f64_16x16x4(a, acc[ct][0][kg], o0);
-                                o1 = mfma_f64_16x16x4(a, acc[ct][1][kg], o1);
+#pragma unroll
+                                for (int t = 0; t < RT; ++t)
+                                    if (t == 0 || !yblk) o[t] = mfma_f64_16x16x4(a, acc[ct][t][kg], o[t]);
                             }
                         const int kp0 = nkp + 2 * cq;
-                        d2_t *q0 = Lf + ((int64_t)rt0 * KP + kp0) * 64 + lane;
-                        q0[0] = d2_t{o0[0], o0[1]};
-                        q0[64] = d2_t{o0[2], o0[3]};
-                        if (!yblk) {
-                            d2_t *q1 = Lf + ((int64_t)(rt0 + 1) * KP + kp0) * 64 + lane;
-                            q1[0] = d2_t{o1[0], o1[1]};
-                            q1[64] = d2_t{o1[2], o1[3]};
-                        } else if (l15 == 0) {
-                            quad_t = fma(o0[0], o0[0], quad_t); quad_t = fma(o0[1], o0[1], quad_t);
-                            quad_t = fma(o0[2], o0[2], quad_t); quad_t = fma(o0[3], o0[3], quad_t);
+#pragma unroll
+                        for (int t = 0; t < RT; ++t)
+                            if (t == 0 || !yblk) {
+                                d2_t *q = Lf + ((int64_t)rtt[t] * KP + kp0) * 64 + lane;
+                                q[0] = d2_t{o[t][0], o[t][1]};
+                                q[64] = d2_t{o[t][2], o[t][3]};
+                            }
+                        if (yblk && l15 == 0) {
+                            quad_t = fma(o[0][0], o[0][0], quad_t); quad_t = fma(o[0][1], o[0][1], quad_t);
+                            quad_t = fma(o[0][2], o[0][2], quad_t); quad_t = fma(o[0][3], o[0][3], quad_t);
                         }
                     }
                 }
@@ -484,10 +508,10 @@ inline int64_t head_bytes(int64_t Nf, int64_t G) {
     return (b + 255) / 256 * 256;
 }
 
-template <int D, int MODE>
-int launch(const double *Xp, const double *yp, int64_t N, int64_t Nf, const double *il2p, int64_t G, double jitter, void *out,
-           double *scratch, hipStream_t st) {
-    const void *fn = reinterpret_cast<const void *>(nlml_fused_kernel<D, MODE>);
+template <int D, int MODE, int RT>
+int launch_rt(const double *Xp, const double *yp, int64_t N, int64_t Nf, const double *il2p, int64_t G, double jitter, void *out,
+              double *scratch, hipStream_t st) {
+    const void *fn = reinterpret_cast<const void *>(nlml_fused_kernel<D, MODE, RT>);
     const size_t lds = sizeof(Lds<D>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPBO_ERR_LAUNCH;
     // as many persistent workgroups as are resident at once (registers and LDS decide), never more than there are slots
@@ -502,10 +526,17 @@ int launch(const double *Xp, const double *yp, int64_t N, int64_t Nf, const doub
     }
     int64_t grid = slots_for(Nf, G);
     if (grid > resident) grid = resident;
-    hipLaunchKernelGGL((nlml_fused_kernel<D, MODE>), dim3((unsigned)grid), dim3(TH), lds, st, Xp, yp, (int)N, (int)Nf,
+    hipLaunchKernelGGL((nlml_fused_kernel<D, MODE, RT>), dim3((unsigned)grid), dim3(TH), lds, st, Xp, yp, (int)N, (int)Nf,
                        il2p, (int)G, jitter, out, scratch);
     GPBO_CHECK_LAUNCH();
     return GPBO_OK;
+}
+
+template <int D, int MODE>
+int launch(const double *Xp, const double *yp, int64_t N, int64_t Nf, const double *il2p, int64_t G, double jitter, void *out,
+           double *scratch, hipStream_t st) {
+    if (Nf >= RT4_FROM) return launch_rt<D, MODE, 4>(Xp, yp, N, Nf, il2p, G, jitter, out, scratch, st);
+    return launch_rt<D, MODE, 2>(Xp, yp, N, Nf, il2p, G, jitter, out, scratch, st);
 }
 
 template <int MODE>

@@ -1044,10 +1044,28 @@ int gpbo_cholinv_run(double *S, int64_t ld, int64_t Np, int32_t *info, const int
     if (want_stamps && !dstamps && hipMalloc(&dstamps, 8 * 8 * 1024) != hipSuccess) return GPBO_ERR_LAUNCH;
     int npair = 0;
 #endif
+#ifdef GPBO_DIAGNOSTICS
+    // GPBO_CI_CEILING (timing builds only, WRONG results): what ANY scheduler of these tiles could reach.
+    //   1: the critical path alone - the NEAR and PAIR launches without their filler tiles;
+    //   2: the work alone - every update tile of the plan in ONE launch, no dependencies, no PAIR workgroups.
+    static const int ceiling = getenv("GPBO_CI_CEILING") ? atoi(getenv("GPBO_CI_CEILING")) : 0;
+    if (ceiling == 2) {
+        a.near = CiNear{0, 0, 0, 0, 0, 0, 0, 0};
+        a.l = CiLaunch{-1, 0, 0, (int)dp->plan.tiles.size(), 1};
+        if (dp->has256) hipLaunchKernelGGL(cholinv_kernel<true>, dim3((unsigned)a.l.ntile), dim3(512), 0, st, CI_FLAT_ARGS(a));
+        else hipLaunchKernelGGL(cholinv_kernel<false>, dim3((unsigned)a.l.ntile), dim3(512), 0, st, CI_FLAT_ARGS(a));
+        GPBO_CHECK_LAUNCH();
+        return GPBO_OK;
+    }
+#endif
     size_t li = 0;
-    for (const CiLaunch &l : dp->plan.launches) {
+    for (const CiLaunch &l0 : dp->plan.launches) {
+        CiLaunch l = l0;
         a.near = dp->near[li++];
         if (left-- <= 0) break;
+#ifdef GPBO_DIAGNOSTICS
+        if (ceiling == 1 && l.npair > 0) l.ntile = 0;
+#endif
         a.l = l;
         const int nblk = ci_launch_blocks(l);
         if (nblk <= 0) continue;
