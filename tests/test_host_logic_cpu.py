@@ -126,6 +126,17 @@ def test_replayed_pmc_figures_belong_to_todays_kernel_sources():
     e, stale = bench._pmc_entry(4096, 8, "f64", 131072)
     assert e is head or e == head
     assert stale is False
-    e, stale = bench._pmc_entry(4096, 8, "i8", 131072)     # collected before hashes were stored: unknown, not "fresh"
-    assert e is not None and stale is None
+    # round 5: every replayed entry was re-collected on the final sources and carries its hash - none is "unknown" any more
+    for key in shapes:
+        assert "kernel_source_hash" in shapes[key], key
+    e, stale = bench._pmc_entry(4096, 8, "i8", 131072)
+    assert e is not None and stale is False
+    # ... and the likelihood grid's entries (profiles/pmc_ard.json, profiles/collect_ard.sh) likewise
+    ard = json.load(open(os.path.join(repo, "profiles", "pmc_ard.json")))
+    assert {"N=176,d=2,cells=2500", "N=512,d=8,cells=2500", "N=1024,d=8,cells=2500"} <= set(ard)
+    for key, e in ard.items():
+        assert e["kernel_source_hash"] == sh.kernel_source_hash("ard"), \
+            f"{key}: ard.hip changed since {e['source']} was collected: re-run profiles/collect_ard.sh + summarise_ard.py"
+    e, stale = bench._pmc_ard_entry(512, 8)
+    assert e is not None and stale is False
     assert bench._pmc_entry(123, 8, "f64", 131072) == (None, None)
