@@ -127,12 +127,20 @@ def _convergence(info, within):
 
 def select_parameters(base_dir: str = ".", selector_factory: Optional[Callable] = None,
                       rng: Optional[np.random.Generator] = None, echo: bool = False,
-                      keep_surrogate: bool = False) -> dict:
+                      keep_surrogate: bool = False, likelihood: str = "reference") -> dict:
     """Run one SELECT_PARAMETERS step in `base_dir`.  Returns a summary dict (what was chosen).
     keep_surrogate: carry the factorisation from job to job in `<measured_points file>.surrogate.npz` (the factory is
-    then called with `state_path=...`; new rows are appended in O(N^2) while the chosen length scales stay the same)."""
+    then called with `state_path=...`; new rows are appended in O(N^2) while the chosen length scales stay the same).
+    likelihood: "reference" (the reference's ARD likelihood, determinant underflow included) or "logdet" (opt-in, finite at
+    any number of observations: INTEGRATION.md section 4); anything but the default is passed on to the selector's constructor."""
+    if likelihood not in ("reference", "logdet"):
+        raise ValueError("likelihood must be 'reference' or 'logdet'")
     if selector_factory is None:
         from .point_selector import PointSelector as selector_factory  # the GPU class (raises without a GPU)
+    if likelihood != "reference":
+        import functools
+
+        selector_factory = functools.partial(selector_factory, likelihood=likelihood)
     log = _Log(os.path.join(base_dir, "algo_log.txt"), echo)
     json_path = os.path.join(base_dir, "opto_log.JSON")
     mp_dir = os.path.join(base_dir, "measured_points")
@@ -268,7 +276,8 @@ def select_parameters(base_dir: str = ".", selector_factory: Optional[Callable] 
 
 def main():
     select_parameters(os.environ.get("GPBO_BASE_DIR", os.getcwd()), echo=True,
-                      keep_surrogate=os.environ.get("GPBO_KEEP_SURROGATE", "0") == "1")
+                      keep_surrogate=os.environ.get("GPBO_KEEP_SURROGATE", "0") == "1",
+                      likelihood=os.environ.get("GPBO_LIKELIHOOD", "reference"))
 
 
 if __name__ == "__main__":

@@ -165,3 +165,24 @@ def test_driver_on_gpu_matches_oracle_selector(tmp_path, which):
     if which in ("PointSelector", "PointSelectorHost"):  # (one state file serves one parameter block)
         assert _run_1d(_fresh(tmp_path / "cpu"), OracleSelector, [7, 8], "A3", 0.1) == \
             _run_1d(_fresh(tmp_path / "gpu"), factory, [7, 8], "A3", 0.1)
+
+
+def test_driver_passes_the_likelihood_mode_to_the_selector(tmp_path):
+    """select_parameters(likelihood="logdet") (module entry point: GPBO_LIKELIHOOD=logdet) constructs its selector with that
+    keyword; the default constructs it exactly as before (no keyword: any drop-in class works)."""
+    seen = []
+
+    class Recording(OracleSelector):
+        def __init__(self, **kw):
+            seen.append(kw)
+            super().__init__()
+
+    base = _fresh(tmp_path)
+    SP.select_parameters(base, selector_factory=Recording, rng=np.random.default_rng(7))      # iteration 0: random point, no GP
+    _fake_time_residuals(base, "T1_T2_ALGO_0_BLOCK_0.npy", 12.5)
+    SP.select_parameters(base, selector_factory=Recording)
+    _fake_time_residuals(base, "T1_T2_ALGO_0_BLOCK_0.npy", 11.0)
+    SP.select_parameters(base, selector_factory=Recording, likelihood="logdet")
+    assert seen and seen[0] == {} and seen[-1] == {"likelihood": "logdet"}
+    with pytest.raises(ValueError):
+        SP.select_parameters(base, selector_factory=Recording, likelihood="det")
