@@ -70,8 +70,19 @@ def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
     assert "qEI" in c4["workload"] and c4["nan_count"] == 0 and 0 <= c4["argmax_batch"] < (1 << 17)
     assert c4["roofline"]["kernel"] == "sigma_acq_kernel" and 0.3 < c4["roofline"]["frac"] <= 1.0
     q = c4["qei_roofline"]
-    assert q["bound"] == "hbm" and q["kernel"] == "qei_kernel" and q["bytes_per_candidate"] == 8.0 * 2048 and 0.0 < q["frac"] <= 1.0
+    # round 5: the stage reads the Gram partials the variance launch leaves (16 x 64 doubles per batch of 8), not the rows of V
+    assert q["bound"] == "hbm" and q["kernel"] == "qei_kernel" and q["bytes_per_candidate"] == 16 * 64.0 and 0.0 < q["frac"] <= 1.0
     assert q["launches"] == c4["roofline"]["launches"] == 3 * 8   # 3 timed steps x 8 chunks of 2^17
+    assert c4["cpu_baseline"]["kind"] == "port" and c4["cpu_baseline"]["max_abs_diff_gpu_vs_oracle_on_sample"] <= 1e-9
+    assert line["also"]["configs[1]"]["cpu_baseline"]["value"] > 0 and c3["cpu_baseline"]["value"] > 0
+    assert line["roofline"]["kstar"]["kernel"] == "kstar_mu_kernel" and 0.3 < line["roofline"]["kstar"]["frac"] <= 1.0
+    ag = line["also"]["ard_grid"]
+    assert [e["roofline"]["cells_per_launch"] for e in ag] == [2500] * 4 and all(e["cpu_baseline"]["value"] > 0 for e in ag)
+    assert ag[0]["roofline"]["bound"] == "latency" and all(e["roofline"]["bound"] == "mfma" and 0.02 < e["roofline"]["frac"] <= 1.0 for e in ag[1:])
+    assert all(e["finite_cells_logdet_mode"] == 2500 and e["logdet_mode_max_rel_err_vs_oracle_on_sample"] <= 1e-9 for e in ag)
+    assert all(e["reference_mode_matches_oracle_where_finite"] in (True, None) for e in ag)
+    ap = line["also"]["append"]
+    assert 0 < ap["append_ms"] < ap["refactorise_ms"] and ap["alpha_max_rel_diff_vs_refactorisation"] <= 1e-9
     fm = line["also"]["configs[2]_all_2^24_candidates_on_one_gpu"]
     assert fm["candidates"] == 1 << 24 and fm["equals_reduction_of_8_shard_calls"] is True and fm["nan_count"] == 0
     assert fm["shard0_is_the_headline_run"] is True and 0.8 < fm["per_candidate_rate_vs_headline"] < 1.25
