@@ -330,7 +330,34 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
                     //  25.6 against 22.6, a bare barrier every 16 / 32 / 64 / 128 products so that the second to fourth
                     //  reader hit L2 23.3 / 23.1 / 23.0 / 22.9 against 22.7: a wave's pace depends on what the OTHER
                     //  workgroup's wave on its SIMD is doing, and every meeting point makes the four wait for the slowest.)
-                    if (has) {
+                    if (has && RT == 2) {
+                        // four register sets in rotation, every pair TWO steps in front of its products (nkp is a multiple of
+                        // 8): with one pair ahead the loop waited for memory, not for the matrix pipes, whenever the other
+                        // workgroup's wave left this SIMD's pipe to it - 2,500 cells at N = 512 / 1024, same box, d = 2:
+                        // 4.00 / 24.7 ms one ahead, 3.63 / 22.6 two, 3.65 / 22.6 three
+                        Frag C, E;
+                        auto ld = [&](Frag &F, int k) { load(F, k < nkp ? k : nkp - 1); };   // (the tail re-loads the last pair)
+                        load(A, 0);
+                        load(B, 1);
+                        for (int kp = 0; kp < nkp; kp += 4) {
+                            ld(C, kp + 2);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mult(A);
+                            __builtin_amdgcn_sched_barrier(0);
+                            ld(E, kp + 3);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mult(B);
+                            __builtin_amdgcn_sched_barrier(0);
+                            ld(A, kp + 4);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mult(C);
+                            __builtin_amdgcn_sched_barrier(0);
+                            ld(B, kp + 5);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mult(E);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else if (has) {   // 64 x 64 wave tiles: two sets (128 accumulator registers leave room for no more)
                         load(A, 0);
                         for (int kp = 0; kp < nkp; kp += 2) {
                             load(B, kp + 1);
