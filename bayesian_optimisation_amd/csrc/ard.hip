@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void nlml_cell_kernel(const double *__restrict
 // CU) and owns one scratch slot of (Nf + 16) x Nf doubles, written once and read (N / 64) / 3 times on average per cell -
 // the matrices of the launch-chain version of rounds 2-4 (up to 8 GiB per sub-batch, swept once per panel by three
 // launches: 11.4 / 61 ms for 2,500 cells at N = 512 / 1024) are gone.  Measured (one MI355X, 2,500 cells, d = 8):
-// N = 176 / 512 / 1024: 0.65 / 4.2 / 23.8 ms = 0.09 / 0.34 / 0.48 of the fp64 matrix peak; where the rest goes
+// N = 176 / 512 / 1024: 0.63 / 3.9 / 23.1 ms = 0.09 / 0.36 / 0.49 of the fp64 matrix peak; where the rest goes
 // (tools/ard_stamps.py, knock-out builds): DESIGN.md section 4a.
 namespace fused {
 
@@ -164,10 +164,6 @@ __device__ int g_nstamps[4];
 #define ARD_STAMP(TAG) do { } while (0)
 #endif
 
-#ifndef GPBO_ARD_RT4_FROM
-#define GPBO_ARD_RT4_FROM 1280
-#endif
-constexpr int RT4_FROM = GPBO_ARD_RT4_FROM;   // padded sizes from here on: 64 x 64 wave tiles (see the kernel)
 constexpr int OCC = 2;                  // workgroups (= waves per SIMD) per CU: LDS (the elimination's image) allows two
 constexpr int TH = 256;                 // 4 waves, one per SIMD; several workgroups per CU fill each other's serial phases
 constexpr int WAVES = TH / 64;
@@ -230,7 +226,7 @@ __global__ __launch_bounds__(256) void nlml_prep_kernel(const double *__restrict
 
 // MODE 0: the reference's likelihood, float32, log(exp(logdet)) (point_selector.py:117-119: np.log(np.linalg.det(K)));
 // MODE 1: fp64, log det straight from the factor (no underflow), NaN when a pivot fails.
-template <int D, int MODE, int RT /* row tiles per block of a wave: 2 or 4 */>
+template <int D, int MODE, int RT /* row tiles per block of a wave: 2 (4 measured and not instantiated, see the kernel) */>
 __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__restrict__ Xp, const double *__restrict__ yp, int N,
                                                          int Nf, const double *__restrict__ il2p, int G, double jitter,
                                                          void *__restrict__ out_, double *scratch) {
@@ -269,11 +265,10 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
             // rows of the panel in blocks of RT row tiles (32 or 64 rows): the first 64 / (16 RT) blocks = the diagonal block,
             // block nblk = y's tile.  Wave w takes blocks w, w + 4, ...; the elimination of the diagonal block sits between the
             // two products of every wave's FIRST block (all four waves pass through every iteration, with or without a block).
-            // RT = 4 (Nf >= 1280): a 64 x 64 wave tile fetches (64 + 64) 8 bytes per 8,192 flop where the 32 x 64 one fetches
-            // (32 + 64) 8 per 4,096 - a third less traffic for the product that runs at the memory system's rate - at the
-            // price of half as many blocks to share out among the four waves and of ~100 spilled registers.  Measured, same
-            // box, 2,500 cells, d = 2, ms with RT = 2 / RT = 4: N = 512: 4.01 / 4.62; 768: 11.3 / 12.0; 1024: 24.8 / 24.9 (d = 8:
-            // 26.2 / 27.2); 1536: 78.5 / 75.3; 2048: 180.7 / 167.7 - it pays from about 1,300 observations on.
+            // (RT = 4 - a 64 x 64 wave tile, a third less operand traffic per flop, 128 accumulator registers, two register
+            //  sets only - was built and measured: with one pair ahead on both sides it won from 1,300 observations on (N = 1536 /
+            //  2048: 75.3 / 167.7 against 78.5 / 180.7 ms), against RT = 2 with its pairs two steps ahead it loses everywhere
+            //  (74.9 / 163.4 against 69.8 / 161.1): only RT = 2 is instantiated.)
             constexpr int DB = 4 / RT;                    // blocks of the diagonal block
             const int nblk = (Nf - J0) / (16 * RT);
             const int jt0 = J0 >> 4;
@@ -324,13 +319,13 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
                             }
                     };
                     // (Every wave fetches the panel rows - pa, the operand the four share - for itself: 104 GB per 2,500 cells
-                    //  at N = 1024, d = 8 with RT = 2 = 1.5x what the 64-column algorithm itself must move.  Sharing them was built
+                    //  at N = 1024, d = 8 = 1.5x what the 64-column algorithm itself must move.  Sharing them was built (with ONE pair ahead)
                     //  three ways and measured slower each time, same box: slabs staged through LDS with one barrier per 64
                     //  products 23.5 against 22.7 ms, three 8-KB stages three slabs ahead with one barrier per 32 products
                     //  25.6 against 22.6, a bare barrier every 16 / 32 / 64 / 128 products so that the second to fourth
                     //  reader hit L2 23.3 / 23.1 / 23.0 / 22.9 against 22.7: a wave's pace depends on what the OTHER
                     //  workgroup's wave on its SIMD is doing, and every meeting point makes the four wait for the slowest.)
-                    if (has && RT == 2) {
+                    if (has) {
                         // four register sets in rotation, every pair TWO steps in front of its products (nkp is a multiple of
                         // 8): with one pair ahead the loop waited for memory, not for the matrix pipes, whenever the other
                         // workgroup's wave left this SIMD's pipe to it - 2,500 cells at N = 512 / 1024, same box, d = 2:
@@ -355,18 +350,6 @@ __global__ __launch_bounds__(TH, OCC) void nlml_fused_kernel(const double *__res
                             ld(B, kp + 5);
                             __builtin_amdgcn_sched_barrier(0);
                             mult(E);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    } else if (has) {   // 64 x 64 wave tiles: two sets (128 accumulator registers leave room for no more)
-                        load(A, 0);
-                        for (int kp = 0; kp < nkp; kp += 2) {
-                            load(B, kp + 1);
-                            __builtin_amdgcn_sched_barrier(0);
-                            mult(A);
-                            __builtin_amdgcn_sched_barrier(0);
-                            load(A, (kp + 2 < nkp) ? kp + 2 : kp + 1);   // (the last step re-loads a pair it has)
-                            __builtin_amdgcn_sched_barrier(0);
-                            mult(B);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -562,7 +545,6 @@ int launch_rt(const double *Xp, const double *yp, int64_t N, int64_t Nf, const d
 template <int D, int MODE>
 int launch(const double *Xp, const double *yp, int64_t N, int64_t Nf, const double *il2p, int64_t G, double jitter, void *out,
            double *scratch, hipStream_t st) {
-    if (Nf >= RT4_FROM) return launch_rt<D, MODE, 4>(Xp, yp, N, Nf, il2p, G, jitter, out, scratch, st);
     return launch_rt<D, MODE, 2>(Xp, yp, N, Nf, il2p, G, jitter, out, scratch, st);
 }
 
