@@ -13,6 +13,7 @@
 #include "gpbo_internal.h"
 #include "exp_neg.h"
 #include "potrf_diag64.h"
+#include <atomic>
 
 #include <cmath>
 #include <limits>
@@ -525,7 +526,8 @@ int launch_rt(const double *Xp, const double *yp, int64_t N, int64_t Nf, const d
     const size_t lds = sizeof(Lds<D>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPBO_ERR_LAUNCH;
     // as many persistent workgroups as are resident at once (registers and LDS decide), never more than there are slots
-    static int resident = 0;   // per template instance; the device's answer does not change
+    static std::atomic<int> resident_{0};   // per template instance; the device's answer does not change
+    int resident = resident_.load(std::memory_order_relaxed);
     if (resident == 0) {
         int per_cu = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TH, lds) != hipSuccess || per_cu < 1) per_cu = 2;
@@ -533,6 +535,7 @@ int launch_rt(const double *Xp, const double *yp, int64_t N, int64_t Nf, const d
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
             cus = 256;
         resident = per_cu * cus;
+        resident_.store(resident, std::memory_order_relaxed);
     }
     int64_t grid = slots_for(Nf, G);
     if (grid > resident) grid = resident;
