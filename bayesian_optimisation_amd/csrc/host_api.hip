@@ -241,7 +241,7 @@ static int nlml_grid_host(const double *X, const double *y, int64_t N, int32_t d
     double *dcells = A.alloc<double>(G * d);
     if (!A.ok) return GPBO_ERR_WORKSPACE;
     if (!A.h2d(dcells, ls_cells, sizeof(double) * G * d)) return GPBO_ERR_LAUNCH;
-    if (N <= 64 && mode == 0) {   // the in-LDS kernel (DeviceGP.ARD_LDS_MAX_N: the same switch as the tensor-resident binding)
+    if (N <= 32 && mode == 0) {   // the in-LDS kernel (DeviceGP.ARD_LDS_MAX_N: the same switch as the tensor-resident binding)
         rc = gpbo_nlml_grid_f64(dX, dy, N, d, dcells, G, jitter, reinterpret_cast<float *>(dout), st);
         if (rc != GPBO_OK) return rc;
     } else {         // one persistent workgroup per cell, the whole factorisation in one launch

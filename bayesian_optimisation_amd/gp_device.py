@@ -772,7 +772,9 @@ class DeviceGP:
         return ScoreResult(v, i, n, mu, sigma, acq)
 
     # -- ARD grid ------------------------------------------------------------------------------------
-    ARD_LDS_MAX_N = 64   # above: the batched blocked Cholesky (faster from here on; see nlml_grid)
+    ARD_LDS_MAX_N = 32   # above: the fused kernel (2,500 cells, d = 2 / 8 / 16, ms: N = 32 in LDS 0.116 / 0.118 / 0.136 against
+                         # 0.125 / 0.144 / 0.183 fused; N = 48: 0.23 / 0.24 / 0.27 against 0.125 / 0.142 / 0.180; N = 64: 0.42 / 0.44 /
+                         # 0.57 against 0.122 / 0.140 / 0.178 - tools/ard_lds_vs_fused.py; the float32 cells of the two are equal)
 
     def nlml_grid(self, X, y, ls_cells, jitter: float = JITTER_KERNEL, likelihood: str = "reference") -> np.ndarray:
         """-log marginal likelihood of every row of ls_cells [G x d]  (point_selector.py:111-156), as a host array.
@@ -800,9 +802,9 @@ class DeviceGP:
         logdet = likelihood == "logdet"
         with torch.cuda.device(self.device):
             if N > self.ARD_LDS_MAX_N or logdet:
-                # one persistent workgroup per cell, the whole factorisation in one launch (csrc/ard.hip, round 5); small N
-                # in reference mode stays on the in-LDS kernel, whose elimination order is the one pinned against the
-                # reference's float32 ties (golden g4_ard_n2).
+                # one persistent workgroup per cell, the whole factorisation in one launch (csrc/ard.hip, round 5); N <= 32
+                # in reference mode stays on the in-LDS kernel (faster there, and its elimination order is the one pinned
+                # against the reference's float32 ties: golden g4_ard_n2).
                 out = torch.empty(G, dtype=torch.float64 if logdet else torch.float32, device=self.device)
                 need = int(self.lib.gpbo_nlml_grid_batched_workspace_bytes(N, G))
                 if need < 0:

@@ -332,7 +332,7 @@ int gpbo_acq_argmax_f64(const double *mu, const double *sigma, int64_t M, int32_
  *   info (host): 0, or the 1-based failing pivot (the reference's inv() raises LinAlgError or returns garbage) -
  *   then nothing is scored and result->best_idx = -1.
  * gpbo_nlml_grid_host_f64 = tune_kernel()'s float32 likelihood grid (point_selector.py:104-163): ls_cells [G x d]
- *   host, out [G] host float32; any N (the in-LDS kernel up to 64 observations, the one-launch workgroup-per-cell
+ *   host, out [G] host float32; any N (the in-LDS kernel up to 32 observations, the one-launch workgroup-per-cell
  *   kernel beyond). */
 /* (When mu_out, sigma_out and acq_out are all NULL, M >= 32768, N > 896 and the acquisition increases with sigma, the next
  * point is found by branch and bound on the exact prefix bound - gpbo_posterior_prefix_f64 / gpbo_bound_select_f64 below -
