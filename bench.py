@@ -576,7 +576,7 @@ def main():
         grid2 = np.stack(np.meshgrid(a, a, indexing="ij"), -1).reshape(-1, 2)
         out = []
         ga = DeviceGP(dev)
-        for (n_, d_) in ((32, 2), (176, 2), (512, 8), (1024, 8)):
+        for (n_, d_) in ((32, 2), (64, 2), (176, 2), (512, 8), (1024, 8)):   # (64: the largest one-panel case of the fused kernel)
             if d_ == 2:
                 cells = grid2
             else:   # a d-feature search's cells: two coordinates over the 50 x 50 grid, the others at geomspace(0.2, 2)
