@@ -250,6 +250,23 @@ def main_g10():
              explore=np.array(4.0 if explore is None else float(explore)), nlogml=nlml_grid_reference(X, y, lsg), **out)
 
 
+def main_g11():
+    """G11 (round 5): the DAG-shaped full path with MORE observations than one 64-column panel of the fused likelihood kernel
+    holds (csrc/ard.hip: it serves N > 32): N = 64 (the largest one-panel case) and N = 100 (two panels), 2-D, the reference's
+    ARD search included - most of the float32 grid is -inf / NaN there (np.linalg.det under- and overflows,
+    point_selector.py:117-119) and the reference takes the first minimum of what is left."""
+    rng = np.random.default_rng(1111)
+    ls2 = np.array([L1, L2])
+    for n in (64, 100):
+        pick = rng.choice(2500, size=n, replace=False)
+        X = np.stack([T1[pick // 50], T2[pick % 50]], 1)
+        y = synth_y2(X, rng)
+        Xs = grid2(T1, T2)
+        out, _ = run_reference(X, y, Xs, [50, 50], length_scales=ls2, name=np.array(["T1", "T2"]), iteration=n)
+        save(f"g11_2d_n{n}", X=X, y=y, Xs=Xs, feature_domain=np.array([50, 50]), length_scales=ls2,
+             explore=np.array(4.0), nlogml=nlml_grid_reference(X, y, ls2), **out)
+
+
 def copy_state_file():
     """The DAG's state file as shipped by the reference (opto_log_clean.JSON: data, not code) - the driver
     tests start from it so the JSON schema they exercise is the reference's own."""
@@ -264,7 +281,9 @@ def copy_state_file():
 if __name__ == "__main__":
     if not ONLY or any(o.startswith("g10") for o in ONLY):
         main_g10()
-    if not ONLY or any(not o.startswith("g10") for o in ONLY):
+    if not ONLY or any(o.startswith("g11") for o in ONLY):
+        main_g11()
+    if not ONLY or any(not o.startswith(("g10", "g11")) for o in ONLY):
         main()
     if not ONLY:
         copy_state_file()

@@ -156,6 +156,31 @@ def test_dropin_full_path_with_ard(golden, name):
         np.testing.assert_allclose(ps.nlogml, g["nlogml"], rtol=2e-6)
 
 
+@pytest.mark.parametrize("name", ["g11_2d_n64", "g11_2d_n100"])
+def test_dropin_full_path_with_ard_beyond_one_panel_of_the_fused_kernel(golden, name):
+    """G11 (round 5): the reference run with 64 and 100 observations - the fused likelihood kernel's largest one-panel case
+    and a two-panel case.  At N = 100 half of the reference's float32 grid is -inf (np.linalg.det underflows,
+    point_selector.py:117-119) and its ARD choice is the first such cell: the same choice, the same posterior, the same
+    index; the grid itself equal wherever the reference's determinant is a normal number, -inf where it is zero, and left
+    out where it is a denormal (log det in [-745, -708]: the reference's own value is rounding noise there)."""
+    g = golden(name)
+    ps, idx = _run_dropin(g)
+    assert np.array_equal(np.asarray(ps.kernel_params), g["kernel_params"]) and ps.kernel_params.shape == g["kernel_params"].shape
+    _check_against(ps.mean_func.ravel(), ps.cov_func.ravel(), ps.acq_func_eval.ravel(),
+                   int(np.ravel_multi_index(tuple(idx), g["mean_func"].shape)), g)
+    ref = g["nlogml"]
+    assert ps.nlogml.dtype == np.float32 and ps.nlogml.shape == ref.shape
+    lsg = g["length_scales"]
+    cells = np.stack(np.meshgrid(lsg[0], lsg[1], indexing="ij"), -1).reshape(-1, 2)
+    logdet = np.array([np.linalg.slogdet(O.kernel_rbf(g["X"], g["X"], c))[1] for c in cells]).reshape(ref.shape)
+    normal = logdet > -707.0
+    zero = logdet < -746.0
+    assert normal.sum() + zero.sum() >= ref.size - 300 and normal.sum() >= 900   # (N = 100: 960 normal, 1,256 zero, 284 between)
+    np.testing.assert_allclose(ps.nlogml[normal], ref[normal], rtol=2e-6)
+    assert np.all(np.isneginf(ref[zero])) and np.all(np.isneginf(ps.nlogml[zero]))
+    assert np.array_equal(np.argwhere(ps.nlogml == ps.nlogml.min())[0], np.argwhere(ref == ref.min())[0])
+
+
 @pytest.mark.parametrize("name", ["g4_tie_tiny_ls", "g4_dup_rows", "g7_n_eq_m", "g9_d24_n96_m512"])
 def test_dropin_preset_length_scales(golden, name):
     g = golden(name)

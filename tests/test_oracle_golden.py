@@ -116,7 +116,8 @@ def test_qei_oracle_limits():
     np.testing.assert_allclose(c, d, rtol=1e-13, atol=1e-15)
 
 
-@pytest.mark.parametrize("name", ["g10_2d_0", "g10_2d_1", "g10_2d_2", "g10_2d_3", "g10_2d_4", "g10_1d_0", "g10_1d_1", "g10_1d_2"])
+@pytest.mark.parametrize("name", ["g10_2d_0", "g10_2d_1", "g10_2d_2", "g10_2d_3", "g10_2d_4", "g10_1d_0", "g10_1d_1", "g10_1d_2",
+                                  "g11_2d_n64", "g11_2d_n100"])   # (G11, round 5: 64 and 100 observations; at 100 half the grid is -inf)
 def test_randomised_dag_shaped_cases(golden, name):
     """G10 (round 4): the reference run on observations drawn from its own grids, with the placeholder objective 10000 in
     the last row (select_parameters.py:163,299), duplicated grid points, exploration weights 0.5 / 1 / 2 / 4 - the ARD
