@@ -89,6 +89,9 @@ SIGNATURES = {
     "gpbo_acq_argmax_f64": (C.c_int, [_p, _p, _i64, _i32, _f64, _f64, _i64, _p, _p, _p, _i64, _p]),
     "gpbo_nlml_grid_max_n": (C.c_int, []),
     "gpbo_nlml_grid_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p, _p]),
+    "gpbo_nlml_grid_wave_max_n": (C.c_int, []),
+    "gpbo_nlml_grid_wave_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p, _p]),
+    "gpbo_nlml_grid_wave_logdet_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p, _p]),
     "gpbo_nlml_grid_batched_workspace_bytes": (_i64, [_i64, _i64]),
     "gpbo_nlml_grid_batched_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p, _p, _i64, _p]),
     "gpbo_nlml_grid_batched_logdet_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _f64, _p, _p, _i64, _p]),

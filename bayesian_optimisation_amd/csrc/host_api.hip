@@ -241,8 +241,9 @@ static int nlml_grid_host(const double *X, const double *y, int64_t N, int32_t d
     double *dcells = A.alloc<double>(G * d);
     if (!A.ok) return GPBO_ERR_WORKSPACE;
     if (!A.h2d(dcells, ls_cells, sizeof(double) * G * d)) return GPBO_ERR_LAUNCH;
-    if (N <= 32 && mode == 0) {   // the in-LDS kernel (DeviceGP.ARD_LDS_MAX_N: the same switch as the tensor-resident binding)
-        rc = gpbo_nlml_grid_f64(dX, dy, N, d, dcells, G, jitter, reinterpret_cast<float *>(dout), st);
+    if (N <= gpbo_nlml_grid_wave_max_n()) {   // the wave-per-cell kernel (the same switch as the tensor-resident binding)
+        rc = mode ? gpbo_nlml_grid_wave_logdet_f64(dX, dy, N, d, dcells, G, jitter, reinterpret_cast<double *>(dout), st)
+                  : gpbo_nlml_grid_wave_f64(dX, dy, N, d, dcells, G, jitter, reinterpret_cast<float *>(dout), st);
         if (rc != GPBO_OK) return rc;
     } else {         // one persistent workgroup per cell, the whole factorisation in one launch
         const int64_t wb = gpbo_nlml_grid_batched_workspace_bytes(N, G);

@@ -772,9 +772,12 @@ class DeviceGP:
         return ScoreResult(v, i, n, mu, sigma, acq)
 
     # -- ARD grid ------------------------------------------------------------------------------------
-    ARD_LDS_MAX_N = 32   # above: the fused kernel (2,500 cells, d = 2 / 8 / 16, ms: N = 32 in LDS 0.116 / 0.118 / 0.136 against
-                         # 0.125 / 0.144 / 0.183 fused; N = 48: 0.23 / 0.24 / 0.27 against 0.125 / 0.142 / 0.180; N = 64: 0.42 / 0.44 /
-                         # 0.57 against 0.122 / 0.140 / 0.178 - tools/ard_lds_vs_fused.py; the float32 cells of the two are equal)
+    ARD_KERNEL = "wave"  # N <= gpbo_nlml_grid_wave_max_n() (64): "wave" = a wave per cell, the matrix in registers (csrc/ard_wave.hip,
+                         # round 5: 2,500 cells at N = 16 / 32 / 48 / 64, d = 2: 0.014 / 0.026 / 0.049 / 0.068 ms);
+                         # "lds" = the workgroup-per-cell kernel of round 2 up to ARD_LDS_MAX_N, the fused kernel beyond (the
+                         # routing until the end of round 5: 0.044 / 0.116 / 0.125 / 0.122 ms; tools/ard_lds_vs_fused.py).
+                         # The float32 cells of the three kernels are equal.
+    ARD_LDS_MAX_N = 32
 
     def nlml_grid(self, X, y, ls_cells, jitter: float = JITTER_KERNEL, likelihood: str = "reference") -> np.ndarray:
         """-log marginal likelihood of every row of ls_cells [G x d]  (point_selector.py:111-156), as a host array.
@@ -801,10 +804,16 @@ class DeviceGP:
         G = int(cells.shape[0])
         logdet = likelihood == "logdet"
         with torch.cuda.device(self.device):
-            if N > self.ARD_LDS_MAX_N or logdet:
-                # one persistent workgroup per cell, the whole factorisation in one launch (csrc/ard.hip, round 5); N <= 32
-                # in reference mode stays on the in-LDS kernel (faster there, and its elimination order is the one pinned
-                # against the reference's float32 ties: golden g4_ard_n2).
+            wave = self.ARD_KERNEL == "wave" and N <= int(self.lib.gpbo_nlml_grid_wave_max_n())
+            if wave:
+                # the reference's own sizes: a wave per cell, the matrix in registers (csrc/ard_wave.hip), both likelihood modes;
+                # pinned against the reference's float32 ties (golden g4_ard_n2) like the in-LDS kernel it replaced
+                out = torch.empty(G, dtype=torch.float64 if logdet else torch.float32, device=self.device)
+                fn = self.lib.gpbo_nlml_grid_wave_logdet_f64 if logdet else self.lib.gpbo_nlml_grid_wave_f64
+                st = fn(self._ptr(Xd), self._ptr(yd), N, d, self._ptr(cells), G, float(jitter), self._ptr(out), self._stream())
+                _lib.check(st, "gpbo_nlml_grid_wave_logdet_f64" if logdet else "gpbo_nlml_grid_wave_f64")
+            elif N > self.ARD_LDS_MAX_N or logdet:
+                # one persistent workgroup per cell, the whole factorisation in one launch (csrc/ard.hip, round 5)
                 out = torch.empty(G, dtype=torch.float64 if logdet else torch.float32, device=self.device)
                 need = int(self.lib.gpbo_nlml_grid_batched_workspace_bytes(N, G))
                 if need < 0:

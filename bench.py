@@ -312,7 +312,7 @@ def _pmc_ard_entry(N, d):
         sys.path.insert(0, os.path.join(REPO, "profiles"))
         from source_hash import kernel_source_hash
 
-        return e, e.get("kernel_source_hash") != kernel_source_hash("ard")
+        return e, e.get("kernel_source_hash") != kernel_source_hash(e.get("hash_key", "ard"))
     except Exception:  # noqa: BLE001
         return None, None
 
@@ -576,7 +576,7 @@ def main():
         grid2 = np.stack(np.meshgrid(a, a, indexing="ij"), -1).reshape(-1, 2)
         out = []
         ga = DeviceGP(dev)
-        for (n_, d_) in ((32, 2), (64, 2), (176, 2), (512, 8), (1024, 8)):   # (64: the largest one-panel case of the fused kernel)
+        for (n_, d_) in ((32, 2), (64, 2), (176, 2), (512, 8), (1024, 8)):   # (32, 64: the wave-per-cell kernel; beyond: the fused kernel)
             if d_ == 2:
                 cells = grid2
             else:   # a d-feature search's cells: two coordinates over the 50 x 50 grid, the others at geomspace(0.2, 2)
@@ -599,18 +599,24 @@ def main():
             ms = e0.elapsed_time(e1) / reps
             flop = 2500.0 * float(n_) ** 3 / 3.0
             tf = flop / (ms * 1e-3) / 1e12
-            fused = n_ > ga.ARD_LDS_MAX_N
+            fused = n_ > int(ga.lib.gpbo_nlml_grid_wave_max_n())
             ent, stale = _pmc_ard_entry(n_, d_)
-            rf = dict(bound="mfma" if fused else "latency", achieved=round(tf, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+            rf = dict(bound="mfma" if fused else "valu", achieved=round(tf, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                       frac=round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
-                      kernel="nlml_fused_kernel (+ nlml_prep_kernel)" if fused else "nlml_grid_kernel",
+                      kernel="nlml_fused_kernel (+ nlml_prep_kernel)" if fused else "nlml_wave_kernel",
                       avg_launch_ms=round(ms, 4), flop_per_cell=float(n_) ** 3 / 3.0, cells_per_launch=2500,
                       traffic=(ent or {}).get("fabric_bytes_per_call"), traffic_stale=stale,
                       algorithmic_bytes=(ent or {}).get("algorithmic_bytes_per_call"),
                       traffic_source=(f"committed PMC pass {ent['source']} (FETCH_SIZE x2 + WRITE_SIZE), not this run" if ent else None))
             if not fused:
-                rf["note"] = ("one workgroup per cell, the bordered matrix in LDS, one workgroup barrier + LDS round trip per "
-                              "column: bound by that latency chain (33 dependent steps), not by the matrix cores or HBM")
+                # N^2 / 2 fused multiply-adds per lane-instruction + two v_readlane each + the kernel entries' exp: counted as
+                # vector instructions against the fp64 issue rate (16 lanes per cycle and SIMD), the matrix cores are not used
+                instr = 2500.0 * (3.0 * n_ * n_ / 2.0 + n_ * (3.0 * d_ + 21.0) + 30.0 * n_)
+                rf["valu_wave_instructions_per_launch"] = instr
+                rf["valu_issue_frac"] = round(instr * 4.0 / (ms * 1e-3) / (1024 * 2.4e9), 4)
+                rf["note"] = ("one wave per cell, the cell's matrix in registers (lane = row), column steps unrolled with v_readlane "
+                              "broadcasts: bound by fp64 vector issue; frac is N^3/3 against the MATRIX peak for comparison with the "
+                              "larger sizes, valu_issue_frac the estimated wave instructions x 4 cycles against 1,024 SIMDs at 2.4 GHz")
             # CPU: the oracle's restatement of eval_log_marginal (inv + det per cell), all host cores, a sample of cells
             nc = 64 if n_ <= 176 else (16 if n_ <= 512 else 6)
             sel = np.linspace(0, 2499, nc).astype(int)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPBO_VERSION 150 /* 0.5.0: the likelihood grid of any N in one launch (one workgroup per cell), a second likelihood mode (log det from the factor: gpbo_nlml_grid_*logdet*) */
+#define GPBO_VERSION 151 /* 0.5.1: + gpbo_nlml_grid_wave_f64 / _wave_logdet_f64 (the likelihood grid of N <= 64 observations, a wave per cell); 0.5.0: the likelihood grid of any N in one launch (one workgroup per cell), a second likelihood mode (log det from the factor: gpbo_nlml_grid_*logdet*) */
 
 /* Environment switches the SHIPPED library reads (each once per process; none changes a result beyond the rounding of a
  * different summation order, none is needed for normal use - they select between measured alternatives for A/B runs):
@@ -332,7 +332,7 @@ int gpbo_acq_argmax_f64(const double *mu, const double *sigma, int64_t M, int32_
  *   info (host): 0, or the 1-based failing pivot (the reference's inv() raises LinAlgError or returns garbage) -
  *   then nothing is scored and result->best_idx = -1.
  * gpbo_nlml_grid_host_f64 = tune_kernel()'s float32 likelihood grid (point_selector.py:104-163): ls_cells [G x d]
- *   host, out [G] host float32; any N (the in-LDS kernel up to 32 observations, the one-launch workgroup-per-cell
+ *   host, out [G] host float32; any N (the wave-per-cell kernel up to 64 observations, the one-launch workgroup-per-cell
  *   kernel beyond). */
 /* (When mu_out, sigma_out and acq_out are all NULL, M >= 32768, N > 896 and the acquisition increases with sigma, the next
  * point is found by branch and bound on the exact prefix bound - gpbo_posterior_prefix_f64 / gpbo_bound_select_f64 below -
@@ -361,6 +361,17 @@ int gpbo_nlml_grid_logdet_host_f64(const double *X_host, const double *y_host, i
 int gpbo_nlml_grid_max_n(void);
 int gpbo_nlml_grid_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells, int64_t G,
                        double jitter, float *out, void *stream);
+
+/* The same grid at the reference's own sizes, N <= gpbo_nlml_grid_wave_max_n() (= 64): one WAVE per cell, the cell's
+ * matrix in registers (lane = row), the column steps unrolled with v_readlane broadcasts, y as a right-hand side
+ * (csrc/ard_wave.hip; ABI 151).  Same arguments and the same value per cell as gpbo_nlml_grid_f64 up to the rounding
+ * of another elimination order; a pivot that is not positive gives NaN (the reference's log(det < 0)).
+ * ..._wave_logdet_f64: the second likelihood mode (fp64 output, log det K straight from the factor: see below). */
+int gpbo_nlml_grid_wave_max_n(void);
+int gpbo_nlml_grid_wave_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells, int64_t G,
+                            double jitter, float *out, void *stream);
+int gpbo_nlml_grid_wave_logdet_f64(const double *X, const double *y, int64_t N, int32_t d, const double *ls_cells,
+                                   int64_t G, double jitter, double *out, void *stream);
 
 /* The same grid for ANY N, one launch: a persistent workgroup per cell runs a left-looking blocked Cholesky of the
  * cell's K (entries generated on the fly, the factor kept in MFMA fragment order in a scratch slot of the workspace,

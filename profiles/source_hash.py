@@ -11,7 +11,8 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 COMMON = ["kernel_build.hip", "exp_neg.h", "gpbo_internal.h"]
 SOURCES = {"f64": ["sigma_acq.hip"] + COMMON, "f64b": ["sigma_acq.hip", "kstar_mfma.hip", "rescore.hip"] + COMMON,
            "f32": ["posterior_f32.hip"] + COMMON, "i8": ["ozaki.hip"] + COMMON, "i8c": ["ozaki.hip"] + COMMON,
-           "ard": ["ard.hip", "potrf_diag64.h", "exp_neg.h", "gpbo_internal.h"]}
+           "ard": ["ard.hip", "potrf_diag64.h", "exp_neg.h", "gpbo_internal.h"],
+           "ard_wave": ["ard_wave.hip", "potrf_diag64.h", "exp_neg.h", "gpbo_internal.h"]}
 
 
 def kernel_source_hash(dtype: str) -> str:

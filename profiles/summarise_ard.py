@@ -23,7 +23,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"]) / REPS
-main = [k for k in t if "nlml_fused" in k or "nlml_grid_kernel" in k]
+main = [k for k in t if "nlml_fused" in k or "nlml_grid_kernel" in k or "nlml_wave_kernel" in k]
 main = max(main, key=lambda k: t[k][1]) if main else None
 if main:
     us = t[main][1] / REPS
@@ -73,7 +73,8 @@ if out and main and "FETCH_SIZE" in agg.get(main, {}):
         "mfma_busy_share_of_cycles": (c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0))
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c else None,
         "kernel_time_us_profiled": t[main][1] / REPS,
-        "kernel_source_hash": kernel_source_hash("ard"),
+        "hash_key": "ard_wave" if "nlml_wave" in main else "ard",
+        "kernel_source_hash": kernel_source_hash("ard_wave" if "nlml_wave" in main else "ard"),
     }
     json.dump(shapes, open(path, "w"), indent=1)
 if out:

@@ -22,7 +22,7 @@ def _header_functions():
 def test_library_is_built_and_loads_without_gpu():
     assert os.path.exists(_lib.LIB_PATH), "run bayesian_optimisation_amd/csrc/build.sh (or __graft_entry__.build())"
     lib = _lib.load()
-    assert lib.gpbo_version() == 150
+    assert lib.gpbo_version() == 151
     assert lib.gpbo_padded_n(1) == 128 and lib.gpbo_padded_n(128) == 128 and lib.gpbo_padded_n(129) == 256
     assert b"workspace" in lib.gpbo_strerror(-3)
 
@@ -45,7 +45,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.gpbo_posterior_workspace_bytes(128, 500, 10) == -1      # chunk not a multiple of 512
     assert lib.gpbo_posterior_workspace_bytes(128, 512, 1000) > 128 * 512 * 8
     assert lib.gpbo_factorise_workspace_bytes(256) == 8 * (2 * 256 * 256 + 256 * 64 + 256)
-    assert lib.gpbo_nlml_grid_max_n() == 176
+    assert lib.gpbo_nlml_grid_max_n() == 176 and lib.gpbo_nlml_grid_wave_max_n() == 64
 
 
 def test_every_compute_entry_point_rejects_null_arguments():
@@ -53,7 +53,7 @@ def test_every_compute_entry_point_rejects_null_arguments():
     import ctypes as C
 
     lib = _lib.load()
-    skip = {"gpbo_version", "gpbo_nlml_grid_max_n", "gpbo_gemm_f64",  # gemm: M = 0 is a valid empty product
+    skip = {"gpbo_version", "gpbo_nlml_grid_max_n", "gpbo_nlml_grid_wave_max_n", "gpbo_gemm_f64",  # gemm: M = 0 is a valid empty product
             "gpbo_profile_create", "gpbo_profile_read", "gpbo_profile_read_kstar", "gpbo_profile_read_qei", "gpbo_profile_reset",
             "gpbo_profile_destroy"}
     checked = 0
@@ -100,6 +100,7 @@ def test_size_contracts_are_checked_on_the_host():
     assert lib.gpbo_trtri_f64(p, p, 100, p, p, None) == -1
     # ARD grid: N beyond the in-LDS limit
     assert lib.gpbo_nlml_grid_f64(p, p, 177, 2, p, 4, 1e-4, p, None) == -1
+    assert lib.gpbo_nlml_grid_wave_f64(p, p, 65, 2, p, 4, 1e-4, p, None) == -1 and lib.gpbo_nlml_grid_wave_f64(p, p, 8, 17, p, 4, 1e-4, p, None) == -1
     # fused factorisation: S is read by 16-byte LDS-DMA pieces - an 8-byte-offset view is refused, as are an odd or short ld
     p8 = C.c_void_p(p.value + 8)
     assert lib.gpbo_cholinv_f64(p8, 512, 256, p, None, None) == -1

@@ -78,9 +78,9 @@ def test_default_line_is_the_metric_configuration_and_matches_the_cpu_port():
     assert line["roofline"]["kstar"]["kernel"] == "kstar_mu_kernel" and 0.3 < line["roofline"]["kstar"]["frac"] <= 1.0
     ag = line["also"]["ard_grid"]
     assert [e["roofline"]["cells_per_launch"] for e in ag] == [2500] * 5 and all(e["cpu_baseline"]["value"] > 0 for e in ag)
-    # (N = 32 in LDS; N = 64, 176, 512, 1024 through the fused kernel: one panel at N = 64, 0.02 of the matrix peak)
-    assert ag[0]["roofline"]["bound"] == "latency" and all(e["roofline"]["bound"] == "mfma" and 0.005 < e["roofline"]["frac"] <= 1.0 for e in ag[1:])
-    assert all(e["roofline"]["frac"] > 0.05 for e in ag[2:])
+    # (N = 32, 64: the wave-per-cell kernel, vector-issue-bound; N = 176, 512, 1024: the fused kernel on the matrix cores)
+    assert all(e["roofline"]["bound"] == "valu" and e["roofline"]["kernel"] == "nlml_wave_kernel" and 0.02 < e["roofline"]["valu_issue_frac"] <= 1.0 for e in ag[:2])
+    assert all(e["roofline"]["bound"] == "mfma" and 0.05 < e["roofline"]["frac"] <= 1.0 for e in ag[2:])
     assert all(e["finite_cells_logdet_mode"] == 2500 and e["logdet_mode_max_rel_err_vs_oracle_on_sample"] <= 1e-9 for e in ag)
     assert all(e["reference_mode_matches_oracle_where_finite"] in (True, None) for e in ag)
     ap = line["also"]["append"]

@@ -256,6 +256,70 @@ def test_nlml_batched_cholesky_agrees_with_the_in_lds_kernel(env, N, d):
     np.testing.assert_allclose(b[fin], a[fin], rtol=3e-6, atol=1e-4)
 
 
+def _nlml_wave(gp, X, y, cells, jitter=1e-4):
+    torch = gp.torch
+    Xd, yd, cd = gp._dev(X), gp._dev(y), gp._dev(cells)
+    out = torch.empty(cells.shape[0], dtype=torch.float32, device=gp.device)
+    st = gp.lib.gpbo_nlml_grid_wave_f64(gp._ptr(Xd), gp._ptr(yd), X.shape[0], X.shape[1], gp._ptr(cd), cells.shape[0], jitter,
+                                        gp._ptr(out), gp._stream())
+    assert st == 0
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 15, 16, 17, 24, 31, 32, 33, 40, 47, 48, 49, 57, 63, 64])
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 11, 16])
+def test_nlml_wave_kernel_vs_oracle_and_the_in_lds_kernel(env, N, d):
+    """The wave-per-cell kernel of the reference's own sizes (csrc/ard_wave.hip, N <= 64): the reference's formula (oracle
+    nlml_cells: inv + det) to float32 rounding, the in-LDS kernel's values, the same first minimum, the log-det mode against
+    the oracle's Cholesky form; every template instance (16 / 32 / 48 / 64 rows x 2 / 4 / 8 / 16 features), cell counts that do
+    not fill the last workgroup."""
+    from bayesian_optimisation_amd import DeviceGP
+
+    X, y, _, _ = make_problem(N, 8, d)
+    rng = np.random.default_rng(100 * N + d)
+    G = int(rng.integers(1, 400))
+    cells = np.exp(rng.uniform(np.log(0.05), np.log(5.0), size=(G, d)))
+    gp = DeviceGP()
+    w = _nlml_wave(gp, X, y, cells)
+    a = _nlml_direct(gp, X, y, cells, batched=False)
+    ref = O.nlml_cells(X, y, cells)
+    assert w.dtype == np.float32 and np.isfinite(w).all() and np.isfinite(ref).all()
+    np.testing.assert_allclose(w, ref, rtol=3e-6, atol=1e-5)
+    np.testing.assert_allclose(w, a, rtol=3e-6, atol=1e-5)
+    if G == 1 or np.ptp(np.sort(ref)[:2]) > 1e-4 * max(1.0, abs(ref.min())):
+        assert int(np.argmin(w)) == int(np.argmin(ref))
+    # DeviceGP routes these sizes to it, in both likelihood modes
+    np.testing.assert_array_equal(gp.nlml_grid(X, y, cells), w)
+    ld = gp.nlml_grid(X, y, cells, likelihood="logdet")
+    want = O.nlml_cells_logdet(X, y, cells)
+    assert ld.dtype == np.float64
+    np.testing.assert_allclose(ld, want, rtol=1e-10, atol=1e-9 * N)
+
+
+def test_nlml_wave_kernel_edge_cases(env):
+    """A pivot that is not positive gives NaN (the reference's log(det < 0)), NaN observations give NaN, and 2,600 cells that
+    are 200 copies of 13 give the bits of the first copy."""
+    from bayesian_optimisation_amd import DeviceGP
+
+    gp = DeviceGP()
+    rng = np.random.default_rng(5)
+    X = rng.uniform(0, 1, (20, 3))
+    y = rng.standard_normal(20)
+    cells = np.array([[0.5, 0.5, 0.5], [2.0, 1.0, 3.0]])
+    assert np.isnan(_nlml_wave(gp, X, y, cells, jitter=-2.0)).all()      # K - 2 I: the first pivot is -1
+    assert np.isfinite(_nlml_wave(gp, X, y, cells)).all()
+    Xn = rng.uniform(0, 1, (12, 2))
+    yn = rng.standard_normal(12)
+    yn[5] = np.nan
+    assert np.isnan(_nlml_wave(gp, Xn, yn, np.array([[0.3, 0.3]]))).all()
+    Xd_ = 0.5 + 0.02 * rng.standard_normal((32, 16))
+    yd_ = 0.1 * rng.standard_normal(32)
+    base = np.exp(rng.uniform(np.log(0.02), np.log(20.0), size=(13, 16)))
+    for rep in range(3):
+        o = _nlml_wave(gp, Xd_, yd_, np.tile(base, (200, 1))).reshape(200, 13)
+        assert np.array_equal(o, np.tile(o[0], (200, 1)), equal_nan=True), rep
+
+
 @pytest.mark.parametrize("N,d,G", [(300, 2, 90), (512, 3, 64), (700, 8, 40), (1030, 2, 12)])
 def test_nlml_batched_large_n_vs_oracle(env, N, d, G):
     """Beyond the LDS kernel: the reference's formula (inv + det, oracle nlml_cells) where its det is a normal number,

@@ -17,6 +17,7 @@ for N in (16, 32, 48, 64, 65, 72, 80, 96, 112, 128, 144, 160, nmax):
     X, y, _, _ = make_problem(N, 8, d)
     Xd, yd, cd = gp._dev(X), gp._dev(y), gp._dev(cells)
     res = []
+    gp.ARD_KERNEL = "lds"          # (the default, "wave", serves N <= 64 with the wave-per-cell kernel: third column)
     for thr in (0, nmax):          # 0: always the fused kernel; nmax: the in-LDS kernel
         gp.ARD_LDS_MAX_N = thr
         out = gp.nlml_grid_device(Xd, yd, cd)
@@ -30,4 +31,17 @@ for N in (16, 32, 48, 64, 65, 72, 80, 96, 112, 128, 144, 160, nmax):
         res.append((e0.elapsed_time(e1) / 10, out.double().cpu().numpy()))
     fin = np.isfinite(res[0][1]) & np.isfinite(res[1][1])
     dv = float(np.max(np.abs(res[0][1][fin] - res[1][1][fin]) / np.maximum(1.0, np.abs(res[1][1][fin])))) if fin.any() else float("nan")
-    print(f"d={d} N={N}: fused {res[0][0]:.3f} ms, in-LDS {res[1][0]:.3f} ms, max rel. difference of the float32 cells {dv:.1e}", flush=True)
+    wv = ""
+    if N <= int(gp.lib.gpbo_nlml_grid_wave_max_n()):
+        gp.ARD_KERNEL = "wave"
+        w = gp.nlml_grid_device(Xd, yd, cd)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            gp.nlml_grid_device(Xd, yd, cd)
+        e1.record()
+        torch.cuda.synchronize()
+        wn = w.double().cpu().numpy()
+        wv = f", wave {e0.elapsed_time(e1) / 10:.3f} ms ({int((wn == res[0][1]).sum())} of 2,500 float32 cells equal to the fused kernel's)"
+    print(f"d={d} N={N}: fused {res[0][0]:.3f} ms, in-LDS {res[1][0]:.3f} ms, max rel. difference of the float32 cells {dv:.1e}{wv}", flush=True)

@@ -21,7 +21,7 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "bayesian_optimisation_amd", "csrc")
 UNITS = ["kernel_build", "kstar_mfma", "gemm_f64", "factor", "cholinv", "subset", "update", "sigma_acq", "ard",
-         "posterior_f32", "rescore", "ozaki"]
+         "ard_wave", "posterior_f32", "rescore", "ozaki"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
