@@ -14,7 +14,7 @@ mkdir -p "$OUT"
 cd "$ROOT/bayesian_optimisation_amd/csrc"
 pids=()
 objs=""
-for f in api kernel_build kstar_mfma gemm_f64 factor cholinv subset update sigma_acq ard posterior_f32 rescore ozaki host_api; do
+for f in api kernel_build kstar_mfma gemm_f64 factor cholinv subset update sigma_acq ard ard_wave posterior_f32 rescore ozaki host_api; do
   $HIPCC $FLAGS -c $f.hip -o "$OUT/$f.o" &
   pids+=($!)
   objs="$objs $OUT/$f.o"
