@@ -49,12 +49,13 @@ __global__ __launch_bounds__(256, NMAX > 32 ? 2 : (D == 16 ? 3 : 4)) void nlml_w
     const int g = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // this wave's cell
     if (g >= G) return;
 
+    const int li = ((NMAX & (NMAX - 1)) == 0) ? (lane & (NMAX - 1)) : (lane >= NMAX ? lane - NMAX : lane);   // a row < NMAX for every lane
     double il2[D], xi[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         const double l = (k < d) ? ls_cells[(int64_t)g * d + k] : 1.0;        // wave-uniform
         il2[k] = (k < d) ? 1.0 / (l * l) : 0.0;
-        xi[k] = Xs[(lane < NMAX ? lane : 0) * D + k];                         // this lane's row
+        xi[k] = Xs[li * D + k];                                               // this lane's row
     }
     // K[i][k] for the lane's row i: column k's coordinates are wave-uniform (one LDS address for the wave)
     double x[NMAX];
@@ -73,7 +74,10 @@ __global__ __launch_bounds__(256, NMAX > 32 ? 2 : (D == 16 ? 3 : 4)) void nlml_w
         // two entries in flight at a time: left to itself the scheduler starts all NMAX chains at once (264 registers)
         if (k & 1) __builtin_amdgcn_sched_barrier(0);
     }
-    double b = (lane < NMAX) ? ys[lane < NMAX ? lane : 0] : 0.0;
+    // (a plain load and a select: written as one conditional expression, the register allocation of the WHOLE kernel
+    //  collapses - 124 spilled registers at NMAX = 32 - and the launch moves 157 MB of scratch)
+    double b = ys[li];
+    if (lane >= NMAX) b = 0.0;
 
     double quad = 0.0, lcc = 1.0;
     bool bad = false;

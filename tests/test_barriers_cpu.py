@@ -61,3 +61,18 @@ def test_no_barrier_of_the_shipped_kernels_is_reachable_with_an_lds_write_in_fli
     out = capsys.readouterr().out
     assert rc == 0, out
     assert "0 reachable" in out
+
+
+@pytest.mark.skipif(shutil.which(cb.HIPCC) is None and not os.path.exists(cb.HIPCC), reason="hipcc not installed")
+def test_the_wave_per_cell_likelihood_kernel_keeps_its_matrix_in_registers(tmp_path):
+    """csrc/ard_wave.hip holds a cell's matrix in registers; its register allocation proved fragile (one conditional load
+    written differently spilled 124 registers at NMAX = 32 and the launch moved 157 MB of scratch, 0.026 -> 0.045 ms): no
+    instance may need more than a few bytes of scratch."""
+    import re
+
+    s = open(cb.assemble("ard_wave", str(tmp_path))).read()
+    sizes = {re.search(r"\.name:\s+(\S+)", b).group(1): int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", b).group(1))
+             for b in s.split("  - .agpr_count:")[1:]}
+    waves = {k: v for k, v in sizes.items() if "nlml_wave_kernel" in k}
+    assert len(waves) == 16, sorted(sizes)
+    assert max(waves.values()) <= 16, waves
