@@ -133,9 +133,10 @@ def test_replayed_pmc_figures_belong_to_todays_kernel_sources():
     assert e is not None and stale is False
     # ... and the likelihood grid's entries (profiles/pmc_ard.json, profiles/collect_ard.sh) likewise
     ard = json.load(open(os.path.join(repo, "profiles", "pmc_ard.json")))
-    assert {"N=176,d=2,cells=2500", "N=512,d=8,cells=2500", "N=1024,d=8,cells=2500"} <= set(ard)
+    assert {"N=32,d=2,cells=2500", "N=64,d=2,cells=2500", "N=176,d=2,cells=2500", "N=512,d=8,cells=2500", "N=1024,d=8,cells=2500"} <= set(ard)
+    assert ard["N=32,d=2,cells=2500"]["hash_key"] == ard["N=64,d=2,cells=2500"]["hash_key"] == "ard_wave"   # (the wave-per-cell kernel)
     for key, e in ard.items():
-        assert e["kernel_source_hash"] == sh.kernel_source_hash("ard"), \
+        assert e["kernel_source_hash"] == sh.kernel_source_hash(e.get("hash_key", "ard")), \
             f"{key}: ard.hip changed since {e['source']} was collected: re-run profiles/collect_ard.sh + summarise_ard.py"
     e, stale = bench._pmc_ard_entry(512, 8)
     assert e is not None and stale is False
