@@ -1,3 +1,5 @@
+"""The wave-per-cell likelihood kernel (csrc/ard_wave.hip) at N = 33 ... 64 called through the ABI: kernel time (2,500 cells,
+HIP events), float32 cells against the fused kernel's and against the oracle on a sample.  usage: python tools/wave64_check.py"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
